@@ -1,0 +1,274 @@
+"""Generate tests/golden/* by running the REFERENCE itself (imported from /root/reference).
+
+Run only in the build container (the GPU box has no /root/reference):
+
+    PYTHONDONTWRITEBYTECODE=1 python -m oracle.gen_golden
+
+The fixtures are data (inputs + the reference's outputs); no reference source is stored.
+cv2 / ipdb / kornia are absent from the image: cv2 and ipdb are stubbed with inert
+modules, kornia with the three functions restated in oracle/hfit_ref.py (third-party,
+parity unpinned -- see that file's header).  'cuda' device strings are mapped to 'cpu'.
+"""
+import json
+import os
+import sys
+import types
+from pathlib import Path
+from types import SimpleNamespace
+from unittest import mock
+
+sys.dont_write_bytecode = True
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+from oracle import hfit_ref  # noqa: E402
+from woft_amd import synth  # noqa: E402
+
+GOLD = ROOT / "tests" / "golden"
+REF = Path("/root/reference")
+
+
+def install_stubs():
+    sys.modules["cv2"] = mock.MagicMock(name="cv2")
+    ipdb = types.ModuleType("ipdb")
+    ipdb.iex = lambda f: f
+    ipdb.post_mortem = lambda *a, **k: None
+    sys.modules["ipdb"] = ipdb
+    names = ["kornia", "kornia.geometry", "kornia.geometry.epipolar",
+             "kornia.geometry.conversions", "kornia.geometry.homography"]
+    mods = {n: types.ModuleType(n) for n in names}
+    mods["kornia"].geometry = mods["kornia.geometry"]
+    mods["kornia.geometry"].epipolar = mods["kornia.geometry.epipolar"]
+    mods["kornia.geometry"].conversions = mods["kornia.geometry.conversions"]
+    mods["kornia.geometry"].homography = mods["kornia.geometry.homography"]
+    mods["kornia.geometry.epipolar"].normalize_points = hfit_ref.normalize_points
+    mods["kornia.geometry.conversions"].convert_points_to_homogeneous = hfit_ref.to_homogeneous
+    mods["kornia.geometry.conversions"].convert_points_from_homogeneous = hfit_ref.from_homogeneous
+    sys.modules.update(mods)
+    _t, _m = torch.Tensor.to, torch.nn.Module.to
+
+    def fix(a):
+        return tuple("cpu" if isinstance(x, str) and x.startswith("cuda") else x for x in a)
+
+    def fixk(k):
+        return {kk: ("cpu" if kk == "device" and isinstance(v, str) and v.startswith("cuda") else v)
+                for kk, v in k.items()}
+    torch.Tensor.to = lambda self, *a, **k: _t(self, *fix(a), **fixk(k))
+    torch.nn.Module.to = lambda self, *a, **k: _m(self, *fix(a), **k)
+    sys.path[:0] = [str(REF), str(REF / "pytracking/external/RAFT")]
+
+
+class FakeCuda(torch.Tensor):
+    is_cuda = property(lambda s: True)
+
+
+def ref_args(small, weighted=True):
+    return SimpleNamespace(small=small, mixed_precision=False, alternate_corr=False,
+                           weight_head_structure=[(128, 3)] * 3, mask_estimation=False)
+
+
+def pair(H, W, seed, shift=(3, -2)):
+    """Two related uint8 BGR images: a smooth-ish texture and a shifted + perturbed copy."""
+    t = synth.make_template(H + 16, W + 16, seq_id=seed)
+    a = t[8:8 + H, 8:8 + W]
+    b = t[8 + shift[1]:8 + shift[1] + H, 8 + shift[0]:8 + shift[0] + W]
+    rs = np.random.RandomState(seed)
+    b = np.clip(b.astype(np.int32) + rs.randint(-6, 7, b.shape), 0, 255).astype(np.uint8)
+    return np.ascontiguousarray(a), np.ascontiguousarray(b)
+
+
+def to_t(a):
+    return torch.from_numpy(a[:, :, ::-1].copy()).permute(2, 0, 1).float()[None]
+
+
+@torch.no_grad()
+def gen_flow():
+    from raft_core.weighted_raft import WeightedRAFT
+    from raft_core.raft import RAFT
+    from raft_core.corr import CorrBlock
+
+    keys = {}
+    # ---- full weighted model ------------------------------------------------------
+    sd = synth.make_state_dict(seed=7, small=False, weighted=True)
+    net = WeightedRAFT(ref_args(False)).eval()
+    net.load_state_dict(sd, strict=True)
+    keys["weighted_full"] = {k: list(v.shape) for k, v in net.state_dict().items()}
+    keys["weighted_full_nparams"] = int(sum(p.numel() for p in net.parameters()))
+
+    # case A: 128x160, 4 iters, with intermediates
+    a, b = pair(128, 160, seed=11)
+    i1, i2 = to_t(a), to_t(b)
+    flow_low, flow_up, vol, w_low, w_up = net(i1, i2, iters=4, test_mode=True)
+    n1 = 2 * (i1 / 255.0) - 1.0
+    n2 = 2 * (i2 / 255.0) - 1.0
+    f1, f2 = net.fnet([n1, n2])
+    cb = CorrBlock(f1.float(), f2.float(), radius=4, num_levels=4)
+    c = net.cnet(n1)
+    h0, inp = torch.tanh(c[:, :128]), torch.relu(c[:, 128:])
+    from raft_core.utils.utils import coords_grid
+    coords0 = coords_grid(1, 16, 20, device="cpu")
+    look0 = cb(coords0)
+    net1, mask1, d1 = net.update_block(h0, inp, look0, coords0 - coords0)
+    np.savez_compressed(
+        GOLD / "flow_full_128x160_it4.npz", img1=a, img2=b, seed=7, iters=4,
+        flow_low=flow_low.numpy(), flow_up=flow_up.numpy(), w_low=w_low.numpy(), w_up=w_up.numpy(),
+        fmap1=f1.numpy(), fmap2=f2.numpy(), net0=h0.numpy(), inp=inp.numpy(),
+        pyr0_rows=cb.corr_pyramid[0][:24, 0].numpy(), pyr1_rows=cb.corr_pyramid[1][:24, 0].numpy(),
+        pyr2_rows=cb.corr_pyramid[2][:24, 0].numpy(), pyr3_rows=cb.corr_pyramid[3][:24, 0].numpy(),
+        lookup0=look0.numpy(), net1=net1.numpy(), mask1=mask1.numpy(), delta1=d1.numpy())
+
+    # case B: 136x200 (odd pyramid sizes 17x25 -> 8x12 -> 4x6 -> 2x3), 12 iters, outputs only
+    a, b = pair(136, 200, seed=12, shift=(-4, 3))
+    flow_low, flow_up, vol, w_low, w_up = net(to_t(a), to_t(b), iters=12, test_mode=True)
+    np.savez_compressed(GOLD / "flow_full_136x200_it12.npz", img1=a, img2=b, seed=7, iters=12,
+                        flow_low=flow_low.numpy(), flow_up=flow_up.numpy(),
+                        w_low=w_low.numpy(), w_up=w_up.numpy())
+
+    # ---- small plain RAFT (config 1 family) -----------------------------------------
+    sds = synth.make_state_dict(seed=8, small=True, weighted=False)
+    nets = RAFT(ref_args(True)).eval()
+    nets.load_state_dict(sds, strict=True)
+    keys["plain_small"] = {k: list(v.shape) for k, v in nets.state_dict().items()}
+    keys["plain_small_nparams"] = int(sum(p.numel() for p in nets.parameters()))
+    a, b = pair(128, 160, seed=13)
+    fl, fu = nets(to_t(a), to_t(b), iters=4, test_mode=True)
+    np.savez_compressed(GOLD / "flow_small_128x160_it4.npz", img1=a, img2=b, seed=8, iters=4,
+                        flow_low=fl.numpy(), flow_up=fu.numpy())
+
+    # ---- small weighted RAFT ---------------------------------------------------------
+    sdw = synth.make_state_dict(seed=9, small=True, weighted=True)
+    netw = WeightedRAFT(ref_args(True)).eval()
+    netw.load_state_dict(sdw, strict=True)
+    keys["weighted_small"] = {k: list(v.shape) for k, v in netw.state_dict().items()}
+    fl, fu, _, wl, wu = netw(to_t(a), to_t(b), iters=4, test_mode=True)
+    np.savez_compressed(GOLD / "flow_wsmall_128x160_it4.npz", img1=a, img2=b, seed=9, iters=4,
+                        flow_low=fl.numpy(), flow_up=fu.numpy(), w_low=wl.numpy(), w_up=wu.numpy())
+
+    (GOLD / "state_dict_keys.json").write_text(json.dumps(keys, indent=0))
+
+    # ---- lookup-only cases on hand-made pyramids --------------------------------------
+    rs = np.random.RandomState(5)
+    h1, w1 = 6, 7
+    P = h1 * w1
+    H2, W2 = 17, 25
+    ramp = (100.0 * np.arange(H2)[:, None] + np.arange(W2)[None, :]).astype(np.float32)
+    vol0 = np.tile(ramp[None, None], (P, 1, 1, 1)) + rs.uniform(-1, 1, (P, 1, H2, W2)).astype(np.float32)
+    vol0[0, 0] = ramp                                   # row 0: pure ramp pins the x-major window order
+    cbk = CorrBlock.__new__(CorrBlock)
+    cbk.num_levels, cbk.radius = 4, 4
+    v = torch.from_numpy(vol0)
+    cbk.corr_pyramid = [v]
+    for _ in range(3):
+        v = torch.nn.functional.avg_pool2d(v, 2, stride=2)
+        cbk.corr_pyramid.append(v)
+    coords = np.stack([rs.uniform(-6, W2 + 5, (h1, w1)), rs.uniform(-6, H2 + 5, (h1, w1))], 0).astype(np.float32)
+    coords[:, 0, 0] = (8.0, 6.0)                       # on-grid probe
+    coords[:, 0, 1] = (8.25, 6.5)
+    coords[:, 0, 2] = (-3.5, -2.25)                    # negative / partly outside
+    coords[:, 0, 3] = (W2 + 3.0, H2 + 2.0)             # fully beyond the border at level 0
+    out = cbk(torch.from_numpy(coords)[None])
+    np.savez_compressed(GOLD / "lookup_handmade.npz", vol0=vol0, coords=coords, out=out.numpy(), radius=4)
+
+
+@torch.no_grad()
+def gen_wrapper():
+    """Operator boundary: RAFTWrapper.compute_flow through the reference's own config loader."""
+    from pytracking.utils.config import load_config
+    import tempfile
+    fc = load_config(REF / "pytracking/optical_flow/configs/v2_SNOB_large_g05_RAFT.py")
+    fc.weights_postprocessing_fn = None
+    sd = synth.make_state_dict(seed=7, small=False, weighted=True)
+    with tempfile.TemporaryDirectory() as td:
+        fc.model = os.path.join(td, "sd.pth")
+        torch.save(sd, fc.model)
+        fc.iters = 4
+        flower = fc.of_class(fc)
+        a, b = pair(128, 160, seed=11)
+        src, dst, w = flower.compute_flow(a, b, mode="TC", do_sigmoid=True)
+        fl, wf = flower.compute_flow(a, b, mode="flow", do_sigmoid=False)
+        # RAFT replicate padding on a non-multiple-of-8 input
+        fc.padding_mode = "RAFT"
+        a2, b2 = a[:125, :157].copy(), b[:125, :157].copy()
+        src2, dst2, w2 = flower.compute_flow(a2, b2, mode="TC", do_sigmoid=True)
+    np.savez_compressed(GOLD / "wrapper_tc_128x160_it4.npz", img1=a, img2=b, seed=7, iters=4,
+                        src=src.numpy(), dst=dst.numpy(), w=w.numpy(), flow=fl.numpy(), w_logit=wf.numpy(),
+                        src_pad=src2.numpy(), dst_pad=dst2.numpy(), w_pad=w2.numpy())
+
+
+@torch.no_grad()
+def gen_hfit():
+    import pytracking.utils.least_squares_H as L
+    import pytracking.utils.geom_utils as G
+    out = {}
+    rs = np.random.RandomState(3)
+
+    def make(N, outlier_frac=0.1, noise=0.3, degenerate=False):
+        Hgt = np.array([[1.02, 0.03, 12.0], [-0.02, 0.98, -7.0], [2e-5, -1e-5, 1.0]])
+        a = np.stack([rs.uniform(100, 1800, N), rs.uniform(80, 1000, N)], 1)
+        if degenerate:
+            a[:, 1] = 300 + 0.001 * a[:, 0] + rs.uniform(-0.5, 0.5, N)
+        ah = np.concatenate([a, np.ones((N, 1))], 1) @ Hgt.T
+        b = ah[:, :2] / ah[:, 2:] + rs.normal(0, noise, (N, 2))
+        no = int(outlier_frac * N)
+        if no:
+            b[:no] += rs.uniform(-80, 80, (no, 2))
+        w = rs.uniform(0.05, 1.0, N)
+        w[:no] *= 0.2
+        return (torch.from_numpy(a.astype(np.float32))[None], torch.from_numpy(b.astype(np.float32))[None],
+                torch.from_numpy(w.astype(np.float32))[None])
+
+    for name, N, kw in (("n4", 4, dict(outlier_frac=0.0, noise=0.0)), ("n500", 500, {}),
+                        ("n4096", 4096, {}), ("degen", 300, dict(degenerate=True, outlier_frac=0.0))):
+        a, b, w = make(N, **kw)
+        out[f"{name}_a"], out[f"{name}_b"], out[f"{name}_w"] = a.numpy(), b.numpy(), w.numpy()
+        out[f"{name}_qr_w"] = L.find_homography_nonhomogeneous_QR(a, b, w).numpy()
+        out[f"{name}_qr_now"] = L.find_homography_nonhomogeneous_QR(a, b, None).numpy()
+        ac = a.as_subclass(FakeCuda)
+        out[f"{name}_irls_l1"] = torch.Tensor(L.find_homography_IRLSq_QR(ac, b, w)).numpy()
+        out[f"{name}_irls_huber2"] = torch.Tensor(L.find_homography_IRLSq_QR(
+            ac, b, w, reweighting_fn=lambda r: L.IRLSq_Huber(r, k=2))).numpy()
+        out[f"{name}_irls_huber001"] = torch.Tensor(L.find_homography_IRLSq_QR(
+            ac, b, w, reweighting_fn=lambda r: L.IRLSq_Huber(r, k=0.01))).numpy()
+        Hq = torch.from_numpy(out[f"{name}_qr_w"])
+        out[f"{name}_projerr"] = L.torch_proj_errors(Hq, a.permute(0, 2, 1), b.permute(0, 2, 1)).numpy()
+    r = torch.from_numpy(np.linspace(-3, 3, 25).astype(np.float32))
+    out["huber_in"] = r.numpy()
+    out["huber_k1"] = L.IRLSq_Huber(r.clone(), k=1).numpy()
+    out["l1"] = L.IRLSq_L1(r.clone()).numpy()
+    H1 = np.array([[1, 0.1, 3], [0, 1.1, -2], [1e-4, 0, 1.0]])
+    H2 = np.array([[0.9, 0, 1], [0.05, 1, 4], [0, 2e-4, 1.2]])
+    out["compose_in1"], out["compose_in2"] = H1, H2
+    out["compose_12"] = G.compose_H(H1, H2)
+    out["compose_121"] = G.compose_H(H1, H2, H1)
+    np.savez_compressed(GOLD / "hfit.npz", **out)
+
+    # Sobol subsampler of the default config, run through the reference config module itself
+    from pytracking.utils.config import load_config  # noqa: F401
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "woftcfg", REF / "pytracking/configs/YAOFT_single_control_repRAFT_sub500_noreliableinl_wLSq.py")
+    cfg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cfg)
+    sob = {}
+    for N in (400, 501, 600, 2000, 518400):
+        idx = torch.arange(N)[None].float()
+        a, _, _ = cfg.subsampler(idx, idx, torch.ones(1, N))
+        sob[f"n{N}"] = a[0].numpy().astype(np.int64)
+    np.savez_compressed(GOLD / "sobol.npz", **sob)
+
+
+def main():
+    GOLD.mkdir(parents=True, exist_ok=True)
+    install_stubs()
+    torch.manual_seed(0)
+    gen_flow()
+    gen_wrapper()
+    gen_hfit()
+    for p in sorted(GOLD.iterdir()):
+        print(f"{p.name:40s} {p.stat().st_size/1024:9.1f} KB")
+
+
+if __name__ == "__main__":
+    main()
