@@ -1,0 +1,176 @@
+/* woft_hip.h -- C ABI of libwoft_hip.so: the MI355X (gfx950) kernels of the WOFT hot path.
+ *
+ * Conventions:
+ *   - every entry point is extern "C", takes plain device pointers / sizes, enqueues on the
+ *     hipStream_t passed as `stream` (void*), never allocates, never synchronises;
+ *   - the caller owns every buffer (PyTorch caching allocator in the Python host);
+ *   - return 0 on success, WOFT_EINVAL (-1) for a rejected argument, WOFT_ELAUNCH (-2) when
+ *     hipGetLastError() reports a launch failure.  No C++ exceptions cross the ABI.
+ *   - activations are NHWC fp32 with an explicit channel stride ("cs", floats per pixel).
+ *
+ * Each entry point cites the reference code it replaces (paths relative to
+ * /root/reference/pytracking/).
+ */
+#ifndef WOFT_HIP_H
+#define WOFT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WOFT_OK 0
+#define WOFT_EINVAL (-1)
+#define WOFT_ELAUNCH (-2)
+
+/* ABI / build identification: returns 10000*major + 100*minor + patch. */
+int woft_abi_version(void);
+/* sizeof(woft_conv_params) (which = 0) / sizeof(woft_lookup_params) (which = 1): layout check for FFI mirrors. */
+int woft_sizeof(int which);
+
+/* ---------------------------------------------------------------------------------------
+ * Implicit-GEMM convolution on f32-input MFMA (v_mfma_f32_32x32x2_f32), NHWC.
+ * Replaces every nn.Conv2d on the path: external/RAFT/raft_core/extractor.py:10-45,127-147,
+ * update.py:9-10,19-21,36-42,82-86,118-125, weighted_raft.py:336-341 -- and, used as an
+ * NT GEMM, the all-pairs correlation torch.matmul of corr.py:62-69.
+ * ------------------------------------------------------------------------------------- */
+enum woft_epilogue {
+    WOFT_EPI_LINEAR = 0,        /* y = alpha*acc + bias                                      */
+    WOFT_EPI_RELU = 1,          /* relu(y)                                                   */
+    WOFT_EPI_SIGMOID = 2,
+    WOFT_EPI_TANH = 3,
+    WOFT_EPI_RELU_RES_RELU = 4, /* relu(e0[m][n] + relu(y))   residual block, extractor.py:48-56 */
+    WOFT_EPI_GRU_ZR = 5,        /* n <  split: out[m][n]   = sigmoid(y)            (z)
+                                   n >= split: out1[m][n-split] = sigmoid(y) * e0[m][n-split] (r*h)
+                                   update.py:47-50 */
+    WOFT_EPI_GRU_Q = 6,         /* out = (1-z)*h + z*tanh(y), h = e0, z = e1   update.py:50-51 */
+    WOFT_EPI_CTX = 7            /* n < split: tanh(y) else relu(y)   weighted_raft.py:217-219   */
+};
+
+typedef struct woft_conv_params {
+    const float* in0;      /* source of input channels [0, c_split)                            */
+    const float* in1;      /* source of input channels [c_split, cin_pad) or NULL              */
+    int32_t cs0, cs1;      /* floats per pixel of in0 / in1                                    */
+    int32_t c_split;       /* multiple of 32; == cin_pad when in1 is NULL                      */
+    int32_t n_img, h, w;   /* input batch and spatial size                                     */
+    int32_t ho, wo;        /* output spatial size                                              */
+    int32_t taps_y, taps_x;/* kernel taps (flat mode: taps_x must be 1)                        */
+    int32_t stride, pad_y, pad_x;
+    int32_t cin_pad;       /* GEMM-K per tap, multiple of 32                                   */
+    int32_t flat;          /* 1: the 32-float K chunk of a tap runs along x over 32/cs0 pixels */
+    const float* wgt;      /* [cout_pad][taps_y*taps_x*cin_pad], K contiguous                  */
+    const float* bias;     /* [cout_pad] or NULL                                               */
+    float alpha;           /* scale applied to the accumulator                                 */
+    int32_t cout;          /* valid output channels                                            */
+    int32_t cout_pad;      /* rows of wgt, multiple of the N tile (64 or 128)                  */
+    float* out;            /* out[m*ldo + co_off + col(n)]                                     */
+    int64_t ldo;
+    int32_t co_off;
+    int32_t out_w, out_pitch; /* if out_pitch != 0: col(n) = (n / out_w)*out_pitch + n % out_w  */
+    int32_t epi;           /* enum woft_epilogue                                               */
+    int32_t split;         /* channel split of GRU_ZR / CTX                                    */
+    const float* e0;       /* epilogue operand (residual / h), row stride lde0                 */
+    const float* e1;       /* epilogue operand (z), row stride lde1                            */
+    int32_t lde0, lde1;
+    float* out1;           /* second output of GRU_ZR, row stride ldo1                         */
+    int32_t ldo1;
+    float* stat_sum;       /* optional [2*ceil(M/BM)][cout_pad] per-wave-row partial sums of y */
+    float* stat_sq;        /*          ... and of y*y  (InstanceNorm statistics)               */
+    int32_t tile_m, tile_n;/* block tile: 128 or 64 each                                       */
+} woft_conv_params;
+
+int woft_conv2d(const woft_conv_params* p, void* stream);
+
+/* InstanceNorm (extractor.py:28-32,129-130; nn.InstanceNorm2d eps=1e-5, biased variance):
+ * finalize per-channel statistics from the conv epilogue's partial sums ... */
+int woft_inorm_finalize(const float* stat_sum, const float* stat_sq, int32_t n_part, int32_t ld,
+                        int32_t channels, int64_t count, float eps,
+                        float* mean, float* rstd, void* stream);
+/* ... and apply them.  mode 0: (x-mean)*rstd ; 1: relu(.) ; 2: relu(res + relu(.)) */
+int woft_inorm_apply(const float* x, const float* mean, const float* rstd, const float* res,
+                     float* out, int64_t n_pix, int32_t channels, int32_t mode, void* stream);
+
+/* uint8 BGR HWC image -> normalised RGB NHWC4 fp32 (2*x/255-1, 4th channel 0).
+ * optical_flow/raft.py:113-120 + weighted_raft.py:194-195.  replicate-pads to (hp, wp) with the
+ * top/left offsets (pad_top, pad_left)  (utils/utils.py:7-19 InputPadder). */
+int woft_preprocess_bgr_u8(const uint8_t* img, int32_t h, int32_t w, float* out,
+                           int32_t hp, int32_t wp, int32_t pad_top, int32_t pad_left, void* stream);
+
+/* 2x2 stride-2 average pool of an NHWC feature map, floor sizes (corr.py:25-27 applied to
+ * fmap2 instead of the volume: identical by linearity, as corr.py:77-81 does). */
+int woft_avgpool2_nhwc(const float* in, int32_t h, int32_t w, int32_t c, float* out, void* stream);
+
+/* Correlation lookup, corr.py:29-59 + utils/utils.py:59-73.
+ * vol[l]: [P][hl][pitch_l] fp32 (level l of the pyramid), coords: [P][2] (x,y) at level 0.
+ * out: [P][ldo] with channel l*(2r+1)^2 + i*(2r+1) + j  <-  sample at (x/2^l + i - r, y/2^l + j - r). */
+typedef struct woft_lookup_params {
+    const float* vol[4];
+    int32_t hl[4], wl[4], pitch[4];
+    int64_t plane[4];       /* floats per source pixel at level l */
+    int32_t levels, radius;
+    const float* coords;
+    int64_t n_pix;
+    float* out;
+    int32_t ldo;
+} woft_lookup_params;
+int woft_corr_lookup(const woft_lookup_params* p, void* stream);
+
+/* coords1 += delta; flow = coords1 - coords0 (weighted_raft.py:232,237).
+ * delta: [P][ld_delta] (first two channels); flow4: [P][4] = (fx, fy, 0, 0);
+ * flow_cat: optional, writes (fx, fy) at flow_cat[p*ld_cat + 0..1]. */
+int woft_coords_update(float* coords1, const float* delta, int32_t ld_delta, int32_t wf, int64_t n_pix,
+                       float* flow4, float* flow_cat, int32_t ld_cat, void* stream);
+int woft_coords_init(float* coords1, int32_t hf, int32_t wf, float* flow4, float* flow_cat,
+                     int32_t ld_cat, void* stream);
+
+/* Weight-head glue (weighted_raft.py:258-279, 347-384).
+ * woft_colsum: total[c] = sum_q f[q][c] in fp64 (ws: [n_part][c] doubles).
+ * woft_wh_pack: mean[p] = alpha * <f1[p], total>  (= mean_q vol[p,q], weighted_raft.py:358-361, in its
+ *   algebraic form) and the head's input patches (weighted_raft.py:267-272, 363-376):
+ *   x8[p][hp][wp][0..3] = lookup[p][(hp*nwin + wp)*4 + 0..3], x8[..][4] = mean[p], x8[..][5..7] = 0.
+ * woft_wh_reduce: final 1x1 conv + mean over the patch (weighted_raft.py:341,378-383):
+ *   out[p] = bias + mean_t <w, act[p][t][:]> */
+int woft_colsum(const float* f, int64_t n_pix, int32_t c, double* ws, int32_t n_part, double* total, void* stream);
+int woft_wh_pack(const float* lookup, int32_t ld_lookup, const float* f1, int32_t c, const double* f2_total,
+                 float alpha, int64_t n_pix, int32_t nwin, float* mean, float* x8, void* stream);
+int woft_wh_reduce(const float* act, int32_t c, int32_t nwin2, const float* w, float bias,
+                   int64_t n_pix, float* out, void* stream);
+
+/* Convex upsampling of flow and weight logits + TC epilogue
+ * (weighted_raft.py:92-103,285-288; optical_flow/raft.py:148-159,185-199).
+ * coords1: [P][2]; wlow: [P] or NULL; mask: [P][ld_mask] channel k*64 + i*8 + j.
+ * Crops to the unpadded window (crop_top, crop_left, h, w) and writes
+ *   flow_up [2][h][w]            (may be NULL)
+ *   dst     [2][h*w] = grid + flow (may be NULL)
+ *   wout    [h*w]   = weights_up (logit, or sigmoid when do_sigmoid)  (NULL if wlow NULL) */
+int woft_convex_upsample(const float* coords1, const float* wlow, const float* mask, int32_t ld_mask,
+                         int32_t hf, int32_t wf, int32_t crop_top, int32_t crop_left, int32_t h, int32_t w,
+                         float* flow_up, float* dst, float* wout, int32_t do_sigmoid, void* stream);
+/* bilinear x8 upsampling, align_corners=True, times 8 (utils/utils.py:82-84), same outputs. */
+int woft_upflow8(const float* coords1, const float* wlow, int32_t hf, int32_t wf,
+                 int32_t crop_top, int32_t crop_left, int32_t h, int32_t w,
+                 float* flow_up, float* dst, float* wout, int32_t do_sigmoid, void* stream);
+
+/* Perspective warp, dst(x) = bilinear src(Hinv x), zeros outside
+ * (tracker/YAOF_tracker_single_control.py:89-95).  hinv: 9 doubles on the HOST (by value copy).
+ * img: HWC uint8 (c channels).  valid (may be NULL): uint8 1 where warp(ones) > 0. */
+int woft_warp_perspective_u8(const uint8_t* img, int32_t h, int32_t w, int32_t c, const double* hinv,
+                             uint8_t* out, uint8_t* valid, int32_t nearest, void* stream);
+
+/* Weighted / iteratively re-weighted least-squares homography, utils/least_squares_H.py:142-210
+ * (n_irls = 0) and :280-346 (n_irls = 5 -> 6 solves); reweight: 0 none, 1 L1 (:268-269),
+ * 2 Huber(k) (:272-277).  pa, pb: [n][2] points (A -> B), w: [n] or NULL; n = min(count[0], n_max)
+ * when count != NULL (device), else n_max.  Hout: 9 floats (row major, device).
+ * status[0] (device) = 0 ok, 1 fewer than 4 points, 2 singular system. */
+int woft_hfit(const float* pa, const float* pb, const float* w, int32_t n_max, const int32_t* count,
+              int32_t reweight, float huber_k, int32_t n_irls, float* Hout, int32_t* status, void* stream);
+/* torch_proj_errors + inlier fraction (least_squares_H.py:474-489; configs/..._wLSq.py:14-21):
+ * frac[0] = mean(|proj(H, A) - B| <= thr). */
+int woft_inlier_frac(const float* pa, const float* pb, int32_t n_max, const int32_t* count, const float* H,
+                     float thr, float* frac, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WOFT_HIP_H */

@@ -1,0 +1,387 @@
+"""GPU parity tests, kernel by kernel, through the C ABI (ctypes) against the CPU oracle /
+plain PyTorch fp32 references of the same op.  Run on the MI355X box: pytest -m gpu."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import hfit_ref, raft_ref, tracker_ref  # noqa: E402  (checker only)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "gpu tests need the MI355X"
+    from woft_amd import _lib, ops as o
+    _lib.load()
+    return o
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+def _close(a, b, atol, rtol=0.0, what=""):
+    a, b = a.detach().cpu().float(), b.detach().cpu().float()
+    err = (a - b).abs()
+    tol = atol + rtol * b.abs()
+    assert bool((err <= tol).all()), f"{what}: max err {float(err.max()):.3e} (tol {atol:.1e}), max ref {float(b.abs().max()):.3e}"
+
+
+# ------------------------------------------------------------------------------------------
+# convolution engine
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cin,cout,k,stride,h,w,tiles", [
+    (64, 64, 3, 1, 20, 28, (64, 64)),
+    (64, 96, 3, 2, 21, 27, (64, 128)),
+    (96, 128, 3, 1, 17, 25, (128, 128)),
+    (128, 256, 1, 1, 17, 25, (128, 64)),
+    (324, 256, 1, 1, 9, 13, None),
+    (256, 2, 3, 1, 17, 25, None),
+    (64, 96, 1, 2, 20, 28, None),
+])
+def test_conv_plain(ops, cin, cout, k, stride, h, w, tiles):
+    x = _rand(2, cin, h, w, seed=1)
+    wt = _rand(cout, cin, k, k, seed=2, scale=1.0 / math.sqrt(cin * k * k))
+    b = _rand(cout, seed=3, scale=0.1)
+    ref = F.conv2d(x, wt, b, stride=stride, padding=k // 2)
+    pc = ops.pack_conv(wt, b, stride=stride)
+    xa = ops.act_from_nchw(x, cs=ops._round_up(cin, 32))
+    out = ops.conv2d(xa, pc, tiles=tiles)
+    torch.cuda.synchronize()
+    _close(out.nchw(), ref, 2e-5, what="conv")
+    # relu epilogue, written at a channel offset into a wider buffer
+    big = ops.new_act(2, ref.shape[2], ref.shape[3], cout + 8, cs=ops._round_up(cout + 8, 4), zero=True)
+    ops.run_conv(ops.conv_params(xa, pc, big, co_off=8, epi=ops._lib.EPI_RELU, tiles=tiles))
+    torch.cuda.synchronize()
+    _close(big.t[:, 8:8 + cout].reshape(2, ref.shape[2], ref.shape[3], cout).permute(0, 3, 1, 2), F.relu(ref), 2e-5,
+           what="conv relu offset")
+    assert float(big.t[:, :8].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("kh,kw", [(1, 5), (5, 1), (3, 3)])
+def test_conv_gru_epilogues(ops, kh, kw):
+    """SepConvGRU half step (update.py:45-60) from two convs with two-source inputs."""
+    n, h, w = 1, 18, 22
+    hprev = torch.tanh(_rand(n, 128, h, w, seed=4))
+    xin = _rand(n, 256, h, w, seed=5)
+    mk = lambda s: (_rand(128, 384, kh, kw, seed=s, scale=1 / math.sqrt(384 * kh * kw)), _rand(128, seed=s + 50, scale=0.1))
+    (wz, bz), (wr, br), (wq, bq) = mk(6), mk(7), mk(8)
+    pad = (kh // 2, kw // 2)
+    hx = torch.cat([hprev, xin], 1)
+    z = torch.sigmoid(F.conv2d(hx, wz, bz, padding=pad))
+    r = torch.sigmoid(F.conv2d(hx, wr, br, padding=pad))
+    q = torch.tanh(F.conv2d(torch.cat([r * hprev, xin], 1), wq, bq, padding=pad))
+    ref = (1 - z) * hprev + z * q
+    pzr = ops.pack_conv(torch.cat([wz, wr], 0), torch.cat([bz, br], 0), padding=pad)
+    pq = ops.pack_conv(wq, bq, padding=pad)
+    ha, xa = ops.act_from_nchw(hprev), ops.act_from_nchw(xin)
+    zb, rh, hn = (ops.new_act(n, h, w, 128, zero=True) for _ in range(3))
+    ops.run_conv(ops.conv_params(ha, pzr, zb, x2=xa, c_split=128, epi=ops._lib.EPI_GRU_ZR, split=128, e0=ha, out1=rh))
+    ops.run_conv(ops.conv_params(rh, pq, hn, x2=xa, c_split=128, epi=ops._lib.EPI_GRU_Q, e0=ha, e1=zb))
+    torch.cuda.synchronize()
+    _close(zb.nchw(), z, 2e-5, what="z")
+    _close(rh.nchw(), r * hprev, 2e-5, what="r*h")
+    _close(hn.nchw(), ref, 3e-5, what="h")
+
+
+def test_conv_flat_first_layer(ops):
+    """7x7 stride-2 conv on a 3-channel image stored NHWC4 (extractor.py:132), flat K packing."""
+    x = _rand(1, 3, 40, 56, seed=9)
+    wt = _rand(64, 3, 7, 7, seed=10, scale=0.1)
+    b = _rand(64, seed=11, scale=0.1)
+    ref = F.conv2d(x, wt, b, stride=2, padding=3)
+    pc = ops.pack_conv(wt, b, stride=2, padding=3, flat_cs=4)
+    xa = ops.act_from_nchw(x, cs=4)
+    out = ops.conv2d(xa, pc)
+    torch.cuda.synchronize()
+    _close(out.nchw(), ref, 2e-5, what="conv7x7s2 flat")
+    # 7x7 stride-1 on a 2-channel flow field (update.py:84)
+    x = _rand(1, 2, 17, 25, seed=12, scale=3.0)
+    wt = _rand(128, 2, 7, 7, seed=13, scale=0.1)
+    b = _rand(128, seed=14, scale=0.1)
+    ref = F.conv2d(x, wt, b, padding=3)
+    out = ops.conv2d(ops.act_from_nchw(x, cs=4), ops.pack_conv(wt, b, padding=3, flat_cs=4))
+    torch.cuda.synchronize()
+    _close(out.nchw(), ref, 2e-5, what="conv7x7 flow flat")
+    # 3x3 on batches of 9x9 5-channel patches stored with 8 channels (weighted_raft.py:336-338)
+    x = _rand(37, 5, 9, 9, seed=15, scale=5.0)
+    wt = _rand(128, 5, 3, 3, seed=16, scale=0.2)
+    b = _rand(128, seed=17, scale=0.1)
+    ref = F.conv2d(x, wt, b, padding=1)
+    out = ops.conv2d(ops.act_from_nchw(x, cs=8), ops.pack_conv(wt, b, padding=1, flat_cs=8))
+    torch.cuda.synchronize()
+    _close(out.nchw(), ref, 5e-5, what="conv3x3 patches flat")
+
+
+def test_residual_epilogue_and_bn_fold(ops):
+    x = _rand(1, 64, 16, 24, seed=18)
+    res = _rand(1, 64, 16, 24, seed=19)
+    wt = _rand(64, 64, 3, 3, seed=20, scale=0.05)
+    b = _rand(64, seed=21, scale=0.1)
+    g, be = 1 + _rand(64, seed=22, scale=0.2), _rand(64, seed=23, scale=0.1)
+    mu, var = _rand(64, seed=24, scale=0.1), 1 + _rand(64, seed=25, scale=0.3)
+    y = F.batch_norm(F.conv2d(x, wt, b, padding=1), mu, var, g, be, False, 0.0, 1e-5)
+    ref = F.relu(res + F.relu(y))
+    wf, bf = ops.fold_bn(wt, b, g, be, mu, var)
+    out = ops.new_act(1, 16, 24, 64, zero=True)
+    ops.run_conv(ops.conv_params(ops.act_from_nchw(x), ops.pack_conv(wf, bf), out, epi=ops._lib.EPI_RELU_RES_RELU,
+                                 e0=ops.act_from_nchw(res)))
+    torch.cuda.synchronize()
+    _close(out.nchw(), ref, 2e-5, what="bn-fold residual")
+
+
+@pytest.mark.parametrize("tiles", [(64, 64), (128, 64)])
+def test_instance_norm(ops, tiles):
+    x = _rand(1, 64, 30, 44, seed=26)
+    wt = _rand(64, 64, 3, 3, seed=27, scale=0.05)
+    b = _rand(64, seed=28, scale=0.3)
+    res = F.relu(_rand(1, 64, 30, 44, seed=29))
+    y = F.conv2d(x, wt, b, padding=1)
+    pc = ops.pack_conv(wt, b)
+    m = 30 * 44
+    rows = 2 * math.ceil(m / tiles[0])
+    stats = (torch.zeros(rows * pc.cout_pad, device="cuda"), torch.zeros(rows * pc.cout_pad, device="cuda"))
+    raw = ops.new_act(1, 30, 44, 64, zero=True)
+    ops.run_conv(ops.conv_params(ops.act_from_nchw(x), pc, raw, stats=stats, tiles=tiles))
+    mean, rstd = torch.zeros(64, device="cuda"), torch.zeros(64, device="cuda")
+    ops.inorm_finalize(stats, rows, pc.cout_pad, 64, m, mean, rstd)
+    out = ops.new_act(1, 30, 44, 64)
+    for mode, ref in ((0, F.instance_norm(y)), (1, F.relu(F.instance_norm(y))),
+                      (2, F.relu(res + F.relu(F.instance_norm(y))))):
+        ops.inorm_apply(raw, mean, rstd, out, mode, res=ops.act_from_nchw(res) if mode == 2 else None)
+        torch.cuda.synchronize()
+        _close(out.nchw(), ref, 3e-5, what=f"instance norm mode {mode}")
+
+
+def test_preprocess_and_pool(ops):
+    rs = np.random.RandomState(0)
+    img = rs.randint(0, 256, (37, 45, 3), dtype=np.uint8)
+    t = torch.from_numpy(img).cuda()
+    out = ops.new_act(1, 40, 48, 3, cs=4)
+    ops.preprocess(t, out, 40, 48, 1, 1)
+    torch.cuda.synchronize()
+    x = torch.from_numpy(img[:, :, ::-1].copy()).permute(2, 0, 1).float()[None]
+    ref = 2 * (F.pad(x, [1, 2, 1, 2], mode="replicate") / 255.0) - 1.0
+    _close(out.nchw(), ref, 0.0, what="preprocess (bit exact)")
+    f = _rand(1, 64, 17, 25, seed=30)
+    fa = ops.act_from_nchw(f)
+    o = ops.new_act(1, 8, 12, 64)
+    ops.avgpool2(fa, o)
+    torch.cuda.synchronize()
+    _close(o.nchw(), F.avg_pool2d(f, 2, stride=2), 1e-6, what="avgpool")
+
+
+# ------------------------------------------------------------------------------------------
+# correlation volume + lookup
+# ------------------------------------------------------------------------------------------
+def _build_pyramid_gpu(ops, f1, f2):
+    """f1, f2: (1, C, H, W) cpu tensors -> volumes [P][hl][pitch] on the GPU via the conv/GEMM kernel."""
+    _, c, h, w = f1.shape
+    a1, a2 = ops.act_from_nchw(f1), ops.act_from_nchw(f2)
+    vols, dims, pitches = [], [], []
+    cur = a2
+    for l in range(4):
+        hl, wl = cur.h, cur.w
+        pitch = ops._round_up(wl, 4)
+        rows = torch.zeros(ops._round_up(hl * wl, 128), c, device="cuda")
+        rows[:hl * wl] = cur.t
+        vol = torch.zeros(h * w, hl * pitch, device="cuda")
+        ops.run_conv(ops.corr_volume(a1, rows, hl * wl, vol, wl, pitch, 1.0 / math.sqrt(c)))
+        vols.append(vol)
+        dims.append((hl, wl))
+        pitches.append(pitch)
+        if l < 3:
+            nxt = ops.new_act(1, hl // 2, wl // 2, c)
+            ops.avgpool2(cur, nxt)
+            cur = nxt
+    torch.cuda.synchronize()
+    return vols, dims, pitches
+
+
+@pytest.mark.parametrize("h,w", [(16, 20), (17, 25)])
+def test_corr_volume_and_lookup(ops, h, w):
+    f1, f2 = _rand(1, 256, h, w, seed=31), _rand(1, 256, h, w, seed=32)
+    pyr = raft_ref.corr_pyramid(f1, f2)
+    vols, dims, pitches = _build_pyramid_gpu(ops, f1, f2)
+    for l in range(4):
+        hl, wl = dims[l]
+        got = vols[l].reshape(h * w, hl, pitches[l])[:, :, :wl]
+        _close(got, pyr[l][:, 0], 3e-5, what=f"volume level {l}")
+    coords = raft_ref.coords_grid(1, h, w) + _rand(1, 2, h, w, seed=33, scale=6.0)
+    coords[0, :, 0, 0] = torch.tensor([-7.3, 2.2])
+    coords[0, :, 0, 1] = torch.tensor([w + 9.5, h + 3.0])
+    ref = raft_ref.corr_lookup(pyr, coords, 4)
+    cg = coords[0].permute(1, 2, 0).reshape(h * w, 2).contiguous().cuda()
+    out = torch.zeros(h * w, 352, device="cuda")
+    ops.run_lookup(ops.make_lookup_params(vols, dims, pitches, cg, out, 4))
+    torch.cuda.synchronize()
+    got = out[:, :324].reshape(1, h, w, 324).permute(0, 3, 1, 2)
+    _close(got, ref, 1e-4, what="lookup")
+    assert float(out[:, 324:].abs().max()) == 0.0
+
+
+def test_lookup_golden_handmade(ops, golden_dir):
+    g = np.load(golden_dir / "lookup_handmade.npz")
+    v = torch.from_numpy(g["vol0"])
+    P = v.shape[0]
+    vols, dims, pitches = [], [], []
+    for l in range(4):
+        hl, wl = v.shape[-2:]
+        pitch = ops._round_up(wl, 4)
+        vv = torch.zeros(P, hl, pitch)
+        vv[:, :, :wl] = v[:, 0]
+        vols.append(vv.reshape(P, hl * pitch).cuda())
+        dims.append((hl, wl))
+        pitches.append(pitch)
+        v = F.avg_pool2d(v, 2, stride=2)
+    coords = torch.from_numpy(g["coords"])                       # (2, h1, w1)
+    h1, w1 = coords.shape[1:]
+    cg = coords.permute(1, 2, 0).reshape(P, 2).contiguous().cuda()
+    out = torch.zeros(P, 324, device="cuda")
+    ops.run_lookup(ops.make_lookup_params(vols, dims, pitches, cg, out, 4))
+    torch.cuda.synchronize()
+    got = out.reshape(1, h1, w1, 324).permute(0, 3, 1, 2)
+    _close(got, torch.from_numpy(g["out"]), 1e-5 * float(np.abs(g["out"]).max()), what="lookup golden")
+    assert abs(float(got[0, 1, 0, 0]) - 304.0) < 1e-3          # x-major window order pin
+
+
+def test_coords_update(ops):
+    hf, wf = 7, 9
+    c = torch.zeros(hf * wf, 2, device="cuda")
+    f4 = torch.ones(hf * wf, 4, device="cuda")
+    cat = torch.zeros(hf * wf, 16, device="cuda")
+    ops.coords_init(c, hf, wf, f4, cat[:, 14:], 16)
+    torch.cuda.synchronize()
+    ref = raft_ref.coords_grid(1, hf, wf)[0].permute(1, 2, 0).reshape(-1, 2)
+    assert torch.equal(c.cpu(), ref) and float(f4.abs().max()) == 0.0
+    d = _rand(hf * wf, 64, seed=34).cuda()
+    ops.coords_update(c, d, 64, wf, f4, cat[:, 14:], 16)
+    torch.cuda.synchronize()
+    assert torch.equal(c.cpu(), ref + d[:, :2].cpu())
+    fl = (ref + d[:, :2].cpu()) - ref
+    assert torch.equal(f4[:, :2].cpu(), fl) and torch.equal(cat[:, 14:16].cpu(), fl)
+    assert float(cat[:, :14].abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------------------------------
+# upsampling / boundary epilogue / warp
+# ------------------------------------------------------------------------------------------
+def test_convex_upsample(ops):
+    hf, wf = 9, 11
+    flow = _rand(1, 2, hf, wf, seed=35, scale=4.0)
+    wl = _rand(1, 1, hf, wf, seed=36, scale=3.0)
+    mask = _rand(1, 576, hf, wf, seed=37, scale=2.0)
+    fu = raft_ref.convex_upsample(flow, mask)
+    wu = raft_ref.convex_upsample(wl, mask) / 8
+    coords = (raft_ref.coords_grid(1, hf, wf) + flow)[0].permute(1, 2, 0).reshape(-1, 2).contiguous().cuda()
+    mk = mask[0].permute(1, 2, 0).reshape(-1, 576).contiguous().cuda()
+    H, W = 8 * hf, 8 * wf
+    f_o, d_o, w_o = torch.zeros(2, H, W, device="cuda"), torch.zeros(2, H * W, device="cuda"), torch.zeros(H * W, device="cuda")
+    ops.convex_upsample(coords, wl.reshape(-1).cuda(), mk, hf, wf, (0, 0), H, W, f_o, d_o, w_o, do_sigmoid=True)
+    torch.cuda.synchronize()
+    _close(f_o, fu[0], 2e-5, what="flow_up")
+    _close(w_o.reshape(H, W), torch.sigmoid(wu[0, 0]), 1e-6, what="sigmoid(w_up)")
+    idx = torch.arange(H * W)
+    src = torch.stack([idx % W, idx // W]).float()
+    _close(d_o, src + fu[0].reshape(2, -1), 3e-5, what="dst coords")
+    # cropped (un-padded) window, raw logits
+    h, w, top, left = H - 5, W - 3, 2, 1
+    f_c, w_c = torch.zeros(2, h, w, device="cuda"), torch.zeros(h * w, device="cuda")
+    ops.convex_upsample(coords, wl.reshape(-1).cuda(), mk, hf, wf, (top, left), h, w, f_c, None, w_c, do_sigmoid=False)
+    torch.cuda.synchronize()
+    _close(f_c, fu[0, :, top:top + h, left:left + w], 2e-5, what="flow_up crop")
+    _close(w_c.reshape(h, w), wu[0, 0, top:top + h, left:left + w], 2e-5, what="w_up crop")
+
+
+def test_upflow8(ops):
+    hf, wf = 6, 9
+    flow = _rand(1, 2, hf, wf, seed=38, scale=4.0)
+    wl = _rand(1, 1, hf, wf, seed=39, scale=3.0)
+    coords = (raft_ref.coords_grid(1, hf, wf) + flow)[0].permute(1, 2, 0).reshape(-1, 2).contiguous().cuda()
+    H, W = 8 * hf, 8 * wf
+    f_o, w_o = torch.zeros(2, H, W, device="cuda"), torch.zeros(H * W, device="cuda")
+    ops.upflow8(coords, wl.reshape(-1).cuda(), hf, wf, (0, 0), H, W, f_o, None, w_o)
+    torch.cuda.synchronize()
+    _close(f_o, raft_ref.upflow8(flow)[0], 3e-5, what="upflow8")
+    _close(w_o.reshape(H, W), (raft_ref.upflow8(wl) / 8)[0, 0], 1e-5, what="upflow8 weights")
+
+
+def test_warp(ops):
+    rs = np.random.RandomState(1)
+    img = rs.randint(0, 256, (60, 84, 3), dtype=np.uint8)
+    Hm = np.array([[1.02, 0.05, 3.5], [-0.03, 0.97, -2.25], [1e-4, -2e-4, 1.0]])
+    t = torch.from_numpy(img).cuda()
+    out, valid = torch.zeros_like(t), torch.zeros(60, 84, dtype=torch.uint8, device="cuda")
+    ops.warp_perspective_u8(t, Hm, out, valid)
+    torch.cuda.synchronize()
+    ref = tracker_ref.warp_linear_u8(img, Hm)
+    d = np.abs(out.cpu().numpy().astype(np.int32) - ref.astype(np.int32))
+    assert d.max() <= 1 and (d > 0).mean() < 1e-3, (d.max(), (d > 0).mean())
+    refm = tracker_ref.warp_linear(np.ones((60, 84)), Hm) > 0
+    assert (valid.cpu().numpy().astype(bool) != refm).mean() < 1e-3
+    m = (rs.uniform(size=(60, 84)) > 0.5).astype(np.uint8) * 255
+    mt = torch.from_numpy(m).cuda()
+    mo = torch.zeros_like(mt)
+    ops.warp_perspective_u8(mt, Hm, mo, None, nearest=True)
+    torch.cuda.synchronize()
+    assert (mo.cpu().numpy() != tracker_ref.warp_nearest(m, Hm)).mean() < 2e-3
+
+
+# ------------------------------------------------------------------------------------------
+# homography fit
+# ------------------------------------------------------------------------------------------
+def _corner_err(Ha, Hb):
+    c = np.array([[100, 80, 1], [1800, 80, 1], [1800, 1000, 1], [100, 1000, 1.0]]).T
+    pa, pb = Ha @ c, Hb @ c
+    return np.abs(pa[:2] / pa[2] - pb[:2] / pb[2]).max()
+
+
+@pytest.mark.parametrize("case", ["n4", "n500", "n4096"])
+def test_hfit_vs_golden_and_oracle(ops, golden_dir, case):
+    g = np.load(golden_dir / "hfit.npz")
+    a, b, w = (torch.from_numpy(g[f"{case}_{k}"]) for k in "abw")
+    pa, pb, pw = a[0].contiguous().cuda(), b[0].contiguous().cuda(), w[0].contiguous().cuda()
+    Hd, st = torch.zeros(9, device="cuda"), torch.zeros(1, dtype=torch.int32, device="cuda")
+
+    def run(**kw):
+        ops.hfit(pa, pb, kw.pop("w", pw), Hd, st, **kw)
+        torch.cuda.synchronize()
+        assert int(st.item()) == 0
+        return Hd.cpu().numpy().reshape(3, 3).astype(np.float64)
+
+    tol = 0.05            # px at the corners of a 1700x920 box (H corners <= 0.05 px in fp32)
+    assert _corner_err(run(), g[f"{case}_qr_w"][0].astype(np.float64)) < tol
+    assert _corner_err(run(w=None), g[f"{case}_qr_now"][0].astype(np.float64)) < tol
+    assert _corner_err(run(reweight=2, huber_k=2.0, n_irls=5), g[f"{case}_irls_huber2"][0].astype(np.float64)) < tol
+    if case != "n4":
+        assert _corner_err(run(reweight=1, n_irls=5), g[f"{case}_irls_l1"][0].astype(np.float64)) < 0.2
+        assert _corner_err(run(reweight=2, huber_k=0.01, n_irls=5), g[f"{case}_irls_huber001"][0].astype(np.float64)) < 0.2
+    # inlier fraction against the oracle's torch_proj_errors
+    Hq = torch.from_numpy(g[f"{case}_qr_w"])
+    e = hfit_ref.torch_proj_errors(Hq, a.permute(0, 2, 1), b.permute(0, 2, 1))
+    fr = torch.zeros(1, device="cuda")
+    ops.inlier_frac(pa, pb, Hq[0].reshape(9).contiguous().cuda(), fr, thr=5.0)
+    torch.cuda.synchronize()
+    assert abs(float(fr.item()) - float((e <= 5).float().mean())) < 2.0 / a.shape[1]
+
+
+def test_hfit_too_few_points(ops):
+    pa = torch.zeros(3, 2, device="cuda")
+    Hd, st = torch.zeros(9, device="cuda"), torch.zeros(1, dtype=torch.int32, device="cuda")
+    ops.hfit(pa, pa, None, Hd, st)
+    torch.cuda.synchronize()
+    assert int(st.item()) == 1
+
+
+def test_abi_rejects_bad_arguments(ops):
+    from woft_amd import _lib
+    import ctypes as C
+    p = _lib.ConvParams()
+    assert _lib.load().woft_conv2d(C.byref(p), None) == -1
+    lp = _lib.LookupParams()
+    assert _lib.load().woft_corr_lookup(C.byref(lp), None) == -1

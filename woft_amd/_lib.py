@@ -1,0 +1,97 @@
+"""ctypes binding of libwoft_hip.so (the C ABI declared in include/woft_hip.h).
+
+The product path has no CPU fallback: if the library is missing or a call fails, this raises.
+`import torch` happens first so that the process-wide HIP runtime (libamdhip64.so.7) is the one
+PyTorch-ROCm loaded; the kernels then run on torch's streams and torch-allocated buffers.
+"""
+import ctypes as C
+from pathlib import Path
+
+import torch  # noqa: F401  (must precede the CDLL so both share one HIP runtime)
+
+LIB_PATH = Path(__file__).resolve().parent / "lib" / "libwoft_hip.so"
+
+EPI_LINEAR, EPI_RELU, EPI_SIGMOID, EPI_TANH, EPI_RELU_RES_RELU, EPI_GRU_ZR, EPI_GRU_Q, EPI_CTX = range(8)
+
+vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+
+class ConvParams(C.Structure):
+    _fields_ = [
+        ("in0", vp), ("in1", vp), ("cs0", i32), ("cs1", i32), ("c_split", i32),
+        ("n_img", i32), ("h", i32), ("w", i32), ("ho", i32), ("wo", i32),
+        ("taps_y", i32), ("taps_x", i32), ("stride", i32), ("pad_y", i32), ("pad_x", i32),
+        ("cin_pad", i32), ("flat", i32), ("wgt", vp), ("bias", vp), ("alpha", f32),
+        ("cout", i32), ("cout_pad", i32), ("out", vp), ("ldo", i64), ("co_off", i32),
+        ("out_w", i32), ("out_pitch", i32), ("epi", i32), ("split", i32),
+        ("e0", vp), ("e1", vp), ("lde0", i32), ("lde1", i32), ("out1", vp), ("ldo1", i32),
+        ("stat_sum", vp), ("stat_sq", vp), ("tile_m", i32), ("tile_n", i32),
+    ]
+
+
+class LookupParams(C.Structure):
+    _fields_ = [
+        ("vol", vp * 4), ("hl", i32 * 4), ("wl", i32 * 4), ("pitch", i32 * 4), ("plane", i64 * 4),
+        ("levels", i32), ("radius", i32), ("coords", vp), ("n_pix", i64), ("out", vp), ("ldo", i32),
+    ]
+
+
+_SIGS = {
+    "woft_abi_version": (i32, []),
+    "woft_sizeof": (i32, [i32]),
+    "woft_conv2d": (i32, [C.POINTER(ConvParams), vp]),
+    "woft_inorm_finalize": (i32, [vp, vp, i32, i32, i32, i64, f32, vp, vp, vp]),
+    "woft_inorm_apply": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, vp]),
+    "woft_preprocess_bgr_u8": (i32, [vp, i32, i32, vp, i32, i32, i32, i32, vp]),
+    "woft_avgpool2_nhwc": (i32, [vp, i32, i32, i32, vp, vp]),
+    "woft_corr_lookup": (i32, [C.POINTER(LookupParams), vp]),
+    "woft_coords_update": (i32, [vp, vp, i32, i32, i64, vp, vp, i32, vp]),
+    "woft_coords_init": (i32, [vp, i32, i32, vp, vp, i32, vp]),
+    "woft_colsum": (i32, [vp, i64, i32, vp, i32, vp, vp]),
+    "woft_wh_pack": (i32, [vp, i32, vp, i32, vp, f32, i64, i32, vp, vp, vp]),
+    "woft_wh_reduce": (i32, [vp, i32, i32, vp, f32, i64, vp, vp]),
+    "woft_convex_upsample": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, i32, vp]),
+    "woft_upflow8": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, i32, vp]),
+    "woft_warp_perspective_u8": (i32, [vp, i32, i32, i32, C.POINTER(C.c_double), vp, vp, i32, vp]),
+    "woft_hfit": (i32, [vp, vp, vp, i32, vp, i32, f32, i32, vp, vp, vp]),
+    "woft_inlier_frac": (i32, [vp, vp, i32, vp, vp, f32, vp, vp]),
+}
+
+EXPORTS = tuple(_SIGS)
+_lib = None
+
+
+class WoftHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libwoft_hip.so (once).  Raises if it has not been built: there is no fallback path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise WoftHipError(f"{LIB_PATH} is missing: build it with `python -m woft_amd.build` "
+                           "(hipcc --offload-arch=gfx950); woft_amd has no CPU fallback")
+    lib = C.CDLL(str(LIB_PATH))
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)           # AttributeError if a declared symbol is not exported
+        fn.restype, fn.argtypes = res, args
+    if lib.woft_sizeof(0) != C.sizeof(ConvParams) or lib.woft_sizeof(1) != C.sizeof(LookupParams):
+        raise WoftHipError("ctypes mirror of woft_conv_params / woft_lookup_params is out of sync with the library")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise WoftHipError(f"{what} failed with code {rc}")
+
+
+def ptr(t):
+    """Device (or host) address of a tensor's first element; None -> NULL."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream

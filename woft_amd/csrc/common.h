@@ -1,0 +1,17 @@
+// Shared helpers for the gfx950 kernels of libwoft_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/woft_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static inline int woft_launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? WOFT_OK : WOFT_ELAUNCH;
+}
+
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }

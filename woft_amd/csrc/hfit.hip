@@ -1,0 +1,258 @@
+// Weighted / iteratively re-weighted least-squares homography (utils/least_squares_H.py:142-210,
+// 268-346) and the re-detection inlier test (least_squares_H.py:474-489, configs/*_wLSq.py:14-21).
+//
+// The reference solves the (2N x 8) inhomogeneous DLT system with a QR factorisation in fp32.  Here
+// the rows are built in fp32 exactly as the reference builds them (Hartley normalisation, plain-w
+// row weighting, per-row IRLS re-weighting) and the 9x9 Gram matrix [A b]^T [A b] is accumulated in
+// fp64 (streaming, 20 B per correspondence per pass) and solved by an fp64 Cholesky factorisation:
+// the least-squares solution is the same, the conditioning loss of the normal equations is absorbed
+// by the wider type.  One workgroup does the whole fit in a single launch (N <= 500 after the Sobol
+// subsampler of the default configs; larger N loops).
+#include "common.h"
+
+namespace {
+
+constexpr int HT = 1024;           // threads of the fit workgroup
+constexpr int NG = 45;             // upper triangle of the 9x9 Gram matrix
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// Sum `cnt` per-thread doubles over the workgroup; result valid for every thread in out[0..cnt).
+template <int CNT>
+__device__ void block_sum(double (&vals)[CNT], double* red /* [16][CNT] */, double* out /* [CNT] */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) {
+        const double s = wave_sum(vals[i]);
+        if (lane == 0) red[wave * CNT + i] = s;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < CNT) {
+        double s = 0.0;
+        for (int wv = 0; wv < HT / 64; ++wv) s += red[wv * CNT + threadIdx.x];
+        out[threadIdx.x] = s;
+    }
+    __syncthreads();
+}
+
+// rows of the DLT system for one correspondence, in fp32 as the reference builds them
+__device__ __forceinline__ void build_rows(float x1, float y1, float x2, float y2, float wv, float (&rx)[9],
+                                           float (&ry)[9]) {
+    rx[0] = 0.f; rx[1] = 0.f; rx[2] = 0.f; rx[3] = -x1; rx[4] = -y1; rx[5] = -1.f; rx[6] = y2 * x1; rx[7] = y2 * y1;
+    rx[8] = -y2;
+    ry[0] = x1; ry[1] = y1; ry[2] = 1.f; ry[3] = 0.f; ry[4] = 0.f; ry[5] = 0.f; ry[6] = -x2 * x1; ry[7] = -x2 * y1;
+    ry[8] = x2;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        rx[k] *= wv;
+        ry[k] *= wv;
+    }
+}
+
+__device__ __forceinline__ float reweight_fn(float r, int mode, float k) {
+    const float a = fabsf(r);
+    if (mode == 2 && a < k) return 1.f;
+    return 1.f / (a + 1e-8f);
+}
+
+__global__ __launch_bounds__(HT) void hfit_kernel(const float* __restrict__ pa, const float* __restrict__ pb,
+                                                  const float* __restrict__ w, int n_max,
+                                                  const int* __restrict__ count, int reweight, float huber_k,
+                                                  int n_solves, float* __restrict__ Hout, int* __restrict__ status) {
+    __shared__ double red[(HT / 64) * NG];
+    __shared__ double tot[NG];
+    __shared__ float sol_s[8];
+    __shared__ int fail_s;
+    int n = n_max;
+    if (count != nullptr) n = min(count[0], n_max);
+    if (n < 4) {
+        if (threadIdx.x == 0) {
+            status[0] = 1;
+            for (int i = 0; i < 9; ++i) Hout[i] = nanf("");
+        }
+        return;
+    }
+    if (threadIdx.x == 0) fail_s = 0;
+
+    // ---- Hartley normalisation (kornia normalize_points semantics, see oracle/hfit_ref.py) ------
+    double s4[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int i = threadIdx.x; i < n; i += HT) {
+        s4[0] += (double)pa[2 * i];
+        s4[1] += (double)pa[2 * i + 1];
+        s4[2] += (double)pb[2 * i];
+        s4[3] += (double)pb[2 * i + 1];
+    }
+    block_sum<4>(s4, red, tot);
+    const float m1x = (float)(tot[0] / n), m1y = (float)(tot[1] / n);
+    const float m2x = (float)(tot[2] / n), m2y = (float)(tot[3] / n);
+    __syncthreads();
+    double d2[2] = {0.0, 0.0};
+    for (int i = threadIdx.x; i < n; i += HT) {
+        const float ax = pa[2 * i] - m1x, ay = pa[2 * i + 1] - m1y;
+        const float bx = pb[2 * i] - m2x, by = pb[2 * i + 1] - m2y;
+        d2[0] += (double)sqrtf(ax * ax + ay * ay);
+        d2[1] += (double)sqrtf(bx * bx + by * by);
+    }
+    block_sum<2>(d2, red, tot);
+    const float s1 = sqrtf(2.0f) / ((float)(tot[0] / n) + 1e-8f);
+    const float s2 = sqrtf(2.0f) / ((float)(tot[1] / n) + 1e-8f);
+    const float t1x = -s1 * m1x, t1y = -s1 * m1y, t2x = -s2 * m2x, t2y = -s2 * m2y;
+    __syncthreads();
+
+    // ---- (re-)weighted normal equations, n_solves solves -----------------------------------------
+    for (int it = 0; it < n_solves; ++it) {
+        double g[NG];
+#pragma unroll
+        for (int k = 0; k < NG; ++k) g[k] = 0.0;
+        float sol[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sol[k] = (it > 0) ? sol_s[k] : 0.f;
+        for (int i = threadIdx.x; i < n; i += HT) {
+            const float x1 = s1 * pa[2 * i] + t1x, y1 = s1 * pa[2 * i + 1] + t1y;
+            const float x2 = s2 * pb[2 * i] + t2x, y2 = s2 * pb[2 * i + 1] + t2y;
+            const float wv = (w != nullptr) ? w[i] : 1.f;
+            float rx[9], ry[9];
+            build_rows(x1, y1, x2, y2, wv, rx, ry);
+            if (it > 0 && reweight != 0) {
+                float resx = -rx[8], resy = -ry[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    resx += rx[k] * sol[k];
+                    resy += ry[k] * sol[k];
+                }
+                const float qx = sqrtf(reweight_fn(resx, reweight, huber_k));
+                const float qy = sqrtf(reweight_fn(resy, reweight, huber_k));
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    rx[k] *= qx;
+                    ry[k] *= qy;
+                }
+            }
+            int idx = 0;
+#pragma unroll
+            for (int a = 0; a < 9; ++a)
+#pragma unroll
+                for (int b = a; b < 9; ++b) {
+                    g[idx] += (double)rx[a] * (double)rx[b] + (double)ry[a] * (double)ry[b];
+                    ++idx;
+                }
+        }
+        block_sum<NG>(g, red, tot);
+        if (threadIdx.x == 0) {
+            // Cholesky of G[0:8,0:8] = L L^T, solve L L^T x = G[0:8,8]
+            double L[8][8], rhs[8];
+            int idx = 0;
+            double G[9][9];
+            for (int a = 0; a < 9; ++a)
+                for (int b = a; b < 9; ++b) {
+                    G[a][b] = tot[idx];
+                    G[b][a] = tot[idx];
+                    ++idx;
+                }
+            bool ok = true;
+            for (int i = 0; i < 8 && ok; ++i) {
+                for (int j = 0; j <= i; ++j) {
+                    double s = G[i][j];
+                    for (int k = 0; k < j; ++k) s -= L[i][k] * L[j][k];
+                    if (i == j) {
+                        if (!(s > 0.0)) { ok = false; break; }
+                        L[i][i] = sqrt(s);
+                    } else {
+                        L[i][j] = s / L[j][j];
+                    }
+                }
+            }
+            if (ok) {
+                for (int i = 0; i < 8; ++i) {
+                    double s = G[i][8];
+                    for (int k = 0; k < i; ++k) s -= L[i][k] * rhs[k];
+                    rhs[i] = s / L[i][i];
+                }
+                for (int i = 7; i >= 0; --i) {
+                    double s = rhs[i];
+                    for (int k = i + 1; k < 8; ++k) s -= L[k][i] * rhs[k];
+                    rhs[i] = s / L[i][i];
+                }
+                for (int i = 0; i < 8; ++i) sol_s[i] = (float)rhs[i];
+            } else {
+                fail_s = 1;
+            }
+        }
+        __syncthreads();
+        if (fail_s) break;
+    }
+
+    if (threadIdx.x == 0) {
+        if (fail_s) {
+            status[0] = 2;
+            for (int i = 0; i < 9; ++i) Hout[i] = nanf("");
+            return;
+        }
+        // H = T2^-1 * Hn * T1, then H / (h33 + 1e-8)   (least_squares_H.py:204-209)
+        const double hn[9] = {sol_s[0], sol_s[1], sol_s[2], sol_s[3], sol_s[4], sol_s[5], sol_s[6], sol_s[7], 1.0};
+        const double T1[9] = {s1, 0, t1x, 0, s1, t1y, 0, 0, 1};
+        const double i2 = 1.0 / (double)s2;
+        const double T2i[9] = {i2, 0, -(double)t2x * i2, 0, i2, -(double)t2y * i2, 0, 0, 1};
+        double tmp[9], hh[9];
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) {
+                double s = 0;
+                for (int k = 0; k < 3; ++k) s += hn[r * 3 + k] * T1[k * 3 + c];
+                tmp[r * 3 + c] = s;
+            }
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) {
+                double s = 0;
+                for (int k = 0; k < 3; ++k) s += T2i[r * 3 + k] * tmp[k * 3 + c];
+                hh[r * 3 + c] = s;
+            }
+        const double den = hh[8] + 1e-8;
+        for (int i = 0; i < 9; ++i) Hout[i] = (float)(hh[i] / den);
+        status[0] = 0;
+    }
+}
+
+// frac[0] = mean_i( || proj(H, A_i) - B_i || <= thr )
+__global__ __launch_bounds__(HT) void inlier_frac_kernel(const float* __restrict__ pa, const float* __restrict__ pb,
+                                                         int n_max, const int* __restrict__ count,
+                                                         const float* __restrict__ H, float thr,
+                                                         float* __restrict__ frac) {
+    __shared__ double red[HT / 64];
+    __shared__ double tot[1];
+    int n = n_max;
+    if (count != nullptr) n = min(count[0], n_max);
+    float h[9];
+    for (int i = 0; i < 9; ++i) h[i] = H[i];
+    double c[1] = {0.0};
+    for (int i = threadIdx.x; i < n; i += HT) {
+        const float x = pa[2 * i], y = pa[2 * i + 1];
+        const float px = h[0] * x + h[1] * y + h[2], py = h[3] * x + h[4] * y + h[5], pz = h[6] * x + h[7] * y + h[8];
+        const float sc = (fabsf(pz) > 1e-8f) ? 1.f / (pz + 1e-8f) : 1.f;
+        const float dx = sc * px - pb[2 * i], dy = sc * py - pb[2 * i + 1];
+        c[0] += (sqrtf(dx * dx + dy * dy) <= thr) ? 1.0 : 0.0;
+    }
+    block_sum<1>(c, red, tot);
+    if (threadIdx.x == 0) frac[0] = (n > 0) ? (float)(tot[0] / n) : 0.f;
+}
+
+}  // namespace
+
+extern "C" int woft_hfit(const float* pa, const float* pb, const float* w, int32_t n_max, const int32_t* count,
+                         int32_t reweight, float huber_k, int32_t n_irls, float* Hout, int32_t* status, void* stream) {
+    if (!pa || !pb || !Hout || !status || n_max < 0 || reweight < 0 || reweight > 2 || n_irls < 0) return WOFT_EINVAL;
+    hipLaunchKernelGGL(hfit_kernel, dim3(1), dim3(HT), 0, (hipStream_t)stream, pa, pb, w, n_max, count, reweight,
+                       huber_k, n_irls + 1, Hout, status);
+    return woft_launch_status();
+}
+
+extern "C" int woft_inlier_frac(const float* pa, const float* pb, int32_t n_max, const int32_t* count, const float* H,
+                                float thr, float* frac, void* stream) {
+    if (!pa || !pb || !H || !frac || n_max < 0) return WOFT_EINVAL;
+    hipLaunchKernelGGL(inlier_frac_kernel, dim3(1), dim3(HT), 0, (hipStream_t)stream, pa, pb, n_max, count, H, thr,
+                       frac);
+    return woft_launch_status();
+}

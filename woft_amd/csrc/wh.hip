@@ -1,0 +1,106 @@
+// Weight-head glue kernels (weighted_raft.py:258-279, 347-384): the mean-response channel in its
+// algebraic form, the packing of the (scrambled) lookup channels into 9x9 patches, and the final
+// 1x1 conv + patch mean.  The three 3x3 convolutions in between run on the MFMA conv kernel.
+#include "common.h"
+
+namespace {
+
+// stage 1: partial[b][c] = sum over the pixel strip of block b;  stage 2: total[c] (double)
+__global__ void colsum_stage1(const float* __restrict__ f, int64_t n_pix, int c, double* __restrict__ partial,
+                              int n_part) {
+    const int64_t per = (n_pix + n_part - 1) / n_part;
+    const int64_t beg = (int64_t)blockIdx.x * per;
+    const int64_t end = beg + per < n_pix ? beg + per : n_pix;
+    for (int ch = threadIdx.x; ch < c; ch += blockDim.x) {
+        double s = 0.0;
+        for (int64_t q = beg; q < end; ++q) s += (double)f[q * c + ch];
+        partial[(int64_t)blockIdx.x * c + ch] = s;
+    }
+}
+__global__ void colsum_stage2(const double* __restrict__ partial, int n_part, int c, double* __restrict__ total) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    double s = 0.0;
+    for (int b = 0; b < n_part; ++b) s += partial[(int64_t)b * c + ch];
+    total[ch] = s;
+}
+
+// mean[p] = alpha * <f1[p], total>   -- one wavefront per pixel, shuffle reduction
+__global__ __launch_bounds__(256) void wh_mean_kernel(const float* __restrict__ f1, int c,
+                                                      const double* __restrict__ total, float alpha,
+                                                      int64_t n_pix, float* __restrict__ mean) {
+    const int lane = threadIdx.x & 63;
+    const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= n_pix) return;
+    double s = 0.0;
+    for (int ch = lane; ch < c; ch += 64) s += (double)f1[p * c + ch] * total[ch];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) mean[p] = (float)(s * (double)alpha);
+}
+
+// x8[p][t][0..3] = lookup[p][t*4 .. t*4+3]  (the reference reads the level-major lookup channels
+// as (hp wp level)), x8[p][t][4] = mean[p], x8[p][t][5..7] = 0
+__global__ void wh_pack_kernel(const float* __restrict__ lookup, int ld, const float* __restrict__ mean,
+                               int64_t n_pix, int nwin2, float* __restrict__ x8) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pix * nwin2) return;
+    const int64_t p = i / nwin2;
+    const int t = (int)(i - p * nwin2);
+    const f32x4 a = *(const f32x4*)(lookup + p * ld + t * 4);
+    const f32x4 b = {mean[p], 0.f, 0.f, 0.f};
+    *(f32x4*)(x8 + i * 8) = a;
+    *(f32x4*)(x8 + i * 8 + 4) = b;
+}
+
+// out[p] = bias + (1/nwin2) * sum_t <w, act[p][t][:]>  -- one wavefront per pixel
+__global__ __launch_bounds__(256) void wh_reduce_kernel(const float* __restrict__ act, int c, int nwin2,
+                                                        const float* __restrict__ w, float bias, int64_t n_pix,
+                                                        float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= n_pix) return;
+    const int c4 = c / 4, n4 = nwin2 * c4;
+    const float* a = act + p * (int64_t)nwin2 * c;
+    float s = 0.f;
+    for (int i = lane; i < n4; i += 64) {
+        const f32x4 v = *(const f32x4*)(a + (int64_t)i * 4);
+        const f32x4 ww = *(const f32x4*)(w + (i % c4) * 4);
+        s += v[0] * ww[0] + v[1] * ww[1] + v[2] * ww[2] + v[3] * ww[3];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) out[p] = bias + s / (float)nwin2;
+}
+
+}  // namespace
+
+extern "C" int woft_colsum(const float* f, int64_t n_pix, int32_t c, double* ws, int32_t n_part, double* total,
+                           void* stream) {
+    if (!f || !ws || !total || n_pix <= 0 || c <= 0 || n_part <= 0) return WOFT_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(colsum_stage1, dim3(n_part), dim3(256), 0, s, f, n_pix, c, ws, n_part);
+    hipLaunchKernelGGL(colsum_stage2, dim3((c + 255) / 256), dim3(256), 0, s, ws, n_part, c, total);
+    return woft_launch_status();
+}
+
+extern "C" int woft_wh_pack(const float* lookup, int32_t ld_lookup, const float* f1, int32_t c, const double* f2_total,
+                            float alpha, int64_t n_pix, int32_t nwin, float* mean, float* x8, void* stream) {
+    if (!lookup || !f1 || !f2_total || !mean || !x8 || n_pix <= 0 || nwin <= 0 || c <= 0) return WOFT_EINVAL;
+    if (ld_lookup < nwin * nwin * 4 || ld_lookup % 4 != 0) return WOFT_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(wh_mean_kernel, dim3((unsigned)ceil_div64(n_pix, 4)), dim3(256), 0, s, f1, c, f2_total, alpha,
+                       n_pix, mean);
+    const int64_t n = n_pix * nwin * nwin;
+    hipLaunchKernelGGL(wh_pack_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, s, lookup, ld_lookup, mean,
+                       n_pix, nwin * nwin, x8);
+    return woft_launch_status();
+}
+
+extern "C" int woft_wh_reduce(const float* act, int32_t c, int32_t nwin2, const float* w, float bias, int64_t n_pix,
+                              float* out, void* stream) {
+    if (!act || !w || !out || c <= 0 || c % 4 != 0 || nwin2 <= 0 || n_pix <= 0) return WOFT_EINVAL;
+    hipLaunchKernelGGL(wh_reduce_kernel, dim3((unsigned)ceil_div64(n_pix, 4)), dim3(256), 0, (hipStream_t)stream, act,
+                       c, nwin2, w, bias, n_pix, out);
+    return woft_launch_status();
+}

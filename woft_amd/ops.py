@@ -1,0 +1,288 @@
+"""Thin Python layer over the C ABI: tensor bookkeeping, weight packing, one function per kernel.
+
+All tensors are torch CUDA (=HIP) tensors; the library enqueues on torch's current stream.
+Activations are NHWC fp32: a tensor of shape (n_pix, channel_stride) (pixels of all images
+flattened) -- `Act` carries the geometry.
+"""
+import ctypes as C
+import math
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import ConvParams, LookupParams, check, ptr, stream_ptr
+
+DEV = "cuda"
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+@dataclass
+class Act:
+    """NHWC activation: t is (n_img*h*w, cs) fp32 contiguous; `c` valid channels."""
+    t: torch.Tensor
+    n: int
+    h: int
+    w: int
+    c: int
+
+    @property
+    def cs(self):
+        return self.t.shape[1]
+
+    @property
+    def n_pix(self):
+        return self.n * self.h * self.w
+
+    def nchw(self):
+        """(n, c, h, w) copy -- test / boundary helper."""
+        return self.t[:, :self.c].reshape(self.n, self.h, self.w, self.c).permute(0, 3, 1, 2).contiguous()
+
+
+def act_from_nchw(x, cs=None):
+    n, c, h, w = x.shape
+    cs = cs or _round_up(c, 4)
+    t = torch.zeros(n * h * w, cs, dtype=torch.float32, device=DEV)
+    t[:, :c] = x.to(DEV).permute(0, 2, 3, 1).reshape(n * h * w, c)
+    return Act(t, n, h, w, c)
+
+
+def new_act(n, h, w, c, cs=None, zero=False):
+    cs = cs or _round_up(c, 4)
+    f = torch.zeros if zero else torch.empty
+    return Act(f(n * h * w, cs, dtype=torch.float32, device=DEV), n, h, w, c)
+
+
+# ------------------------------------------------------------------------------------------
+# weight packing
+# ------------------------------------------------------------------------------------------
+@dataclass
+class PackedConv:
+    wgt: torch.Tensor        # (cout_pad, taps*cin_pad) fp32 on device
+    bias: torch.Tensor       # (cout_pad,)
+    cout: int
+    cout_pad: int
+    cin_pad: int
+    taps_y: int
+    taps_x: int
+    pad_y: int
+    pad_x: int
+    stride: int
+    flat: int
+    flat_cs: int = 0
+    kh: int = 0              # real kernel size (flat packing folds kw into the K chunk)
+    kw: int = 0
+
+    def out_hw(self, h, w):
+        kh, kw = (self.kh or self.taps_y), (self.kw or self.taps_x)
+        return (h + 2 * self.pad_y - kh) // self.stride + 1, (w + 2 * self.pad_x - kw) // self.stride + 1
+
+
+def pack_conv(weight, bias, stride=1, padding=None, cin_layout=None, flat_cs=0, scale=1.0):
+    """OIHW conv weight -> [cout_pad][taps][cin_pad] (K contiguous).
+
+    cin_layout: list of (src_begin, src_end, dst_begin) channel ranges mapping the reference's
+                input-channel order onto the (padded) channel order of our input buffers;
+                default = identity.
+    flat_cs:    >0 -> "flat" packing for tiny Cin: the K chunk of tap ky is kw pixels x flat_cs
+                channels laid out as the NHWC row itself (k = kx*flat_cs + c), padded to 32.
+    """
+    weight = weight.detach().float().cpu() * scale
+    cout, cin, kh, kw = weight.shape
+    if padding is None:
+        padding = (kh // 2, kw // 2)
+    if isinstance(padding, int):
+        padding = (padding, padding)
+    cout_pad = _round_up(cout, 64)
+    if cout_pad > 64:
+        cout_pad = _round_up(cout, 128)
+    b = torch.zeros(cout_pad)
+    if bias is not None:
+        b[:cout] = bias.detach().float().cpu() * scale
+    if flat_cs:
+        assert kw * flat_cs <= 32 and cin <= flat_cs
+        wp = torch.zeros(cout_pad, kh, 32)
+        for kx in range(kw):
+            wp[:cout, :, kx * flat_cs:kx * flat_cs + cin] = weight[:, :, :, kx].permute(0, 2, 1)
+        return PackedConv(wp.reshape(cout_pad, kh * 32).contiguous().to(DEV), b.to(DEV), cout, cout_pad, 32,
+                          kh, 1, padding[0], padding[1], stride, 1, flat_cs, kh, kw)
+    if cin_layout is None:
+        cin_layout = [(0, cin, 0)]
+    cin_pad = _round_up(max(d + (e - s) for s, e, d in cin_layout), 32)
+    wp = torch.zeros(cout_pad, kh * kw, cin_pad)
+    wt = weight.permute(0, 2, 3, 1).reshape(cout, kh * kw, cin)
+    for s, e, d in cin_layout:
+        wp[:cout, :, d:d + (e - s)] = wt[:, :, s:e]
+    return PackedConv(wp.reshape(cout_pad, kh * kw * cin_pad).contiguous().to(DEV), b.to(DEV), cout, cout_pad,
+                      cin_pad, kh, kw, padding[0], padding[1], stride, 0, 0, kh, kw)
+
+
+def fold_bn(weight, bias, bn_w, bn_b, mean, var, eps=1e-5):
+    """Eval-mode BatchNorm folded into the preceding conv (extractor.py:22-26)."""
+    s = (bn_w.double() / torch.sqrt(var.double() + eps))
+    w = (weight.double() * s[:, None, None, None]).float()
+    b = ((bias.double() - mean.double()) * s + bn_b.double()).float()
+    return w, b
+
+
+def pick_tiles(m, cout_pad):
+    tn = 128 if cout_pad % 128 == 0 else 64
+    blocks128 = math.ceil(m / 128) * (cout_pad // tn)
+    tm = 128 if blocks128 >= 512 else 64
+    return tm, tn
+
+
+# ------------------------------------------------------------------------------------------
+# kernels
+# ------------------------------------------------------------------------------------------
+def conv_params(x, pc, out, co_off=0, epi=_lib.EPI_LINEAR, x2=None, c_split=0, e0=None, e1=None, out1=None,
+                split=0, alpha=1.0, stats=None, ho=None, wo=None, tiles=None, cout=None):
+    """Build (and keep alive) a woft_conv_params for `out[:, co_off:co_off+cout] = epi(conv(x))`."""
+    if ho is None or wo is None:
+        ho, wo = pc.out_hw(x.h, x.w)
+    p = ConvParams()
+    p.in0, p.cs0 = ptr(x.t), x.cs
+    if x2 is not None:
+        p.in1, p.cs1, p.c_split = ptr(x2.t), x2.cs, c_split
+    else:
+        p.in1, p.cs1, p.c_split = None, 0, pc.cin_pad
+    p.n_img, p.h, p.w, p.ho, p.wo = x.n, x.h, x.w, ho, wo
+    p.taps_y, p.taps_x, p.stride, p.pad_y, p.pad_x = pc.taps_y, pc.taps_x, pc.stride, pc.pad_y, pc.pad_x
+    p.cin_pad, p.flat = pc.cin_pad, pc.flat
+    p.wgt, p.bias, p.alpha = ptr(pc.wgt), ptr(pc.bias), alpha
+    p.cout, p.cout_pad = (cout or pc.cout), pc.cout_pad
+    p.out, p.ldo, p.co_off = ptr(out.t), out.cs, co_off
+    p.out_w, p.out_pitch = 0, 0
+    p.epi, p.split = epi, split
+    p.e0, p.lde0 = (ptr(e0.t), e0.cs) if e0 is not None else (None, 0)
+    p.e1, p.lde1 = (ptr(e1.t), e1.cs) if e1 is not None else (None, 0)
+    p.out1, p.ldo1 = (ptr(out1.t), out1.cs) if out1 is not None else (None, 0)
+    m = x.n * ho * wo
+    tm, tn = tiles or pick_tiles(m, pc.cout_pad)
+    p.tile_m, p.tile_n = tm, tn
+    if stats is not None:
+        rows = 2 * math.ceil(m / tm)
+        assert stats[0].numel() >= rows * pc.cout_pad
+        p.stat_sum, p.stat_sq = ptr(stats[0]), ptr(stats[1])
+    else:
+        p.stat_sum, p.stat_sq = None, None
+    p._keep = (x, x2, pc, out, e0, e1, out1, stats)
+    p._m = m
+    return p
+
+
+def run_conv(p):
+    check(_lib.load().woft_conv2d(C.byref(p), stream_ptr()), "woft_conv2d")
+
+
+def conv2d(x, pc, c_out_stride=None, **kw):
+    """Convenience: allocate the output and run.  Returns Act."""
+    ho, wo = pc.out_hw(x.h, x.w)
+    out = kw.pop("out", None) or new_act(x.n, ho, wo, pc.cout, cs=c_out_stride or _round_up(pc.cout, 4), zero=True)
+    p = conv_params(x, pc, out, ho=ho, wo=wo, **kw)
+    run_conv(p)
+    return out
+
+
+def inorm_finalize(stats, n_part, ld, channels, count, mean, rstd, eps=1e-5):
+    check(_lib.load().woft_inorm_finalize(ptr(stats[0]), ptr(stats[1]), n_part, ld, channels, count, eps,
+                                          ptr(mean), ptr(rstd), stream_ptr()), "woft_inorm_finalize")
+
+
+def inorm_apply(x, mean, rstd, out, mode, res=None):
+    assert x.cs == x.c and out.cs == x.c
+    check(_lib.load().woft_inorm_apply(ptr(x.t), ptr(mean), ptr(rstd), ptr(res.t) if res is not None else None,
+                                       ptr(out.t), x.n_pix, x.c, mode, stream_ptr()), "woft_inorm_apply")
+
+
+def preprocess(img_u8, out, hp, wp, pad_top, pad_left):
+    h, w = img_u8.shape[:2]
+    check(_lib.load().woft_preprocess_bgr_u8(ptr(img_u8), h, w, ptr(out.t), hp, wp, pad_top, pad_left, stream_ptr()),
+          "woft_preprocess_bgr_u8")
+
+
+def avgpool2(x, out):
+    check(_lib.load().woft_avgpool2_nhwc(ptr(x.t), x.h, x.w, x.cs, ptr(out.t), stream_ptr()), "woft_avgpool2_nhwc")
+
+
+def corr_volume(f1, f2_rows, n_q, out, wq, pitch, alpha):
+    """out[p][ (q // wq) * pitch + q % wq ] = alpha * <f1[p], f2_rows[q]>, q < n_q.
+    f1: Act (P, C); f2_rows: tensor (rows_pad, C) zero padded to a multiple of 128 rows."""
+    pc = PackedConv(f2_rows, None, n_q, f2_rows.shape[0], f1.cs, 1, 1, 0, 0, 1, 0)
+    p = ConvParams()
+    p.in0, p.cs0, p.in1, p.cs1, p.c_split = ptr(f1.t), f1.cs, None, 0, f1.cs
+    p.n_img, p.h, p.w, p.ho, p.wo = 1, f1.h, f1.w, f1.h, f1.w
+    p.taps_y = p.taps_x = p.stride = 1
+    p.pad_y = p.pad_x = 0
+    p.cin_pad, p.flat = f1.cs, 0
+    p.wgt, p.bias, p.alpha = ptr(f2_rows), None, alpha
+    p.cout, p.cout_pad = n_q, f2_rows.shape[0]
+    p.out, p.ldo, p.co_off = ptr(out), out.shape[1], 0
+    p.out_w, p.out_pitch = (wq, pitch) if pitch != wq else (0, 0)
+    p.epi = _lib.EPI_LINEAR
+    p.tile_m, p.tile_n = (128, 128) if f2_rows.shape[0] % 128 == 0 else (128, 64)
+    p._keep = (f1, f2_rows, out)
+    return p
+
+
+def make_lookup_params(vols, dims, pitches, coords, out, radius):
+    p = LookupParams()
+    for l, v in enumerate(vols):
+        p.vol[l] = ptr(v)
+        p.hl[l], p.wl[l] = dims[l]
+        p.pitch[l] = pitches[l]
+        p.plane[l] = dims[l][0] * pitches[l]
+    p.levels, p.radius = len(vols), radius
+    p.coords, p.n_pix, p.out, p.ldo = ptr(coords), coords.shape[0], ptr(out), out.shape[1]
+    p._keep = (vols, coords, out)
+    return p
+
+
+def run_lookup(p):
+    check(_lib.load().woft_corr_lookup(C.byref(p), stream_ptr()), "woft_corr_lookup")
+
+
+def coords_init(coords, hf, wf, flow4=None, flow_cat=None, ld_cat=0):
+    check(_lib.load().woft_coords_init(ptr(coords), hf, wf, ptr(flow4), ptr(flow_cat), ld_cat, stream_ptr()),
+          "woft_coords_init")
+
+
+def coords_update(coords, delta, ld_delta, wf, flow4=None, flow_cat=None, ld_cat=0):
+    check(_lib.load().woft_coords_update(ptr(coords), ptr(delta), ld_delta, wf, coords.shape[0], ptr(flow4),
+                                         ptr(flow_cat), ld_cat, stream_ptr()), "woft_coords_update")
+
+
+def convex_upsample(coords, wlow, mask, hf, wf, crop, h, w, flow_up=None, dst=None, wout=None, do_sigmoid=False):
+    check(_lib.load().woft_convex_upsample(ptr(coords), ptr(wlow), ptr(mask), mask.shape[1], hf, wf, crop[0], crop[1],
+                                           h, w, ptr(flow_up), ptr(dst), ptr(wout), int(do_sigmoid), stream_ptr()),
+          "woft_convex_upsample")
+
+
+def upflow8(coords, wlow, hf, wf, crop, h, w, flow_up=None, dst=None, wout=None, do_sigmoid=False):
+    check(_lib.load().woft_upflow8(ptr(coords), ptr(wlow), hf, wf, crop[0], crop[1], h, w, ptr(flow_up), ptr(dst),
+                                   ptr(wout), int(do_sigmoid), stream_ptr()), "woft_upflow8")
+
+
+def warp_perspective_u8(img, Hmat, out=None, valid=None, nearest=False):
+    """img: (H,W,C) or (H,W) uint8 CUDA tensor; Hmat: 3x3 numpy (src -> dst).  dst(x) = src(H^-1 x)."""
+    h, w = img.shape[:2]
+    c = 1 if img.dim() == 2 else img.shape[2]
+    hinv = np.ascontiguousarray(np.linalg.inv(np.asarray(Hmat, dtype=np.float64)).reshape(9))
+    arr = (C.c_double * 9)(*hinv.tolist())
+    check(_lib.load().woft_warp_perspective_u8(ptr(img), h, w, c, arr, ptr(out), ptr(valid), int(nearest),
+                                               stream_ptr()), "woft_warp_perspective_u8")
+
+
+def hfit(pa, pb, w, Hout, status, count=None, reweight=0, huber_k=1.0, n_irls=0):
+    n = pa.shape[0]
+    check(_lib.load().woft_hfit(ptr(pa), ptr(pb), ptr(w), n, ptr(count), reweight, float(huber_k), n_irls,
+                                ptr(Hout), ptr(status), stream_ptr()), "woft_hfit")
+
+
+def inlier_frac(pa, pb, Hm, frac, thr=5.0, count=None):
+    check(_lib.load().woft_inlier_frac(ptr(pa), ptr(pb), pa.shape[0], ptr(count), ptr(Hm), float(thr), ptr(frac),
+                                       stream_ptr()), "woft_inlier_frac")
