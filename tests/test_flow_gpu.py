@@ -1,0 +1,138 @@
+"""GPU parity of the whole flow operator (encoders -> volume -> refinement -> weight head ->
+upsampling -> TC epilogue) against the CPU oracle and the golden vectors of the imported
+reference.  Tolerances: GPU fp32 vs oracle EPE mean <= 1e-3 px, max <= 1e-2 px,
+sigmoid(weights) <= 1e-4."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import raft_ref  # noqa: E402  (checker only)
+from woft_amd import synth  # noqa: E402
+
+
+def _t(a):
+    return torch.from_numpy(a[:, :, ::-1].copy()).permute(2, 0, 1).float()[None]
+
+
+def _flow_config(sd, iters, raft_type="weighted", padding_mode="nopad", small=False):
+    from woft_amd.config import Config
+    from woft_amd.flow_provider import RAFTWrapper
+    c = Config()
+    c.of_class = RAFTWrapper
+    c.raft_type = raft_type
+    c.class_params = Config()
+    c.class_params.small = small
+    c.class_params.mixed_precision = False
+    c.class_params.alternate_corr = False
+    c.class_params.weight_head_structure = [(128, 3)] * 3
+    c.model = sd
+    c.iters = iters
+    c.padding_mode = padding_mode
+    return c
+
+
+def _epe(a, b):
+    d = a.detach().cpu().float() - b.detach().cpu().float()
+    e = torch.sqrt((d ** 2).sum(dim=-3))
+    return float(e.mean()), float(e.max())
+
+
+@torch.no_grad()
+def test_stages_against_oracle(golden_dir):
+    """Stage-by-stage comparison on the 128x160 golden pair (first failing stage is the culprit)."""
+    g = np.load(golden_dir / "flow_full_128x160_it4.npz")
+    sd = synth.make_state_dict(seed=int(g["seed"]))
+    tr = {}
+    ref = raft_ref.raft_forward(sd, _t(g["img1"]), _t(g["img2"]), 4, trace=tr)
+    from woft_amd.engine import RaftEngine
+    eng = RaftEngine(sd)
+    plan = eng.plan(128, 160)
+    plan.load_image(0, torch.from_numpy(g["img1"]).cuda(), 0, 0)
+    plan.load_image(1, torch.from_numpy(g["img2"]).cuda(), 0, 0)
+    plan.encode_source()
+    snaps = []
+
+    def trace(p, it):
+        snaps.append(dict(lookup=p.corr.nchw().cpu(), net=p.hB.nchw().cpu(),
+                          coords=p.coords.cpu().reshape(p.hf, p.wf, 2).permute(2, 0, 1).clone()))
+    fu, dst, wo = (torch.zeros(2, 128, 160, device="cuda"), torch.zeros(2, 128 * 160, device="cuda"),
+                   torch.zeros(1, 128 * 160, device="cuda"))
+    plan.flow(4, (0, 0), 128, 160, flow_up=fu, dst=dst, wout=wo, do_sigmoid=False, trace=trace)
+    torch.cuda.synchronize()
+
+    def close(a, b, tol, what):
+        err = float((a.cpu() - b).abs().max())
+        assert err <= tol, f"{what}: max err {err:.3e} > {tol:.1e} (ref max {float(b.abs().max()):.2e})"
+
+    close(plan.f1.nchw(), tr["fmap1"], 2e-4, "fmap1")
+    close(plan.f2act[0].nchw(), tr["fmap2"], 2e-4, "fmap2")
+    close(torch.from_numpy(g["fmap1"]), tr["fmap1"], 1e-4, "oracle vs golden fmap1")
+    close(plan.net0.nchw(), tr["net0"], 5e-5, "net0")
+    close(plan.xbuf.nchw()[:, :128], tr["inp"], 5e-5, "inp")
+    for l in range(4):
+        hl, wl = plan.dims[l]
+        v = plan.vol[l].reshape(plan.P, hl, plan.pitch[l])[:, :, :wl]
+        close(v, tr["pyr"][l][:, 0], 3e-4, f"volume level {l}")
+    close(snaps[0]["lookup"], tr["lookups"][0], 5e-4, "lookup 0")
+    close(snaps[0]["net"], tr["nets"][0], 2e-4, "net after iter 0")
+    for it in range(4):
+        close(snaps[it]["coords"], tr["coords"][it][0], 2e-3, f"coords after iter {it}")
+    m, mx = _epe(fu, ref["flow_up"][0])
+    assert m < 1e-3 and mx < 1e-2, ("flow_up vs oracle", m, mx)
+    m, mx = _epe(fu, torch.from_numpy(g["flow_up"])[0])
+    assert m < 1e-3 and mx < 1e-2, ("flow_up vs golden", m, mx)
+    close(plan.wlow.reshape(1, 1, plan.hf, plan.wf), ref["weights_low"], 2e-3, "weight logits (1/8 res)")
+    close(wo.reshape(1, 1, 128, 160), ref["weights_up"], 2e-3, "weight logits (full res)")
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("name", ["flow_full_136x200_it12"])
+def test_operator_vs_golden(golden_dir, name):
+    g = np.load(golden_dir / f"{name}.npz")
+    sd = synth.make_state_dict(seed=int(g["seed"]))
+    fc = _flow_config(sd, int(g["iters"]))
+    flower = fc.of_class(fc)
+    flow, w = flower.compute_flow(g["img1"], g["img2"], mode="flow", do_sigmoid=False)
+    torch.cuda.synchronize()
+    assert tuple(flow.shape) == (2, 136, 200) and tuple(w.shape) == (1, 136, 200)
+    m, mx = _epe(flow, torch.from_numpy(g["flow_up"])[0])
+    assert m < 1e-3 and mx < 1e-2, (m, mx)
+    assert float((torch.sigmoid(w.cpu()) - torch.sigmoid(torch.from_numpy(g["w_up"])[0])).abs().max()) < 1e-4
+
+
+@torch.no_grad()
+def test_operator_tc_boundary(golden_dir):
+    """RAFTWrapper.compute_flow contract: types, shapes, TC mode, replicate padding, pinned source."""
+    g = np.load(golden_dir / "wrapper_tc_128x160_it4.npz")
+    sd = synth.make_state_dict(seed=int(g["seed"]))
+    fc = _flow_config(sd, int(g["iters"]))
+    flower = fc.of_class(fc)
+    flower.pin_source(g["img1"])
+    for rep in range(2):                                   # second call hits the template cache
+        src, dst, w = flower.compute_flow(g["img1"], g["img2"], mode="TC", do_sigmoid=True)
+        torch.cuda.synchronize()
+        assert src.dtype == torch.int64 and tuple(src.shape) == (2, 128 * 160) and src.is_cuda
+        assert dst.dtype == torch.float32 and tuple(dst.shape) == (2, 128 * 160)
+        assert tuple(w.shape) == (1, 128 * 160)
+        assert np.array_equal(src.cpu().numpy(), g["src"])
+        assert np.abs(dst.cpu().numpy() - g["dst"]).max() < 1e-2
+        assert np.abs(w.cpu().numpy() - g["w"]).max() < 1e-4
+    assert flower.last_flow_shape == {"batch": 1, "delta": 2, "H": 128, "W": 160}
+    with pytest.raises(AssertionError):
+        flower.compute_flow(g["img1"], g["img2"][:-8], mode="TC")
+    with pytest.raises(AssertionError):
+        flower.compute_flow(g["img1"], g["img2"], mode="bogus")
+    with pytest.raises(AssertionError):                    # nopad insists on multiples of 8 (raft.py:223-226)
+        flower.compute_flow(g["img1"][:125], g["img2"][:125], mode="TC")
+    fc2 = _flow_config(sd, int(g["iters"]), padding_mode="RAFT")
+    fl2 = fc2.of_class(fc2)
+    a2, b2 = g["img1"][:125, :157].copy(), g["img2"][:125, :157].copy()
+    s2, d2, w2 = fl2.compute_flow(a2, b2, mode="TC", do_sigmoid=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(s2.cpu().numpy(), g["src_pad"])
+    assert np.abs(d2.cpu().numpy() - g["dst_pad"]).max() < 1e-2
+    assert np.abs(w2.cpu().numpy() - g["w_pad"]).max() < 1e-4

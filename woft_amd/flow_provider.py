@@ -1,0 +1,136 @@
+"""Flow-provider operator: the MI355X counterpart of the reference's RAFTWrapper
+(/root/reference/pytracking/optical_flow/raft.py:29-218), same constructor config keys, same
+`compute_flow` signature, return types and error behaviour.  `pytracking.optical_flow.raft`
+(the compatibility shim) re-exports it under the reference's import path.
+"""
+import logging
+from timeit import default_timer as timer
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from .engine import RaftEngine
+
+logger = logging.getLogger(__name__)
+
+
+def _pad_geometry(h, w, mode):
+    """-> (hp, wp, pad_top, pad_left, out_h, out_w, load_h, load_w)"""
+    if mode == "nopad":                                   # raft.py:221-226
+        assert h % 8 == 0
+        assert w % 8 == 0
+        return h, w, 0, 0, h, w, h, w
+    if mode == "crop":                                    # raft.py:235-247 (outputs keep the cropped size)
+        ch, cw = (h // 8) * 8, (w // 8) * 8
+        return ch, cw, 0, 0, ch, cw, ch, cw
+    if mode == "RAFT":                                    # raft_core/utils/utils.py:7-26, 'sintel' mode
+        ph = (((h // 8) + 1) * 8 - h) % 8
+        pw = (((w // 8) + 1) * 8 - w) % 8
+        return h + ph, w + pw, ph // 2, pw // 2, h, w, h, w
+    if mode == "Michal":
+        raise NotImplementedError("padding_mode 'Michal' (bilinear rescale, raft.py:250-271) is not on the HIP path")
+    raise ValueError(f"invalid padding_mode '{mode}'")
+
+
+class RAFTWrapper:
+    def __init__(self, config):
+        self.C = config
+        cp = config.class_params
+        if cp.alternate_corr:
+            raise NotImplementedError("alternate_corr is never enabled by the reference configs (corr.py:72-100)")
+        if cp.mask_estimation:
+            raise NotImplementedError("mask_estimation (MaskHead) is unset in every shipped config")
+        if self.C.raft_type not in ("orig", "weighted"):
+            raise ValueError(f"Unknown RAFT type {self.C.raft_type}")
+        logger.info(f"Loading weights from: {self.C.model}")
+        state_dict = self.C.model if isinstance(self.C.model, dict) else torch.load(self.C.model, map_location="cpu")
+        state_dict = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in state_dict.items()}
+        weighted = self.C.raft_type == "weighted"
+        small = bool(cp.small)
+        if small:
+            from .engine_small import RaftEngineSmall
+            self.engine = RaftEngineSmall(state_dict, weighted=weighted)
+        else:
+            self.engine = RaftEngine(state_dict, weighted=weighted)
+        self._pinned = None
+        self._pinned_key = None
+        self._out = {}
+
+    # ---- template caching (results-identical: InstanceNorm is per sample, extractor.py:171-190) ----
+    def pin_source(self, src_img):
+        """Declare `src_img` (an ndarray the caller will not mutate) as a recurring source image:
+        its feature/context tensors are computed once and reused by compute_flow(src_img, ...)."""
+        self._pinned = src_img
+        self._pinned_key = None
+
+    def postprocess_weights(self, flat_weights, fn):
+        s = self.last_flow_shape
+        weights = fn(flat_weights.reshape(s["batch"], 1, s["H"], s["W"]))
+        return weights.reshape(s["batch"], s["H"] * s["W"])
+
+    def _outputs(self, h, w):
+        key = (h, w)
+        if key not in self._out:
+            z = lambda *s: torch.empty(*s, dtype=torch.float32, device="cuda")
+            self._out[key] = dict(flow=z(2, h, w), dst=z(2, h * w), w=z(1, h * w),
+                                  src=torch.stack([torch.arange(h * w, device="cuda") % w,
+                                                   torch.div(torch.arange(h * w, device="cuda"), w, rounding_mode="floor")]))
+        return self._out[key]
+
+    def compute_flow(self, src_img, dst_img, mode="TC", vis=False, src_img_identifier=None,
+                     numpy_out=False, do_sigmoid=False):
+        """src_img / dst_img: (H, W, 3) uint8 BGR (numpy, or CUDA tensors already on the device).
+        mode 'TC' -> (src_coords (2,HW) int64, dst_coords (2,HW) f32, weights (1,HW) f32 | None)
+        mode 'flow' -> (flow (2,H,W), weights (1,H,W) | None)."""
+        assert mode in ["flow", "TC"]
+        assert src_img.shape == dst_img.shape
+        if src_img_identifier is not None and self.C.flow_cache_dir:
+            logger.debug("flow cache (utils/caching.py) is not part of the HIP path; computing the flow")
+        H, W = src_img.shape[:2]
+        hp, wp, top, left, oh, ow, lh, lw = _pad_geometry(H, W, self.C.padding_mode)
+        plan = self.engine.plan(hp, wp)
+        start_time = timer()
+
+        def up(a):
+            if isinstance(a, torch.Tensor):
+                t = a if a.is_cuda else a.cuda(non_blocking=True)
+            else:
+                t = torch.from_numpy(np.ascontiguousarray(a)).cuda(non_blocking=True)
+            if (lh, lw) != (H, W):
+                t = t[:lh, :lw].contiguous()
+            return t.contiguous()
+
+        key = (hp, wp, top, left)
+        if src_img is self._pinned and self._pinned_key == key and plan.source_tag is self:
+            pass                                           # fmap1 / net / inp still resident in the plan
+        else:
+            s = up(src_img)
+            plan.load_image(0, s, top, left)
+            plan.encode_source()
+            plan.source_tag = self if src_img is self._pinned else None
+            self._pinned_key = key if src_img is self._pinned else None
+        d = up(dst_img)
+        plan.load_image(1, d, top, left)
+        o = self._outputs(oh, ow)
+        weighted = self.C.raft_type == "weighted"
+        plan.flow(int(self.C.iters), (top, left), oh, ow, flow_up=o["flow"], dst=o["dst"],
+                  wout=o["w"] if weighted else None, do_sigmoid=bool(do_sigmoid))
+        logger.debug(f"flow enqueue time [s]: {float(timer() - start_time)}")
+        weights = o["w"] if weighted else None
+        if self.C.weights_postprocessing_fn and weights is not None:
+            # the reference applies it to the logits before the sigmoid (raft.py:152-159)
+            raise NotImplementedError("weights_postprocessing_fn is None in every shipped config")
+        if mode == "flow":
+            flow = o["flow"]
+            wts = weights.reshape(1, oh, ow) if weights is not None else None
+            if numpy_out:
+                flow = flow.cpu().numpy()
+                wts = wts.cpu().numpy() if wts is not None else None
+            return flow, wts
+        self.last_flow_shape = {"batch": 1, "delta": 2, "H": oh, "W": ow}
+        src_coords, dst_coords = o["src"], o["dst"]
+        if numpy_out:
+            return (src_coords.cpu().numpy(), dst_coords.cpu().numpy(),
+                    weights.cpu().numpy() if weights is not None else None)
+        return src_coords, dst_coords, weights
