@@ -116,6 +116,7 @@ class _Plan:
         assert hp % 8 == 0 and wp % 8 == 0
         self.eng, self.hp, self.wp = eng, hp, wp
         self.source_tag = None
+        self.lookup_events = None      # bench hook: list collecting (start, end) HIP events per lookup launch
         hf, wf = hp // 8, wp // 8
         self.hf, self.wf, self.P = hf, wf, hf * wf
         P = self.P
@@ -278,12 +279,22 @@ class _Plan:
             elif kind == "pool":
                 ops.avgpool2(a[0], a[1])
             elif kind == "lookup":
-                ops.run_lookup(a)
+                self._lookup(a)
             elif kind == "coords":
                 ops.coords_update(self.coords, self.delta.t, self.delta.cs, self.wf, self.flow4.t,
                                   self.xbuf.t[:, 254:], self.xbuf.cs)
             else:
                 raise ValueError(kind)
+
+    def _lookup(self, params):
+        if self.lookup_events is None:
+            ops.run_lookup(params)
+            return
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        ops.run_lookup(params)
+        e.record()
+        self.lookup_events.append((s, e))
 
     def load_image(self, slot, img_u8, pad_top, pad_left):
         ops.preprocess(img_u8, self.img[slot], self.hp, self.wp, pad_top, pad_left)
@@ -309,7 +320,7 @@ class _Plan:
             ops.run_conv(p)
         wlow = None
         if e.weighted:
-            ops.run_lookup(self.lookup)                              # final lookup, weighted_raft.py:266
+            self._lookup(self.lookup)                                # final lookup, weighted_raft.py:266
             lib = _lib.load()
             _lib.check(lib.woft_colsum(_lib.ptr(self.f2act[0].t), self.P, 256, _lib.ptr(self.cs_ws), 256,
                                        _lib.ptr(self.cs_tot), _lib.stream_ptr()), "woft_colsum")
