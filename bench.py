@@ -43,6 +43,18 @@ def make_sequence(H, W, seq_id, n_frames):
     return template, frames
 
 
+def usable_cores():
+    """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(sd, template, mask, frame_np, iters):
     """The CPU oracle (torch-CPU restatement of the reference path, parity-checked against the
     imported reference) timed on the host cores for one tracked frame."""
@@ -136,7 +148,7 @@ def main():
                      "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": lk_avg, "launches_timed": len(lk_ms)},
     }
     if world == 1 and not args.no_cpu_baseline:
-        torch.set_num_threads(os.cpu_count() or 1)
+        torch.set_num_threads(usable_cores())
         f0 = frames[0].cpu().numpy()
         dt, Hr, tc = cpu_baseline(sd, template, mask, f0, args.iters)
         # quality gate on the same frame: flow EPE of the HIP path against the CPU oracle

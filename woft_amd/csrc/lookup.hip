@@ -23,64 +23,63 @@ template <int R>
 __global__ __launch_bounds__(256) void corr_lookup_kernel(const woft_lookup_params p) {
     constexpr int WIN = 2 * R + 2;       // integer patch side
     constexpr int NW = 2 * R + 1;        // output window side
-    __shared__ float patch[WAVES_PER_BLOCK][4][WIN * WIN];
+    constexpr int W2 = WIN * WIN, N2 = NW * NW;
+    constexpr int NLOAD = (4 * W2 + 63) / 64, NOUT = (4 * N2 + 63) / 64;
+    __shared__ float patch[WAVES_PER_BLOCK][4 * W2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t pix = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave;
     const bool active = pix < p.n_pix;
-    const int L = p.levels;
+    const int ntap = p.levels * W2, nout = p.levels * N2;
 
     float cx = 0.f, cy = 0.f;
     if (active) {
         cx = p.coords[pix * 2 + 0];
         cy = p.coords[pix * 2 + 1];
     }
-    // per-level integer origin and fractional parts (division by 2^l is exact in fp32)
-    int x0[4], y0[4];
-    float fx[4], fy[4];
+
+    // ---- gather: all of a lane's taps are issued before any is consumed -----------------------
+    float v[NLOAD];
 #pragma unroll
-    for (int l = 0; l < 4; ++l) {
-        const float sc = 1.0f / (float)(1 << l);
-        const float xs = cx * sc, ys = cy * sc;
-        float flx = floorf(xs), fly = floorf(ys);
-        fx[l] = xs - flx;
-        fy[l] = ys - fly;
+    for (int k = 0; k < NLOAD; ++k) {
+        const int t = lane + 64 * k;
+        const int l = t / W2;                       // level of this tap (lane dependent)
+        const int rem = t - l * W2;
+        const int ry = rem / WIN, rx = rem - ry * WIN;
+        const float sc = 1.0f / (float)(1 << l);    // exact: x / 2^l
+        float flx = floorf(cx * sc), fly = floorf(cy * sc);
         flx = fminf(fmaxf(flx, -1.0e6f), 1.0e6f);   // keeps the int conversion defined for wild coords
         fly = fminf(fmaxf(fly, -1.0e6f), 1.0e6f);
-        x0[l] = (int)flx - R;
-        y0[l] = (int)fly - R;
-    }
-
-    // ---- gather: L * WIN*WIN taps, lane-contiguous along window rows -------------------------
-    const int ntap = L * WIN * WIN;
-    for (int t = lane; t < ntap; t += 64) {
-        const int l = t / (WIN * WIN);
-        const int rem = t - l * (WIN * WIN);
-        const int ry = rem / WIN, rx = rem - ry * WIN;
-        int ox = x0[0], oy = y0[0];
-        if (l == 1) { ox = x0[1]; oy = y0[1]; }
-        if (l == 2) { ox = x0[2]; oy = y0[2]; }
-        if (l == 3) { ox = x0[3]; oy = y0[3]; }
-        const int gx = ox + rx, gy = oy + ry;
+        const int gx = (int)flx - R + rx, gy = (int)fly - R + ry;
         float val = 0.f;
-        if (active && gx >= 0 && gx < p.wl[l] && gy >= 0 && gy < p.hl[l])
-            val = p.vol[l][pix * p.plane[l] + (int64_t)gy * p.pitch[l] + gx];
-        patch[wave][l][rem] = val;
+        if (active && t < ntap) {
+            const int ll = l < 4 ? l : 3;
+            if (gx >= 0 && gx < p.wl[ll] && gy >= 0 && gy < p.hl[ll])
+                val = p.vol[ll][pix * p.plane[ll] + (int64_t)gy * p.pitch[ll] + gx];
+        }
+        v[k] = val;
+    }
+#pragma unroll
+    for (int k = 0; k < NLOAD; ++k) {
+        const int t = lane + 64 * k;
+        if (t < 4 * W2) patch[wave][t] = v[k];
     }
     __syncthreads();
 
-    // ---- interpolate + write --------------------------------------------------------------------
+    // ---- interpolate + write (dword stores, 256 B per wave instruction; 16-B-per-lane stores were
+    //      measured slower: 53 vs 49 us at 1080p) -------------------------------------------------
     if (!active) return;
-    const int nout = L * NW * NW;
     float* o = p.out + pix * p.ldo;
-    for (int c = lane; c < nout; c += 64) {
-        const int l = c / (NW * NW);
-        const int rem = c - l * (NW * NW);
+#pragma unroll
+    for (int k = 0; k < NOUT; ++k) {
+        const int c = lane + 64 * k;
+        if (c >= nout) break;
+        const int l = c / N2;
+        const int rem = c - l * N2;
         const int i = rem / NW, j = rem - i * NW;      // i: x offset, j: y offset (x-major window)
-        float wx = fx[0], wy = fy[0];
-        if (l == 1) { wx = fx[1]; wy = fy[1]; }
-        if (l == 2) { wx = fx[2]; wy = fy[2]; }
-        if (l == 3) { wx = fx[3]; wy = fy[3]; }
-        const float* q = &patch[wave][l][j * WIN + i];
+        const float sc = 1.0f / (float)(1 << l);
+        const float xs = cx * sc, ys = cy * sc;
+        const float wx = xs - floorf(xs), wy = ys - floorf(ys);
+        const float* q = &patch[wave][l * W2 + j * WIN + i];
         const float top = q[0] * (1.f - wx) + q[1] * wx;
         const float bot = q[WIN] * (1.f - wx) + q[WIN + 1] * wx;
         o[c] = top * (1.f - wy) + bot * wy;
