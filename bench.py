@@ -83,6 +83,8 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--iters", type=int, default=12)
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3", "bf16"],
+                    help="conv / correlation-GEMM arithmetic: exact fp32 MFMA, split-bf16 (fp32-emulating), bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-template-cache", action="store_true",
                     help="recompute the template's features every frame, as the reference does")
@@ -99,6 +101,7 @@ def main():
     conf = load_config(ROOT / "pytracking" / "configs" / "WOFT.py")
     conf.flow_config.model = sd
     conf.flow_config.iters = args.iters
+    conf.flow_config.precision = args.precision
     tracker = conf.tracker_class(conf)
     template, frames = make_sequence(H, W, rank, Wm + K)
     mask = synth.make_init_mask(H, W)
@@ -136,7 +139,8 @@ def main():
         "metric": "tracked frames/sec at 1080p, 12 RAFT iters; flow EPE vs reference",
         "value": world * K / elapsed, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
         "ms_per_step": 1000.0 * elapsed / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": {"fp32": "f32", "bf16x3": "bf16x3 (split-bf16 MFMA operands emulating fp32, fp32 accumulate)",
+                  "bf16": "bf16 (fp32 accumulate)"}[args.precision], "data": "synthetic",
         "config": {"workload": f"{H}x{W} synthetic sequence per GPU: WeightedRAFT-full {args.iters} iters + "
                                "weighted LSq homography on Sobol-500 correspondences (reference default config WOFT.py)",
                    "resolution": [H, W], "iters": args.iters, "sequences": world,

@@ -59,7 +59,10 @@ typedef struct woft_conv_params {
     int32_t stride, pad_y, pad_x;
     int32_t cin_pad;       /* GEMM-K per tap, multiple of 32                                   */
     int32_t flat;          /* 1: the 32-float K chunk of a tap runs along x over 32/cs0 pixels */
-    const float* wgt;      /* [cout_pad][taps_y*taps_x*cin_pad], K contiguous                  */
+    const float* wgt;      /* [cout_pad][taps_y*taps_x*cin_pad] fp32, K contiguous (precision 0) */
+    const void* wgt_hi;    /* same shape, bf16: hi = bf16(w)          (precision 1, 2)         */
+    const void* wgt_lo;    /* same shape, bf16: lo = bf16(w - hi)     (precision 1)            */
+    int32_t precision;     /* 0: fp32 MFMA; 1: split-bf16 x3 (fp32-emulating); 2: bf16         */
     const float* bias;     /* [cout_pad] or NULL                                               */
     float alpha;           /* scale applied to the accumulator                                 */
     int32_t cout;          /* valid output channels                                            */
@@ -81,6 +84,9 @@ typedef struct woft_conv_params {
 } woft_conv_params;
 
 int woft_conv2d(const woft_conv_params* p, void* stream);
+/* fp32 array (n % 4 == 0) -> bf16 planes hi = bf16(x), lo = bf16(x - hi) (lo may be NULL): the
+ * split form of a dynamic B operand (fmap2 in the correlation GEMM). */
+int woft_split_bf16(const float* x, int64_t n, void* hi, void* lo, void* stream);
 
 /* InstanceNorm (extractor.py:28-32,129-130; nn.InstanceNorm2d eps=1e-5, biased variance):
  * finalize per-channel statistics from the conv epilogue's partial sums ... */

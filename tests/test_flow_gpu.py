@@ -18,7 +18,7 @@ def _t(a):
     return torch.from_numpy(a[:, :, ::-1].copy()).permute(2, 0, 1).float()[None]
 
 
-def _flow_config(sd, iters, raft_type="weighted", padding_mode="nopad", small=False):
+def _flow_config(sd, iters, raft_type="weighted", padding_mode="nopad", small=False, precision=None):
     from woft_amd.config import Config
     from woft_amd.flow_provider import RAFTWrapper
     c = Config()
@@ -32,6 +32,8 @@ def _flow_config(sd, iters, raft_type="weighted", padding_mode="nopad", small=Fa
     c.model = sd
     c.iters = iters
     c.padding_mode = padding_mode
+    if precision:
+        c.precision = precision
     return c
 
 
@@ -136,3 +138,20 @@ def test_operator_tc_boundary(golden_dir):
     assert np.array_equal(s2.cpu().numpy(), g["src_pad"])
     assert np.abs(d2.cpu().numpy() - g["dst_pad"]).max() < 1e-2
     assert np.abs(w2.cpu().numpy() - g["w_pad"]).max() < 1e-4
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("precision,epe_mean,epe_max,wtol", [("bf16x3", 1e-3, 1e-2, 1e-4), ("bf16", 5e-2, 0.5, 5e-3)])
+def test_reduced_precision_operating_points(golden_dir, precision, epe_mean, epe_max, wtol):
+    """Split-bf16 (fp32-emulating) and plain bf16 MFMA paths against the reference's golden flow.
+    Stated budgets: bf16x3 keeps the fp32 tolerances; bf16 EPE mean <= 0.05 px."""
+    g = np.load(golden_dir / "flow_full_136x200_it12.npz")
+    sd = synth.make_state_dict(seed=int(g["seed"]))
+    fc = _flow_config(sd, int(g["iters"]), precision=precision)
+    flower = fc.of_class(fc)
+    flow, w = flower.compute_flow(g["img1"], g["img2"], mode="flow", do_sigmoid=True)
+    torch.cuda.synchronize()
+    m, mx = _epe(flow, torch.from_numpy(g["flow_up"])[0])
+    print(f"{precision}: EPE mean {m:.2e} max {mx:.2e}")
+    assert m < epe_mean and mx < epe_max, (m, mx)
+    assert float((w.cpu() - torch.sigmoid(torch.from_numpy(g["w_up"])[0])).abs().max()) < wtol

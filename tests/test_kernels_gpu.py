@@ -44,21 +44,22 @@ def _close(a, b, atol, rtol=0.0, what=""):
     (256, 2, 3, 1, 17, 25, None),
     (64, 96, 1, 2, 20, 28, None),
 ])
-def test_conv_plain(ops, cin, cout, k, stride, h, w, tiles):
+@pytest.mark.parametrize("precision,tol", [("fp32", 2e-5), ("bf16x3", 1e-4), ("bf16", 3e-2)])
+def test_conv_plain(ops, cin, cout, k, stride, h, w, tiles, precision, tol):
     x = _rand(2, cin, h, w, seed=1)
     wt = _rand(cout, cin, k, k, seed=2, scale=1.0 / math.sqrt(cin * k * k))
     b = _rand(cout, seed=3, scale=0.1)
     ref = F.conv2d(x, wt, b, stride=stride, padding=k // 2)
     pc = ops.pack_conv(wt, b, stride=stride)
     xa = ops.act_from_nchw(x, cs=ops._round_up(cin, 32))
-    out = ops.conv2d(xa, pc, tiles=tiles)
+    out = ops.conv2d(xa, pc, tiles=tiles, precision=precision)
     torch.cuda.synchronize()
-    _close(out.nchw(), ref, 2e-5, what="conv")
+    _close(out.nchw(), ref, tol, what=f"conv {precision}")
     # relu epilogue, written at a channel offset into a wider buffer
     big = ops.new_act(2, ref.shape[2], ref.shape[3], cout + 8, cs=ops._round_up(cout + 8, 4), zero=True)
-    ops.run_conv(ops.conv_params(xa, pc, big, co_off=8, epi=ops._lib.EPI_RELU, tiles=tiles))
+    ops.run_conv(ops.conv_params(xa, pc, big, co_off=8, epi=ops._lib.EPI_RELU, tiles=tiles, precision=precision))
     torch.cuda.synchronize()
-    _close(big.t[:, 8:8 + cout].reshape(2, ref.shape[2], ref.shape[3], cout).permute(0, 3, 1, 2), F.relu(ref), 2e-5,
+    _close(big.t[:, 8:8 + cout].reshape(2, ref.shape[2], ref.shape[3], cout).permute(0, 3, 1, 2), F.relu(ref), tol,
            what="conv relu offset")
     assert float(big.t[:, :8].abs().max()) == 0.0
 
@@ -89,33 +90,36 @@ def test_conv_gru_epilogues(ops, kh, kw):
     _close(hn.nchw(), ref, 3e-5, what="h")
 
 
-def test_conv_flat_first_layer(ops):
+@pytest.mark.parametrize("precision,tol", [("fp32", 1.0), ("bf16x3", 6.0)])
+def test_conv_flat_first_layer(ops, precision, tol):
     """7x7 stride-2 conv on a 3-channel image stored NHWC4 (extractor.py:132), flat K packing."""
+    import functools
+    conv2d = functools.partial(ops.conv2d, precision=precision)
     x = _rand(1, 3, 40, 56, seed=9)
     wt = _rand(64, 3, 7, 7, seed=10, scale=0.1)
     b = _rand(64, seed=11, scale=0.1)
     ref = F.conv2d(x, wt, b, stride=2, padding=3)
     pc = ops.pack_conv(wt, b, stride=2, padding=3, flat_cs=4)
     xa = ops.act_from_nchw(x, cs=4)
-    out = ops.conv2d(xa, pc)
+    out = conv2d(xa, pc)
     torch.cuda.synchronize()
-    _close(out.nchw(), ref, 2e-5, what="conv7x7s2 flat")
+    _close(out.nchw(), ref, 2e-5 * tol, what="conv7x7s2 flat")
     # 7x7 stride-1 on a 2-channel flow field (update.py:84)
     x = _rand(1, 2, 17, 25, seed=12, scale=3.0)
     wt = _rand(128, 2, 7, 7, seed=13, scale=0.1)
     b = _rand(128, seed=14, scale=0.1)
     ref = F.conv2d(x, wt, b, padding=3)
-    out = ops.conv2d(ops.act_from_nchw(x, cs=4), ops.pack_conv(wt, b, padding=3, flat_cs=4))
+    out = conv2d(ops.act_from_nchw(x, cs=4), ops.pack_conv(wt, b, padding=3, flat_cs=4))
     torch.cuda.synchronize()
-    _close(out.nchw(), ref, 2e-5, what="conv7x7 flow flat")
+    _close(out.nchw(), ref, 2e-5 * tol, what="conv7x7 flow flat")
     # 3x3 on batches of 9x9 5-channel patches stored with 8 channels (weighted_raft.py:336-338)
     x = _rand(37, 5, 9, 9, seed=15, scale=5.0)
     wt = _rand(128, 5, 3, 3, seed=16, scale=0.2)
     b = _rand(128, seed=17, scale=0.1)
     ref = F.conv2d(x, wt, b, padding=1)
-    out = ops.conv2d(ops.act_from_nchw(x, cs=8), ops.pack_conv(wt, b, padding=1, flat_cs=8))
+    out = conv2d(ops.act_from_nchw(x, cs=8), ops.pack_conv(wt, b, padding=1, flat_cs=8))
     torch.cuda.synchronize()
-    _close(out.nchw(), ref, 5e-5, what="conv3x3 patches flat")
+    _close(out.nchw(), ref, 5e-5 * tol, what="conv3x3 patches flat")
 
 
 def test_residual_epilogue_and_bn_fold(ops):
@@ -179,7 +183,7 @@ def test_preprocess_and_pool(ops):
 # ------------------------------------------------------------------------------------------
 # correlation volume + lookup
 # ------------------------------------------------------------------------------------------
-def _build_pyramid_gpu(ops, f1, f2):
+def _build_pyramid_gpu(ops, f1, f2, precision="fp32"):
     """f1, f2: (1, C, H, W) cpu tensors -> volumes [P][hl][pitch] on the GPU via the conv/GEMM kernel."""
     _, c, h, w = f1.shape
     a1, a2 = ops.act_from_nchw(f1), ops.act_from_nchw(f2)
@@ -191,7 +195,11 @@ def _build_pyramid_gpu(ops, f1, f2):
         rows = torch.zeros(ops._round_up(hl * wl, 128), c, device="cuda")
         rows[:hl * wl] = cur.t
         vol = torch.zeros(h * w, hl * pitch, device="cuda")
-        ops.run_conv(ops.corr_volume(a1, rows, hl * wl, vol, wl, pitch, 1.0 / math.sqrt(c)))
+        hi, lo = torch.zeros_like(rows, dtype=torch.bfloat16), torch.zeros_like(rows, dtype=torch.bfloat16)
+        if precision != "fp32":
+            ops.split_bf16(rows, hi, lo)
+        ops.run_conv(ops.corr_volume(a1, rows, hl * wl, vol, wl, pitch, 1.0 / math.sqrt(c), precision=precision,
+                                     f2_hi=hi, f2_lo=lo))
         vols.append(vol)
         dims.append((hl, wl))
         pitches.append(pitch)
@@ -203,15 +211,18 @@ def _build_pyramid_gpu(ops, f1, f2):
     return vols, dims, pitches
 
 
-@pytest.mark.parametrize("h,w", [(16, 20), (17, 25)])
-def test_corr_volume_and_lookup(ops, h, w):
+@pytest.mark.parametrize("h,w,precision,tol", [(16, 20, "fp32", 3e-5), (17, 25, "fp32", 3e-5), (17, 25, "bf16x3", 2e-4),
+                                               (16, 20, "bf16", 5e-2)])
+def test_corr_volume_and_lookup(ops, h, w, precision, tol):
     f1, f2 = _rand(1, 256, h, w, seed=31), _rand(1, 256, h, w, seed=32)
     pyr = raft_ref.corr_pyramid(f1, f2)
-    vols, dims, pitches = _build_pyramid_gpu(ops, f1, f2)
+    vols, dims, pitches = _build_pyramid_gpu(ops, f1, f2, precision)
     for l in range(4):
         hl, wl = dims[l]
         got = vols[l].reshape(h * w, hl, pitches[l])[:, :, :wl]
-        _close(got, pyr[l][:, 0], 3e-5, what=f"volume level {l}")
+        _close(got, pyr[l][:, 0], tol, what=f"volume level {l}")
+    if precision != "fp32":
+        return
     coords = raft_ref.coords_grid(1, h, w) + _rand(1, 2, h, w, seed=33, scale=6.0)
     coords[0, :, 0, 0] = torch.tensor([-7.3, 2.2])
     coords[0, :, 0, 1] = torch.tensor([w + 9.5, h + 3.0])

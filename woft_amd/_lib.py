@@ -21,7 +21,8 @@ class ConvParams(C.Structure):
         ("in0", vp), ("in1", vp), ("cs0", i32), ("cs1", i32), ("c_split", i32),
         ("n_img", i32), ("h", i32), ("w", i32), ("ho", i32), ("wo", i32),
         ("taps_y", i32), ("taps_x", i32), ("stride", i32), ("pad_y", i32), ("pad_x", i32),
-        ("cin_pad", i32), ("flat", i32), ("wgt", vp), ("bias", vp), ("alpha", f32),
+        ("cin_pad", i32), ("flat", i32), ("wgt", vp), ("wgt_hi", vp), ("wgt_lo", vp), ("precision", i32),
+        ("bias", vp), ("alpha", f32),
         ("cout", i32), ("cout_pad", i32), ("out", vp), ("ldo", i64), ("co_off", i32),
         ("out_w", i32), ("out_pitch", i32), ("epi", i32), ("split", i32),
         ("e0", vp), ("e1", vp), ("lde0", i32), ("lde1", i32), ("out1", vp), ("ldo1", i32),
@@ -40,6 +41,7 @@ _SIGS = {
     "woft_abi_version": (i32, []),
     "woft_sizeof": (i32, [i32]),
     "woft_conv2d": (i32, [C.POINTER(ConvParams), vp]),
+    "woft_split_bf16": (i32, [vp, i64, vp, vp, vp]),
     "woft_inorm_finalize": (i32, [vp, vp, i32, i32, i32, i64, f32, vp, vp, vp]),
     "woft_inorm_apply": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, vp]),
     "woft_preprocess_bgr_u8": (i32, [vp, i32, i32, vp, i32, i32, i32, i32, vp]),

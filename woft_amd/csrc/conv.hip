@@ -1,4 +1,4 @@
-// Implicit-GEMM convolution / NT-GEMM on f32-input MFMA for gfx950 (MI355X).
+// Implicit-GEMM convolution / NT-GEMM on the gfx950 matrix cores (MI355X).
 //
 //   C[m][n] = alpha * sum_k A[m][k] * B[n][k] + bias[n]      (then a fused epilogue)
 //
@@ -6,22 +6,33 @@
 //   n : output channel                                       (GEMM N)
 //   k : (tap, input channel); 32 channels of one tap per K step
 //
-// A rows are gathered from one or two NHWC sources (channel concat without a copy), zero filled
-// outside the image.  B is the pre-packed weight matrix [cout_pad][taps*cin_pad] (K contiguous) --
-// or, for the all-pairs correlation volume (corr.py:62-69), the second feature map itself.
+// A rows are gathered from one or two NHWC fp32 sources (channel concat without a copy), zero
+// filled outside the image.  B is the pre-packed weight matrix [cout_pad][taps*cin_pad] (K
+// contiguous) -- or, for the all-pairs correlation volume (corr.py:62-69), the second feature map.
 //
 // Block = 256 threads = 4 waves as 2(M) x 2(N); block tile BM x BN in {64,128}^2; each wave owns
-// (BM/2) x (BN/2) as 32x32 tiles of v_mfma_f32_32x32x2_f32 (exact fp32: a k-ordered fmaf chain).
-// Both operand tiles are staged through LDS with a 36-float row pitch (conflict-free
-// ds_read_b128 fragment reads); global loads for step k+1 are issued into registers before the
-// MFMAs of step k (register double buffering).  Each lane half (lane>>5) consumes its own
-// contiguous 16-wide k range of the step, so fragments are read as 4 x ds_read_b128.
-#include "common.h"
+// (BM/2) x (BN/2) as 32x32 MFMA tiles.  Two arithmetic modes:
+//
+//  * precision 0 -- v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulation (a k-ordered
+//    fmaf chain), 157 TF peak.  Operand tiles in LDS as fp32, 36-float row pitch (conflict-free
+//    ds_read_b128); each lane half consumes its own contiguous 16-wide k range of the step.
+//  * precision 1/2 -- v_mfma_f32_32x32x16_bf16 on SPLIT operands: every fp32 operand x is split
+//    on the fly into hi = bf16(x) and lo = bf16(x - hi) (weights are pre-split once), and
+//      precision 1 ("bf16x3"):  acc += Ahi*Bhi + Ahi*Blo + Alo*Bhi   (~2^-16 relative products)
+//      precision 2 ("bf16"):    acc += Ahi*Bhi
+//    with fp32 accumulation; the MFMA rate is 16x the fp32 one, so bf16x3 has a 5.3x higher matrix
+//    ceiling than precision 0 at near-fp32 accuracy.  LDS tiles are bf16 with an 80-byte row pitch
+//    (conflict-free ds_read_b128 fragment reads).
+//
+// In both modes the global loads for step k+1 are issued into registers before the MFMAs of step k.
+#include "conv_common.h"
 
 namespace {
 
-constexpr int BK = 32;
-constexpr int LDS_LD = 36;   // floats; 144 B rows: 16-B aligned, conflict-free for b128 reads
+using woft::ARows;
+using woft::BK;
+
+constexpr int LDS_LD = 36;   // fp32 tiles: floats per row (144 B: 16-B aligned, conflict-free b128 reads)
 
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void conv_mfma_f32_kernel(const woft_conv_params p) {
@@ -44,58 +55,15 @@ __global__ __launch_bounds__(256) void conv_mfma_f32_kernel(const woft_conv_para
     const int nk = p.taps_y * p.taps_x * nchunk;
     const int64_t ktot = (int64_t)nk * BK;
 
-    // ---- per-thread A row bookkeeping -------------------------------------------------------
-    int iy0[RA], ix0[RA];
-    int64_t img_base[RA];
-    bool mvalid[RA];
-    {
-        const int hw = p.ho * p.wo;
-#pragma unroll
-        for (int j = 0; j < RA; ++j) {
-            int64_t m = m0 + r0 + 32 * j;
-            mvalid[j] = m < M;
-            if (!mvalid[j]) m = 0;
-            const int img = (int)(m / hw);
-            const int rem = (int)(m - (int64_t)img * hw);
-            const int oy = rem / p.wo, ox = rem - oy * p.wo;
-            iy0[j] = oy * p.stride - p.pad_y;
-            ix0[j] = ox * p.stride - p.pad_x;
-            img_base[j] = (int64_t)img * p.h * p.w;
-        }
-    }
+    ARows<RA> arows;
+    woft::a_rows_init<RA>(p, m0, r0, M, arows);
     const float* brow[RB];
 #pragma unroll
     for (int j = 0; j < RB; ++j) brow[j] = p.wgt + (int64_t)(n0 + r0 + 32 * j) * ktot + 4 * v;
 
     f32x4 ra[RA], rb[RB];
     auto load_tiles = [&](int ks) {
-        const int tap = ks / nchunk;
-        const int c0 = (ks - tap * nchunk) * BK;
-        const int ky = tap / p.taps_x, kx = tap - ky * p.taps_x;
-        if (!p.flat) {
-            const bool second = (p.in1 != nullptr) && (c0 >= p.c_split);
-            const float* src = second ? p.in1 : p.in0;
-            const int cs = second ? p.cs1 : p.cs0;
-            const int cc = (second ? c0 - p.c_split : c0) + 4 * v;
-#pragma unroll
-            for (int j = 0; j < RA; ++j) {
-                const int iy = iy0[j] + ky, ix = ix0[j] + kx;
-                const bool ok = mvalid[j] && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w;
-                f32x4 val = {0.f, 0.f, 0.f, 0.f};
-                if (ok) val = *(const f32x4*)(src + (img_base[j] + (int64_t)iy * p.w + ix) * cs + cc);
-                ra[j] = val;
-            }
-        } else {
-            const int dpix = (4 * v) / p.cs0;
-#pragma unroll
-            for (int j = 0; j < RA; ++j) {
-                const int iy = iy0[j] + ky, ixp = ix0[j] + dpix;
-                const bool ok = mvalid[j] && iy >= 0 && iy < p.h && ixp >= 0 && ixp < p.w;
-                f32x4 val = {0.f, 0.f, 0.f, 0.f};
-                if (ok) val = *(const f32x4*)(p.in0 + (img_base[j] + (int64_t)iy * p.w + ix0[j]) * p.cs0 + 4 * v);
-                ra[j] = val;
-            }
-        }
+        woft::a_load<RA>(p, arows, ks, nchunk, v, ra);
 #pragma unroll
         for (int j = 0; j < RB; ++j) rb[j] = *(const f32x4*)(brow[j] + (int64_t)ks * BK);
     };
@@ -150,70 +118,138 @@ __global__ __launch_bounds__(256) void conv_mfma_f32_kernel(const woft_conv_para
             __syncthreads();
         }
     }
+    woft::conv_epilogue<BM, BN>(p, acc, m0, n0, wm, wn, r32, hh, M);
+}
 
-    // ---- epilogue -----------------------------------------------------------------------------
-    // C/D layout of the 32x32 MFMA: column = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
-    const bool do_stats = p.stat_sum != nullptr;
+// ---- split-bf16 kernel -------------------------------------------------------------------------
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int LDB = 40;      // bf16 tiles: elements per row (80 B: 16-B aligned, conflict-free b128 reads)
+
+template <int BM, int BN, int TERMS>
+__global__ __launch_bounds__(256) void conv_mfma_bf16_kernel(const woft_conv_params p) {
+    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int RA = BM / 32;            // float4 rows per thread (A, fp32 source)
+    constexpr int RB = BN / 64;            // 16-B rows per thread and plane (B, pre-split bf16)
+    constexpr int NP = (TERMS == 3) ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) __bf16 smem[(BM + BN) * LDB * NP];
+    __bf16* As = smem;                                 // [NP][BM][LDB]
+    __bf16* Bs = smem + NP * BM * LDB;                 // [NP][BN][LDB]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r32 = lane & 31, hh = lane >> 5;
+    const int v = tid & 7, r0 = tid >> 3;              // A loader: float4 column, base row
+    const int vb = tid & 3, rb0 = tid >> 2;            // B loader: 16-B column, base row
+
+    const int64_t M = (int64_t)p.n_img * p.ho * p.wo;
+    const int64_t m0 = (int64_t)blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    const int nchunk = p.cin_pad / BK;
+    const int nk = p.taps_y * p.taps_x * nchunk;
+    const int64_t ktot = (int64_t)nk * BK;
+
+    ARows<RA> arows;
+    woft::a_rows_init<RA>(p, m0, r0, M, arows);
+    const __bf16* bsrc[NP];
+    bsrc[0] = (const __bf16*)p.wgt_hi;
+    if (NP == 2) bsrc[NP - 1] = (const __bf16*)p.wgt_lo;
+
+    f32x4 ra[RA];
+    bf16x8 rb[NP][RB];
+    auto load_tiles = [&](int ks) {
+        woft::a_load<RA>(p, arows, ks, nchunk, v, ra);
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * (BN / 2) + j * 32 + r32;
-        const bool nvalid = n < p.cout;
-        const float bias = (p.bias != nullptr) ? p.bias[n] : 0.f;
-        int64_t col = n;
-        if (p.out_pitch != 0) col = (int64_t)(n / p.out_w) * p.out_pitch + (n % p.out_w);
-        col += p.co_off;
-        float ssum = 0.f, ssq = 0.f;
+        for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+            for (int j = 0; j < RB; ++j)
+                rb[pl][j] = *(const bf16x8*)(bsrc[pl] + (int64_t)(n0 + rb0 + 64 * j) * ktot + (int64_t)ks * BK + 8 * vb);
+    };
+    auto store_tiles = [&]() {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t m = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                const bool ok = nvalid && (m < M);
-                float y = p.alpha * acc[i][j][r] + bias;
-                if (do_stats && ok) { ssum += y; ssq += y * y; }
-                if (!ok) continue;
-                switch (p.epi) {
-                    case WOFT_EPI_LINEAR: break;
-                    case WOFT_EPI_RELU: y = fmaxf(y, 0.f); break;
-                    case WOFT_EPI_SIGMOID: y = sigmoidf_(y); break;
-                    case WOFT_EPI_TANH: y = tanhf(y); break;
-                    case WOFT_EPI_RELU_RES_RELU:
-                        y = fmaxf(p.e0[m * p.lde0 + n] + fmaxf(y, 0.f), 0.f);
-                        break;
-                    case WOFT_EPI_GRU_ZR:
-                        y = sigmoidf_(y);
-                        if (n >= p.split) {
-                            p.out1[m * p.ldo1 + (n - p.split)] = y * p.e0[m * p.lde0 + (n - p.split)];
-                            continue;
-                        }
-                        break;
-                    case WOFT_EPI_GRU_Q: {
-                        const float z = p.e1[m * p.lde1 + n], hprev = p.e0[m * p.lde0 + n];
-                        y = (1.f - z) * hprev + z * tanhf(y);
-                    } break;
-                    case WOFT_EPI_CTX: y = (n < p.split) ? tanhf(y) : fmaxf(y, 0.f); break;
-                    default: break;
-                }
-                p.out[m * p.ldo + col] = y;
+        for (int j = 0; j < RA; ++j) {
+            const bf16x4 hi = __builtin_convertvector(ra[j], bf16x4);
+            *(bf16x4*)(As + (r0 + 32 * j) * LDB + 4 * v) = hi;
+            if (NP == 2) {
+                const f32x4 rem = ra[j] - __builtin_convertvector(hi, f32x4);
+                *(bf16x4*)(As + BM * LDB + (r0 + 32 * j) * LDB + 4 * v) = __builtin_convertvector(rem, bf16x4);
             }
         }
-        if (do_stats) {
-            ssum += __shfl_xor(ssum, 32);
-            ssq += __shfl_xor(ssq, 32);
-            if (hh == 0) {
-                const int64_t row = (int64_t)blockIdx.x * 2 + wm;
-                p.stat_sum[row * p.cout_pad + n] = ssum;
-                p.stat_sq[row * p.cout_pad + n] = ssq;
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+            for (int j = 0; j < RB; ++j) *(bf16x8*)(Bs + pl * BN * LDB + (rb0 + 64 * j) * LDB + 8 * vb) = rb[pl][j];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // lane (r32, hh) feeds k = s*16 + hh*8 + [0,8) of the step for both operands
+    const __bf16* a_frag = As + (wm * (BM / 2) + r32) * LDB + hh * 8;
+    const __bf16* b_frag = Bs + (wn * (BN / 2) + r32) * LDB + hh * 8;
+
+    load_tiles(0);
+    store_tiles();
+    __syncthreads();
+    for (int ks = 0; ks < nk; ++ks) {
+        if (ks + 1 < nk) load_tiles(ks + 1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 a[NP][TM], b[NP][TN];
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[pl][i] = *(const bf16x8*)(a_frag + pl * BM * LDB + i * 32 * LDB + s * 16);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[pl][j] = *(const bf16x8*)(b_frag + pl * BN * LDB + j * 32 * LDB + s * 16);
             }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if (NP == 2) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[NP - 1][i], b[0][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[NP - 1][j], acc[i][j], 0, 0, 0);
+                    }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], acc[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+        if (ks + 1 < nk) {
+            store_tiles();
+            __syncthreads();
         }
     }
+    woft::conv_epilogue<BM, BN>(p, acc, m0, n0, wm, wn, r32, hh, M);
+}
+
+// fp32 matrix -> hi / lo bf16 planes (used for the dynamic B operand of the correlation GEMM)
+__global__ void split_bf16_kernel(const float* __restrict__ x, int64_t n4, __bf16* __restrict__ hi,
+                                  __bf16* __restrict__ lo) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const f32x4 vv = *(const f32x4*)(x + i * 4);
+    const bf16x4 h = __builtin_convertvector(vv, bf16x4);
+    *(bf16x4*)(hi + i * 4) = h;
+    if (lo != nullptr) *(bf16x4*)(lo + i * 4) = __builtin_convertvector(vv - __builtin_convertvector(h, f32x4), bf16x4);
 }
 
 template <int BM, int BN>
 int launch_conv(const woft_conv_params& p, hipStream_t s) {
     const int64_t M = (int64_t)p.n_img * p.ho * p.wo;
     dim3 grid((unsigned)ceil_div64(M, BM), (unsigned)(p.cout_pad / BN));
-    hipLaunchKernelGGL((conv_mfma_f32_kernel<BM, BN>), grid, dim3(256), 0, s, p);
+    if (p.precision == 0)
+        hipLaunchKernelGGL((conv_mfma_f32_kernel<BM, BN>), grid, dim3(256), 0, s, p);
+    else if (p.precision == 1)
+        hipLaunchKernelGGL((conv_mfma_bf16_kernel<BM, BN, 3>), grid, dim3(256), 0, s, p);
+    else
+        hipLaunchKernelGGL((conv_mfma_bf16_kernel<BM, BN, 1>), grid, dim3(256), 0, s, p);
     return woft_launch_status();
 }
 
@@ -222,7 +258,11 @@ int launch_conv(const woft_conv_params& p, hipStream_t s) {
 extern "C" int woft_conv2d(const woft_conv_params* pp, void* stream) {
     if (pp == nullptr) return WOFT_EINVAL;
     const woft_conv_params& p = *pp;
-    if (p.in0 == nullptr || p.wgt == nullptr || p.out == nullptr) return WOFT_EINVAL;
+    if (p.in0 == nullptr || p.out == nullptr) return WOFT_EINVAL;
+    if (p.precision < 0 || p.precision > 2) return WOFT_EINVAL;
+    if (p.precision == 0 && p.wgt == nullptr) return WOFT_EINVAL;
+    if (p.precision >= 1 && p.wgt_hi == nullptr) return WOFT_EINVAL;
+    if (p.precision == 1 && p.wgt_lo == nullptr) return WOFT_EINVAL;
     if (p.cin_pad <= 0 || p.cin_pad % BK != 0) return WOFT_EINVAL;
     if (p.in1 != nullptr && (p.c_split % BK != 0 || p.c_split <= 0 || p.c_split >= p.cin_pad)) return WOFT_EINVAL;
     if (p.cs0 % 4 != 0 || (p.in1 != nullptr && p.cs1 % 4 != 0)) return WOFT_EINVAL;
@@ -244,4 +284,11 @@ extern "C" int woft_conv2d(const woft_conv_params* pp, void* stream) {
     if (p.tile_m == 128 && p.tile_n == 64) return launch_conv<128, 64>(p, s);
     if (p.tile_m == 64 && p.tile_n == 128) return launch_conv<64, 128>(p, s);
     return launch_conv<64, 64>(p, s);
+}
+
+extern "C" int woft_split_bf16(const float* x, int64_t n, void* hi, void* lo, void* stream) {
+    if (!x || !hi || n <= 0 || n % 4 != 0) return WOFT_EINVAL;
+    hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)ceil_div64(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       n / 4, (__bf16*)hi, (__bf16*)lo);
+    return woft_launch_status();
 }

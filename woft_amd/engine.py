@@ -63,7 +63,11 @@ class _Enc:
 
 
 class RaftEngine:
-    def __init__(self, state_dict, small=False, weighted=True):
+    def __init__(self, state_dict, small=False, weighted=True, precision="fp32"):
+        """precision: "fp32" (exact fp32 MFMA), "bf16x3" (split-bf16, fp32-emulating) or "bf16"."""
+        if precision not in ops.PRECISION:
+            raise ValueError(f"precision must be one of {sorted(ops.PRECISION)}")
+        self.precision = precision
         if small:
             raise NotImplementedError("the small model runs on woft_amd.engine_small")
         _lib.load()
@@ -115,6 +119,7 @@ class _Plan:
     def __init__(self, eng, hp, wp):
         assert hp % 8 == 0 and wp % 8 == 0
         self.eng, self.hp, self.wp = eng, hp, wp
+        self.prec = eng.precision
         self.source_tag = None
         self.lookup_events = None      # bench hook: list collecting (start, end) HIP events per lookup launch
         hf, wf = hp // 8, wp // 8
@@ -127,12 +132,15 @@ class _Plan:
         # feature maps: f1 (source) and f2 rows (target, zero padded to the GEMM N tile)
         self.f1 = new_act(1, hf, wf, 256, zero=True)
         self.dims, self.pitch, self.f2rows, self.f2act, self.vol = [], [], [], [], []
+        self.f2hi, self.f2lo = [], []
         h, w = hf, wf
         for _ in range(eng.levels):
             self.dims.append((h, w))
             self.pitch.append(_ru(w, 4))
             rows = z(_ru(h * w, 128), 256)
             self.f2rows.append(rows)
+            self.f2hi.append(torch.zeros_like(rows, dtype=torch.bfloat16))
+            self.f2lo.append(torch.zeros_like(rows, dtype=torch.bfloat16))
             self.f2act.append(Act(rows[:h * w], 1, h, w, 256))
             self.vol.append(z(P, h * _ru(w, 4)))
             h, w = h // 2, w // 2
@@ -165,7 +173,7 @@ class _Plan:
         self.lookup = ops.make_lookup_params(self.vol, self.dims, self.pitch, self.coords, self.corr.t, eng.radius)
         self.prog_iter_first = self._iter_program(first=True)
         self.prog_iter = self._iter_program(first=False)
-        cp = ops.conv_params
+        cp = self._cp
         self.prog_mask = [cp(self.hB, eng.mk1, self.mk, epi=EPI.EPI_RELU), cp(self.mk, eng.mk2, self.mask)]
         if eng.weighted:
             self.x8 = new_act(P, 9, 9, 5, cs=8, zero=True)
@@ -178,6 +186,10 @@ class _Plan:
             self.prog_wh = [cp(self.x8, eng.wh0, self.a1, epi=EPI.EPI_RELU),
                             cp(self.a1, eng.wh2, self.a2, epi=EPI.EPI_RELU),
                             cp(self.a2, eng.wh4, self.a1, epi=EPI.EPI_RELU)]
+
+    def _cp(self, *a, **kw):
+        kw.setdefault("precision", self.prec)
+        return ops.conv_params(*a, **kw)
 
     # ---- encoders ------------------------------------------------------------------------
     def _scratch(self, name, n, h, w, c):
@@ -194,7 +206,7 @@ class _Plan:
         def conv_norm(x, pc, name, mode, res=None):
             ho, wo = pc.out_hw(x.h, x.w)
             raw = self._scratch("raw_" + name, 1, ho, wo, pc.cout)
-            p = ops.conv_params(x, pc, raw, stats=self.stats)
+            p = self._cp(x, pc, raw, stats=self.stats)
             rows = 2 * math.ceil(p._m / p.tile_m)
             out = self._scratch("act_" + name, 1, ho, wo, pc.cout)
             prog.append(("conv", p))
@@ -209,7 +221,7 @@ class _Plan:
             if blk["stride"] != 1:
                 res = conv_norm(x, blk["down"], f"b{i}d", 0)
             x = conv_norm(y, blk["conv2"], f"b{i}b", 2, res=res)
-        prog.append(("conv", ops.conv_params(x, e.conv2, fmap_out)))
+        prog.append(("conv", self._cp(x, e.conv2, fmap_out)))
         return prog
 
     def _cnet_program(self, img):
@@ -220,7 +232,7 @@ class _Plan:
         def conv(x, pc, name, **kw):
             ho, wo = pc.out_hw(x.h, x.w)
             out = self._scratch("c_" + name, 1, ho, wo, pc.cout)
-            prog.append(("conv", ops.conv_params(x, pc, out, **kw)))
+            prog.append(("conv", self._cp(x, pc, out, **kw)))
             return out
 
         x = conv(img, e.conv1, "c1", epi=EPI.EPI_RELU)
@@ -228,8 +240,8 @@ class _Plan:
             y = conv(x, blk["conv1"], f"b{i}a", epi=EPI.EPI_RELU)
             res = x if blk["stride"] == 1 else conv(x, blk["down"], f"b{i}d")
             x = conv(y, blk["conv2"], f"b{i}b", epi=EPI.EPI_RELU_RES_RELU, e0=res)
-        prog.append(("conv", ops.conv_params(x, e.conv2_net, self.net0, epi=EPI.EPI_TANH)))
-        prog.append(("conv", ops.conv_params(x, e.conv2_inp, self.xbuf, co_off=0, epi=EPI.EPI_RELU)))
+        prog.append(("conv", self._cp(x, e.conv2_net, self.net0, epi=EPI.EPI_TANH)))
+        prog.append(("conv", self._cp(x, e.conv2_inp, self.xbuf, co_off=0, epi=EPI.EPI_RELU)))
         return prog
 
     def _volume_program(self):
@@ -238,13 +250,16 @@ class _Plan:
             if l > 0:
                 prog.append(("pool", (self.f2act[l - 1], self.f2act[l])))
             h, w = self.dims[l]
+            if self.prec != "fp32":
+                prog.append(("split", (self.f2rows[l], self.f2hi[l], self.f2lo[l] if self.prec == "bf16x3" else None)))
             prog.append(("conv", ops.corr_volume(self.f1, self.f2rows[l], h * w, self.vol[l], w, self.pitch[l],
-                                                 1.0 / math.sqrt(256.0))))
+                                                 1.0 / math.sqrt(256.0), precision=self.prec,
+                                                 f2_hi=self.f2hi[l], f2_lo=self.f2lo[l])))
         return prog
 
     # ---- one refinement iteration (update.py:127-136, weighted_raft.py:228-237) -----------
     def _iter_program(self, first):
-        e, cp = self.eng, ops.conv_params
+        e, cp = self.eng, self._cp
         h_in = self.net0 if first else self.hB
         return [
             ("lookup", self.lookup),
@@ -278,6 +293,8 @@ class _Plan:
                 ops.inorm_apply(raw, self.mean, self.rstd, out, mode, res=res)
             elif kind == "pool":
                 ops.avgpool2(a[0], a[1])
+            elif kind == "split":
+                ops.split_bf16(a[0], a[1], a[2])
             elif kind == "lookup":
                 self._lookup(a)
             elif kind == "coords":

@@ -4,6 +4,7 @@
 (the compatibility shim) re-exports it under the reference's import path.
 """
 import logging
+import os
 from timeit import default_timer as timer
 
 import numpy as np
@@ -48,11 +49,16 @@ class RAFTWrapper:
         state_dict = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in state_dict.items()}
         weighted = self.C.raft_type == "weighted"
         small = bool(cp.small)
+        # arithmetic of the convolutions / correlation GEMM: "fp32" (exact fp32 MFMA, the reference's
+        # precision class), "bf16x3" (split-bf16 operands, fp32 accumulation: fp32-emulating) or "bf16".
+        # `mixed_precision=True` (autocast in the reference, weighted_raft.py:204,215,233) selects "bf16".
+        self.precision = os.environ.get("WOFT_PRECISION") or self.C.precision or \
+            ("bf16" if cp.mixed_precision else "fp32")
         if small:
             from .engine_small import RaftEngineSmall
-            self.engine = RaftEngineSmall(state_dict, weighted=weighted)
+            self.engine = RaftEngineSmall(state_dict, weighted=weighted, precision=self.precision)
         else:
-            self.engine = RaftEngine(state_dict, weighted=weighted)
+            self.engine = RaftEngine(state_dict, weighted=weighted, precision=self.precision)
         self._pinned = None
         self._pinned_key = None
         self._out = {}

@@ -76,6 +76,15 @@ class PackedConv:
     flat_cs: int = 0
     kh: int = 0              # real kernel size (flat packing folds kw into the K chunk)
     kw: int = 0
+    wgt_hi: torch.Tensor = None   # bf16 split of wgt: hi = bf16(w), lo = bf16(w - hi)
+    wgt_lo: torch.Tensor = None
+
+    def __post_init__(self):
+        if self.wgt is not None and self.wgt_hi is None and self.wgt.dtype == torch.float32:
+            w = self.wgt.detach().cpu()
+            hi = w.to(torch.bfloat16)
+            self.wgt_hi = hi.to(self.wgt.device)
+            self.wgt_lo = (w - hi.float()).to(torch.bfloat16).to(self.wgt.device)
 
     def out_hw(self, h, w):
         kh, kw = (self.kh or self.taps_y), (self.kw or self.taps_x)
@@ -129,6 +138,9 @@ def fold_bn(weight, bias, bn_w, bn_b, mean, var, eps=1e-5):
     return w, b
 
 
+PRECISION = {"fp32": 0, "bf16x3": 1, "bf16": 2}
+
+
 def pick_tiles(m, cout_pad):
     tn = 128 if cout_pad % 128 == 0 else 64
     blocks128 = math.ceil(m / 128) * (cout_pad // tn)
@@ -140,7 +152,7 @@ def pick_tiles(m, cout_pad):
 # kernels
 # ------------------------------------------------------------------------------------------
 def conv_params(x, pc, out, co_off=0, epi=_lib.EPI_LINEAR, x2=None, c_split=0, e0=None, e1=None, out1=None,
-                split=0, alpha=1.0, stats=None, ho=None, wo=None, tiles=None, cout=None):
+                split=0, alpha=1.0, stats=None, ho=None, wo=None, tiles=None, cout=None, precision=0):
     """Build (and keep alive) a woft_conv_params for `out[:, co_off:co_off+cout] = epi(conv(x))`."""
     if ho is None or wo is None:
         ho, wo = pc.out_hw(x.h, x.w)
@@ -154,6 +166,7 @@ def conv_params(x, pc, out, co_off=0, epi=_lib.EPI_LINEAR, x2=None, c_split=0, e
     p.taps_y, p.taps_x, p.stride, p.pad_y, p.pad_x = pc.taps_y, pc.taps_x, pc.stride, pc.pad_y, pc.pad_x
     p.cin_pad, p.flat = pc.cin_pad, pc.flat
     p.wgt, p.bias, p.alpha = ptr(pc.wgt), ptr(pc.bias), alpha
+    p.wgt_hi, p.wgt_lo, p.precision = ptr(pc.wgt_hi), ptr(pc.wgt_lo), PRECISION.get(precision, precision)
     p.cout, p.cout_pad = (cout or pc.cout), pc.cout_pad
     p.out, p.ldo, p.co_off = ptr(out.t), out.cs, co_off
     p.out_w, p.out_pitch = 0, 0
@@ -209,10 +222,14 @@ def avgpool2(x, out):
     check(_lib.load().woft_avgpool2_nhwc(ptr(x.t), x.h, x.w, x.cs, ptr(out.t), stream_ptr()), "woft_avgpool2_nhwc")
 
 
-def corr_volume(f1, f2_rows, n_q, out, wq, pitch, alpha):
+def split_bf16(x, hi, lo=None):
+    check(_lib.load().woft_split_bf16(ptr(x), x.numel(), ptr(hi), ptr(lo), stream_ptr()), "woft_split_bf16")
+
+
+def corr_volume(f1, f2_rows, n_q, out, wq, pitch, alpha, precision=0, f2_hi=None, f2_lo=None):
     """out[p][ (q // wq) * pitch + q % wq ] = alpha * <f1[p], f2_rows[q]>, q < n_q.
-    f1: Act (P, C); f2_rows: tensor (rows_pad, C) zero padded to a multiple of 128 rows."""
-    pc = PackedConv(f2_rows, None, n_q, f2_rows.shape[0], f1.cs, 1, 1, 0, 0, 1, 0)
+    f1: Act (P, C); f2_rows: tensor (rows_pad, C) zero padded to a multiple of 128 rows;
+    f2_hi / f2_lo: its bf16 split (ops.split_bf16) for the bf16 precisions."""
     p = ConvParams()
     p.in0, p.cs0, p.in1, p.cs1, p.c_split = ptr(f1.t), f1.cs, None, 0, f1.cs
     p.n_img, p.h, p.w, p.ho, p.wo = 1, f1.h, f1.w, f1.h, f1.w
@@ -220,12 +237,13 @@ def corr_volume(f1, f2_rows, n_q, out, wq, pitch, alpha):
     p.pad_y = p.pad_x = 0
     p.cin_pad, p.flat = f1.cs, 0
     p.wgt, p.bias, p.alpha = ptr(f2_rows), None, alpha
+    p.wgt_hi, p.wgt_lo, p.precision = ptr(f2_hi), ptr(f2_lo), PRECISION.get(precision, precision)
     p.cout, p.cout_pad = n_q, f2_rows.shape[0]
     p.out, p.ldo, p.co_off = ptr(out), out.shape[1], 0
     p.out_w, p.out_pitch = (wq, pitch) if pitch != wq else (0, 0)
     p.epi = _lib.EPI_LINEAR
     p.tile_m, p.tile_n = (128, 128) if f2_rows.shape[0] % 128 == 0 else (128, 64)
-    p._keep = (f1, f2_rows, out)
+    p._keep = (f1, f2_rows, out, f2_hi, f2_lo)
     return p
 
 
