@@ -38,7 +38,8 @@ template <int BM, int BN>
 __global__ __launch_bounds__(256) void conv_mfma_f32_kernel(const woft_conv_params p) {
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int RA = BM / 32, RB = BN / 32;
-    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDS_LD];
+    constexpr int SMEM_FLOATS = ((BM + BN) * LDS_LD > 4 * woft::STAGE_FLOATS) ? (BM + BN) * LDS_LD : 4 * woft::STAGE_FLOATS;
+    __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
     float* As = smem;
     float* Bs = smem + BM * LDS_LD;
 
@@ -118,7 +119,8 @@ __global__ __launch_bounds__(256) void conv_mfma_f32_kernel(const woft_conv_para
             __syncthreads();
         }
     }
-    woft::conv_epilogue<BM, BN>(p, acc, m0, n0, wm, wn, r32, hh, M);
+    // the loop ends with a block barrier: operand tiles are dead, reuse the LDS for output staging
+    woft::conv_epilogue<BM, BN>(p, acc, smem + wave * woft::STAGE_FLOATS, m0, n0, wm, wn, lane, M);
 }
 
 // ---- split-bf16 kernel -------------------------------------------------------------------------
@@ -132,7 +134,8 @@ __global__ __launch_bounds__(256) void conv_mfma_bf16_kernel(const woft_conv_par
     constexpr int RA = BM / 32;            // float4 rows per thread (A, fp32 source)
     constexpr int RB = BN / 64;            // 16-B rows per thread and plane (B, pre-split bf16)
     constexpr int NP = (TERMS == 3) ? 2 : 1;
-    __shared__ __attribute__((aligned(16))) __bf16 smem[(BM + BN) * LDB * NP];
+    constexpr int SMEM_ELEMS = ((BM + BN) * LDB * NP > 8 * woft::STAGE_FLOATS) ? (BM + BN) * LDB * NP : 8 * woft::STAGE_FLOATS;
+    __shared__ __attribute__((aligned(16))) __bf16 smem[SMEM_ELEMS];
     __bf16* As = smem;                                 // [NP][BM][LDB]
     __bf16* Bs = smem + NP * BM * LDB;                 // [NP][BN][LDB]
 
@@ -226,7 +229,7 @@ __global__ __launch_bounds__(256) void conv_mfma_bf16_kernel(const woft_conv_par
             __syncthreads();
         }
     }
-    woft::conv_epilogue<BM, BN>(p, acc, m0, n0, wm, wn, r32, hh, M);
+    woft::conv_epilogue<BM, BN>(p, acc, (float*)smem + wave * woft::STAGE_FLOATS, m0, n0, wm, wn, lane, M);
 }
 
 // fp32 matrix -> hi / lo bf16 planes (used for the dynamic B operand of the correlation GEMM)
@@ -278,6 +281,9 @@ extern "C" int woft_conv2d(const woft_conv_params* pp, void* stream) {
         return WOFT_EINVAL;
     if (p.epi == WOFT_EPI_GRU_Q && p.e1 == nullptr) return WOFT_EINVAL;
     if (p.epi == WOFT_EPI_GRU_ZR && p.out1 == nullptr) return WOFT_EINVAL;
+    if (p.e0 != nullptr && p.lde0 % 4 != 0) return WOFT_EINVAL;
+    if (p.e1 != nullptr && p.lde1 % 4 != 0) return WOFT_EINVAL;
+    if (p.out1 != nullptr && (p.ldo1 % 4 != 0 || p.split % 4 != 0)) return WOFT_EINVAL;
     if ((p.stat_sum == nullptr) != (p.stat_sq == nullptr)) return WOFT_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     if (p.tile_m == 128 && p.tile_n == 128) return launch_conv<128, 128>(p, s);

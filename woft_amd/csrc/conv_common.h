@@ -65,63 +65,146 @@ __device__ __forceinline__ void a_load(const woft_conv_params& p, const ARows<RA
     }
 }
 
-// Fused epilogue on the 32x32 MFMA accumulators of one wave.
-// C/D layout: column = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+// Fused epilogue.  Each 32x32 accumulator tile (C/D layout: column = lane & 31,
+// row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) is transposed through a per-wave LDS staging
+// tile (32 x 36 floats) so that every lane then owns 4 consecutive output channels of one pixel:
+// bias / activation / GRU / residual operands and the result move as 16-byte accesses and one wave
+// instruction stores 8 rows x 128 B of full cache lines (4 store instructions per tile instead of 16
+// dword ones -- the epilogue is store-issue bound otherwise, e.g. 4.2 GB of the 1080p volume).
+constexpr int STAGE_LD = 36;
+constexpr int STAGE_FLOATS = 32 * STAGE_LD;     // per wave
+
+__device__ __forceinline__ float epi_scalar(const woft_conv_params& p, float y, int64_t m, int n, bool& skip_store) {
+    skip_store = false;
+    switch (p.epi) {
+        case WOFT_EPI_RELU: return fmaxf(y, 0.f);
+        case WOFT_EPI_SIGMOID: return sigmoidf_(y);
+        case WOFT_EPI_TANH: return tanhf(y);
+        case WOFT_EPI_RELU_RES_RELU: return fmaxf(p.e0[m * p.lde0 + n] + fmaxf(y, 0.f), 0.f);
+        case WOFT_EPI_GRU_ZR:
+            y = sigmoidf_(y);
+            if (n >= p.split) {
+                p.out1[m * p.ldo1 + (n - p.split)] = y * p.e0[m * p.lde0 + (n - p.split)];
+                skip_store = true;
+            }
+            return y;
+        case WOFT_EPI_GRU_Q: {
+            const float z = p.e1[m * p.lde1 + n], hprev = p.e0[m * p.lde0 + n];
+            return (1.f - z) * hprev + z * tanhf(y);
+        }
+        case WOFT_EPI_CTX: return (n < p.split) ? tanhf(y) : fmaxf(y, 0.f);
+        default: return y;
+    }
+}
+
 template <int BM, int BN>
-__device__ __forceinline__ void conv_epilogue(const woft_conv_params& p, f32x16 (&acc)[BM / 64][BN / 64], int64_t m0,
-                                              int n0, int wm, int wn, int r32, int hh, int64_t M) {
+__device__ __forceinline__ void conv_epilogue(const woft_conv_params& p, f32x16 (&acc)[BM / 64][BN / 64],
+                                              float* stage, int64_t m0, int n0, int wm, int wn, int lane, int64_t M) {
     constexpr int TM = BM / 64, TN = BN / 64;
+    const int r32 = lane & 31, hh = lane >> 5;
+    const int rr = lane >> 3, c4 = (lane & 7) * 4;
     const bool do_stats = p.stat_sum != nullptr;
+    // 16-byte stores need an aligned, un-remapped destination; otherwise fall back to dword stores
+    const bool vec_out = (p.out_pitch == 0) && (p.ldo % 4 == 0) && (p.co_off % 4 == 0);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * (BN / 2) + j * 32 + r32;
-        const bool nvalid = n < p.cout;
-        const float bias = (p.bias != nullptr) ? p.bias[n] : 0.f;
-        int64_t col = n;
-        if (p.out_pitch != 0) col = (int64_t)(n / p.out_w) * p.out_pitch + (n % p.out_w);
-        col += p.co_off;
-        float ssum = 0.f, ssq = 0.f;
+        const int n = n0 + wn * (BN / 2) + j * 32 + c4;       // first of this lane's 4 channels
+        f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias != nullptr) bias4 = *(const f32x4*)(p.bias + n);
+        const bool full = (n + 3) < p.cout;                    // all 4 channels valid
+        float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t m = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                const bool ok = nvalid && (m < M);
-                float y = p.alpha * acc[i][j][r] + bias;
-                if (do_stats && ok) { ssum += y; ssq += y * y; }
-                if (!ok) continue;
-                switch (p.epi) {
-                    case WOFT_EPI_LINEAR: break;
-                    case WOFT_EPI_RELU: y = fmaxf(y, 0.f); break;
-                    case WOFT_EPI_SIGMOID: y = sigmoidf_(y); break;
-                    case WOFT_EPI_TANH: y = tanhf(y); break;
-                    case WOFT_EPI_RELU_RES_RELU:
-                        y = fmaxf(p.e0[m * p.lde0 + n] + fmaxf(y, 0.f), 0.f);
-                        break;
-                    case WOFT_EPI_GRU_ZR:
-                        y = sigmoidf_(y);
-                        if (n >= p.split) {
-                            p.out1[m * p.ldo1 + (n - p.split)] = y * p.e0[m * p.lde0 + (n - p.split)];
-                            continue;
-                        }
-                        break;
-                    case WOFT_EPI_GRU_Q: {
-                        const float z = p.e1[m * p.lde1 + n], hprev = p.e0[m * p.lde0 + n];
-                        y = (1.f - z) * hprev + z * tanhf(y);
-                    } break;
-                    case WOFT_EPI_CTX: y = (n < p.split) ? tanhf(y) : fmaxf(y, 0.f); break;
-                    default: break;
+            for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * hh) * STAGE_LD + r32] = acc[i][j][r];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int row = rr + 8 * pass;
+                const int64_t m = m0 + wm * (BM / 2) + i * 32 + row;
+                const f32x4 v = *(const f32x4*)(stage + row * STAGE_LD + c4);
+                if (m >= M || n >= p.cout) continue;
+                f32x4 y;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = p.alpha * v[e] + bias4[e];
+                if (do_stats) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < p.cout) { ssum[e] += y[e]; ssq[e] += y[e] * y[e]; }
                 }
-                p.out[m * p.ldo + col] = y;
+                if (full && vec_out && p.epi != WOFT_EPI_CTX) {
+                    bool stored = false;
+                    switch (p.epi) {
+                        case WOFT_EPI_LINEAR: break;
+                        case WOFT_EPI_RELU:
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) y[e] = fmaxf(y[e], 0.f);
+                            break;
+                        case WOFT_EPI_SIGMOID:
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) y[e] = sigmoidf_(y[e]);
+                            break;
+                        case WOFT_EPI_TANH:
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) y[e] = tanhf(y[e]);
+                            break;
+                        case WOFT_EPI_RELU_RES_RELU: {
+                            const f32x4 res = *(const f32x4*)(p.e0 + m * p.lde0 + n);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) y[e] = fmaxf(res[e] + fmaxf(y[e], 0.f), 0.f);
+                        } break;
+                        case WOFT_EPI_GRU_ZR:
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) y[e] = sigmoidf_(y[e]);
+                            if (n >= p.split) {                 // split % 4 == 0 (validated): whole vector is r
+                                const f32x4 hp = *(const f32x4*)(p.e0 + m * p.lde0 + (n - p.split));
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) y[e] *= hp[e];
+                                *(f32x4*)(p.out1 + m * p.ldo1 + (n - p.split)) = y;
+                                stored = true;
+                            }
+                            break;
+                        case WOFT_EPI_GRU_Q: {
+                            const f32x4 z = *(const f32x4*)(p.e1 + m * p.lde1 + n);
+                            const f32x4 hp = *(const f32x4*)(p.e0 + m * p.lde0 + n);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) y[e] = (1.f - z[e]) * hp[e] + z[e] * tanhf(y[e]);
+                        } break;
+                        default: break;
+                    }
+                    if (!stored) *(f32x4*)(p.out + m * p.ldo + p.co_off + n) = y;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int ne = n + e;
+                        if (ne >= p.cout) continue;
+                        bool skip;
+                        const float ye = epi_scalar(p, y[e], m, ne, skip);
+                        if (skip) continue;
+                        int64_t col = ne;
+                        if (p.out_pitch != 0) col = (int64_t)(ne / p.out_w) * p.out_pitch + (ne % p.out_w);
+                        p.out[m * p.ldo + p.co_off + col] = ye;
+                    }
+                }
             }
+            __builtin_amdgcn_wave_barrier();
         }
         if (do_stats) {
-            ssum += __shfl_xor(ssum, 32);
-            ssq += __shfl_xor(ssq, 32);
-            if (hh == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int o = 8; o < 64; o <<= 1) {
+                    ssum[e] += __shfl_xor(ssum[e], o);
+                    ssq[e] += __shfl_xor(ssq[e], o);
+                }
+            }
+            if (rr == 0) {
                 const int64_t row = (int64_t)blockIdx.x * 2 + wm;
-                p.stat_sum[row * p.cout_pad + n] = ssum;
-                p.stat_sq[row * p.cout_pad + n] = ssq;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    p.stat_sum[row * p.cout_pad + n + e] = ssum[e];
+                    p.stat_sq[row * p.cout_pad + n + e] = ssq[e];
+                }
             }
         }
     }

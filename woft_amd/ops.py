@@ -6,6 +6,7 @@ flattened) -- `Act` carries the geometry.
 """
 import ctypes as C
 import math
+import os
 from dataclasses import dataclass
 
 import numpy as np
@@ -141,10 +142,15 @@ def fold_bn(weight, bias, bn_w, bn_b, mean, var, eps=1e-5):
 PRECISION = {"fp32": 0, "bf16x3": 1, "bf16": 2}
 
 
+TILE_MIN_BLOCKS = int(os.environ.get("WOFT_TILE_MIN_BLOCKS", "512"))
+
+
 def pick_tiles(m, cout_pad):
+    """Block tile: 128-wide in N when the padded cout allows; 128 rows in M when that still yields
+    at least TILE_MIN_BLOCKS workgroups (256 CUs), else 64."""
     tn = 128 if cout_pad % 128 == 0 else 64
     blocks128 = math.ceil(m / 128) * (cout_pad // tn)
-    tm = 128 if blocks128 >= 512 else 64
+    tm = 128 if blocks128 >= TILE_MIN_BLOCKS else 64
     return tm, tn
 
 
