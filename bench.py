@@ -83,8 +83,10 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--iters", type=int, default=12)
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3", "bf16"],
-                    help="conv / correlation-GEMM arithmetic: exact fp32 MFMA, split-bf16 (fp32-emulating), bf16")
+    ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16x3", "bf16"],
+                    help="conv / correlation-GEMM arithmetic: exact fp32 MFMA, split-bf16 (fp32-emulating, default), bf16")
+    ap.add_argument("--no-alt-precisions", action="store_true",
+                    help="skip the short extra runs at the other two precisions (reported under 'alt_precisions')")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-template-cache", action="store_true",
                     help="recompute the template's features every frame, as the reference does")
@@ -98,16 +100,21 @@ def main():
     assert H % 8 == 0 and W % 8 == 0
 
     sd = synth.make_state_dict(seed=7)
-    conf = load_config(ROOT / "pytracking" / "configs" / "WOFT.py")
-    conf.flow_config.model = sd
-    conf.flow_config.iters = args.iters
-    conf.flow_config.precision = args.precision
-    tracker = conf.tracker_class(conf)
     template, frames = make_sequence(H, W, rank, Wm + K)
     mask = synth.make_init_mask(H, W)
-    tracker.init(template, mask)
-    if args.no_template_cache:
-        tracker.flower.pin_source(None)
+
+    def make_tracker(precision):
+        conf = load_config(ROOT / "pytracking" / "configs" / "WOFT.py")
+        conf.flow_config.model = sd
+        conf.flow_config.iters = args.iters
+        conf.flow_config.precision = precision
+        trk = conf.tracker_class(conf)
+        trk.init(template, mask)
+        if args.no_template_cache:
+            trk.flower.pin_source(None)
+        return trk
+
+    tracker = make_tracker(args.precision)
     plan = tracker.flower.engine.plan(H, W)
 
     results = []
@@ -151,18 +158,49 @@ def main():
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": lk_avg, "launches_timed": len(lk_ms)},
     }
+    tc_gpu = {}
+    if world == 1:
+        _, dst, _ = tracker.flower.compute_flow(template, frames[0], mode="TC", do_sigmoid=True)
+        tc_gpu[args.precision] = dst.cpu()
+    if world == 1 and not args.no_alt_precisions:
+        # the other two arithmetic modes, same sequence, short runs (each its own engine + buffers)
+        alt = {}
+        del tracker, plan
+        torch.cuda.empty_cache()
+        for prec in ("fp32", "bf16x3", "bf16"):
+            if prec == args.precision:
+                continue
+            trk = make_tracker(prec)
+            for f in frames[:2]:
+                trk.track(f)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            n_alt = min(K, 8)
+            for f in frames[Wm:Wm + n_alt]:
+                trk.track(f)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            _, dst, _ = trk.flower.compute_flow(template, frames[0], mode="TC", do_sigmoid=True)
+            tc_gpu[prec] = dst.cpu()
+            alt[prec] = {"frames_per_s": n_alt / dt, "ms_per_step": 1000.0 * dt / n_alt, "steps": n_alt}
+            del trk
+            torch.cuda.empty_cache()
+        out["alt_precisions"] = alt
     if world == 1 and not args.no_cpu_baseline:
         torch.set_num_threads(usable_cores())
         f0 = frames[0].cpu().numpy()
         dt, Hr, tc = cpu_baseline(sd, template, mask, f0, args.iters)
-        # quality gate on the same frame: flow EPE of the HIP path against the CPU oracle
-        _, dst, _ = tracker.flower.compute_flow(template, frames[0], mode="TC", do_sigmoid=True)
-        d = (dst.cpu() - tc[1]).reshape(2, -1)
-        epe = torch.sqrt((d ** 2).sum(0))
+        # quality gate on the same frame: flow EPE of the HIP path(s) against the CPU oracle
+        epes = {}
+        for prec, dst in tc_gpu.items():
+            e = torch.sqrt(((dst - tc[1]).reshape(2, -1) ** 2).sum(0))
+            epes[prec] = {"mean_px": float(e.mean()), "max_px": float(e.max())}
+        epe = torch.sqrt(((tc_gpu[args.precision] - tc[1]).reshape(2, -1) ** 2).sum(0))
         out["cpu_baseline"] = {"value": 1.0 / dt, "unit": "frames/s", "cores": torch.get_num_threads(),
                                "kind": "port", "sample": f"1 tracked frame at {H}x{W}, {args.iters} iters "
                                f"(oracle/tracker_ref.py, torch-CPU fp32), {dt:.1f} s"}
         out["flow_epe_vs_cpu_oracle"] = {"mean_px": float(epe.mean()), "max_px": float(epe.max())}
+        out["flow_epe_vs_cpu_oracle_by_precision"] = epes
     print(json.dumps(out), flush=True)
 
 

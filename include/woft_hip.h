@@ -91,8 +91,8 @@ int woft_split_bf16(const float* x, int64_t n, void* hi, void* lo, void* stream)
 /* InstanceNorm (extractor.py:28-32,129-130; nn.InstanceNorm2d eps=1e-5, biased variance):
  * finalize per-channel statistics from the conv epilogue's partial sums ... */
 int woft_inorm_finalize(const float* stat_sum, const float* stat_sq, int32_t n_part, int32_t ld,
-                        int32_t channels, int64_t count, float eps,
-                        float* mean, float* rstd, void* stream);
+                        int32_t channels, int32_t channels_pad, int64_t count, float eps,
+                        float* mean, float* rstd, void* stream);   /* mean/rstd[channels..channels_pad) := 0 */
 /* ... and apply them.  mode 0: (x-mean)*rstd ; 1: relu(.) ; 2: relu(res + relu(.)) */
 int woft_inorm_apply(const float* x, const float* mean, const float* rstd, const float* res,
                      float* out, int64_t n_pix, int32_t channels, int32_t mode, void* stream);

@@ -92,18 +92,30 @@ def test_stages_against_oracle(golden_dir):
 
 
 @torch.no_grad()
-@pytest.mark.parametrize("name", ["flow_full_136x200_it12"])
-def test_operator_vs_golden(golden_dir, name):
+@pytest.mark.parametrize("name,small,raft_type", [
+    ("flow_full_136x200_it12", False, "weighted"),
+    ("flow_small_128x160_it4", True, "orig"),          # config-1 family: plain RAFT-small (raft.py:49-56)
+    ("flow_wsmall_128x160_it4", True, "weighted"),
+])
+def test_operator_vs_golden(golden_dir, name, small, raft_type):
     g = np.load(golden_dir / f"{name}.npz")
-    sd = synth.make_state_dict(seed=int(g["seed"]))
-    fc = _flow_config(sd, int(g["iters"]))
+    weighted = raft_type == "weighted"
+    sd = synth.make_state_dict(seed=int(g["seed"]), small=small, weighted=weighted)
+    fc = _flow_config(sd, int(g["iters"]), raft_type=raft_type, small=small)
     flower = fc.of_class(fc)
     flow, w = flower.compute_flow(g["img1"], g["img2"], mode="flow", do_sigmoid=False)
     torch.cuda.synchronize()
-    assert tuple(flow.shape) == (2, 136, 200) and tuple(w.shape) == (1, 136, 200)
+    H, W = g["img1"].shape[:2]
+    assert tuple(flow.shape) == (2, H, W)
     m, mx = _epe(flow, torch.from_numpy(g["flow_up"])[0])
     assert m < 1e-3 and mx < 1e-2, (m, mx)
-    assert float((torch.sigmoid(w.cpu()) - torch.sigmoid(torch.from_numpy(g["w_up"])[0])).abs().max()) < 1e-4
+    if weighted:
+        assert tuple(w.shape) == (1, H, W)
+        assert float((torch.sigmoid(w.cpu()) - torch.sigmoid(torch.from_numpy(g["w_up"])[0])).abs().max()) < 1e-4
+    else:
+        assert w is None
+        src, dst, ww = flower.compute_flow(g["img1"], g["img2"], mode="TC")
+        assert ww is None and tuple(dst.shape) == (2, H * W)
 
 
 @torch.no_grad()

@@ -42,7 +42,7 @@ _SIGS = {
     "woft_sizeof": (i32, [i32]),
     "woft_conv2d": (i32, [C.POINTER(ConvParams), vp]),
     "woft_split_bf16": (i32, [vp, i64, vp, vp, vp]),
-    "woft_inorm_finalize": (i32, [vp, vp, i32, i32, i32, i64, f32, vp, vp, vp]),
+    "woft_inorm_finalize": (i32, [vp, vp, i32, i32, i32, i32, i64, f32, vp, vp, vp]),
     "woft_inorm_apply": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, vp]),
     "woft_preprocess_bgr_u8": (i32, [vp, i32, i32, vp, i32, i32, i32, i32, vp]),
     "woft_avgpool2_nhwc": (i32, [vp, i32, i32, i32, vp, vp]),

@@ -22,8 +22,13 @@ __global__ void preprocess_kernel(const uint8_t* __restrict__ img, int h, int w,
 
 // ---- InstanceNorm statistics: reduce the conv epilogue's per-wave-row partial sums -----------
 __global__ void inorm_finalize_kernel(const float* __restrict__ s1, const float* __restrict__ s2, int n_part, int ld,
-                                      int64_t count, float eps, float* __restrict__ mean, float* __restrict__ rstd) {
+                                      int channels, int64_t count, float eps, float* __restrict__ mean,
+                                      float* __restrict__ rstd) {
     const int c = blockIdx.x;
+    if (c >= channels) {            // padding channels of the activation buffer: keep them exactly zero
+        if (threadIdx.x == 0) { mean[c] = 0.f; rstd[c] = 0.f; }
+        return;
+    }
     double a = 0.0, b = 0.0;
     for (int i = threadIdx.x; i < n_part; i += blockDim.x) {
         a += (double)s1[(int64_t)i * ld + c];
@@ -102,11 +107,12 @@ extern "C" int woft_preprocess_bgr_u8(const uint8_t* img, int32_t h, int32_t w, 
 }
 
 extern "C" int woft_inorm_finalize(const float* stat_sum, const float* stat_sq, int32_t n_part, int32_t ld,
-                                   int32_t channels, int64_t count, float eps, float* mean, float* rstd,
-                                   void* stream) {
+                                   int32_t channels, int32_t channels_pad, int64_t count, float eps, float* mean,
+                                   float* rstd, void* stream) {
     if (!stat_sum || !stat_sq || !mean || !rstd || n_part <= 0 || channels <= 0 || count <= 0) return WOFT_EINVAL;
-    hipLaunchKernelGGL(inorm_finalize_kernel, dim3(channels), dim3(256), 0, (hipStream_t)stream, stat_sum, stat_sq,
-                       n_part, ld, count, eps, mean, rstd);
+    if (channels_pad < channels) return WOFT_EINVAL;
+    hipLaunchKernelGGL(inorm_finalize_kernel, dim3(channels_pad), dim3(256), 0, (hipStream_t)stream, stat_sum, stat_sq,
+                       n_part, ld, channels, count, eps, mean, rstd);
     return woft_launch_status();
 }
 

@@ -1,4 +1,4 @@
-"""RAFT / WeightedRAFT inference engine on the HIP kernels (full model).
+"""RAFT / WeightedRAFT inference engine on the HIP kernels (full and small models).
 
 Host-side orchestration only: packs a reference-format state-dict once, plans every buffer and
 every kernel-argument struct once per input resolution, then a frame is a fixed sequence of C-ABI
@@ -6,8 +6,8 @@ calls on torch's current stream -- no allocation, no host synchronisation inside
 
 Reference being replaced (paths under /root/reference/pytracking/external/RAFT/raft_core/):
   WeightedRAFT.forward  weighted_raft.py:179-315      RAFT.forward  raft.py:169-262
-  BasicEncoder          extractor.py:118-192          CorrBlock     corr.py:11-69
-  BasicUpdateBlock      update.py:114-136             WeightHead    weighted_raft.py:318-384
+  BasicEncoder / SmallEncoder  extractor.py:118-267   CorrBlock     corr.py:11-69
+  BasicUpdateBlock / SmallUpdateBlock  update.py:99-136   WeightHead  weighted_raft.py:318-384
 
 Results-identical restructurings: BatchNorm(eval) folded into the cnet convs; the
 mask head evaluated only after the last iteration (test_mode consumes only that one,
@@ -30,10 +30,29 @@ def _ru(x, m):
     return (x + m - 1) // m * m
 
 
-class _Enc:
-    """Packed weights of one BasicEncoder (extractor.py:118-165)."""
+class _Spec:
+    """Architecture constants of the two model sizes (weighted_raft.py:34-72, raft.py:33-65)."""
 
-    def __init__(self, sd, p, norm):
+    def __init__(self, small):
+        self.small = small
+        if small:
+            self.fdim, self.hdim, self.cdim, self.radius = 128, 96, 64, 3
+            self.fnorm, self.cnorm = "instance", "none"
+        else:
+            self.fdim, self.hdim, self.cdim, self.radius = 256, 128, 128, 4
+            self.fnorm, self.cnorm = "instance", "batch"
+        self.levels = 4
+        self.nwin = 2 * self.radius + 1
+        self.corr_c = self.levels * self.nwin ** 2            # 324 / 196
+        self.corr_cs = _ru(self.corr_c, 32)                   # 352 / 224
+        self.xdim = _ru(self.cdim + (82 if small else 128), 32)   # GRU input buffer [inp | motion | flow]
+        self.flow_off = self.cdim + (80 if small else 126)    # channel of the flow inside that buffer
+
+
+class _Enc:
+    """Packed weights of one BasicEncoder / SmallEncoder (extractor.py:118-267)."""
+
+    def __init__(self, sd, p, norm, spec, out_split=None):
         self.norm = norm
 
         def get(name, stride=1, flat_cs=0, bn=None):
@@ -49,15 +68,19 @@ class _Enc:
             for bi in range(2):
                 q = f"{p}.layer{li}.{bi}"
                 s = stride if bi == 0 else 1
-                blk = dict(stride=s, conv1=get(q + ".conv1", s, bn=q + ".norm1"),
-                           conv2=get(q + ".conv2", 1, bn=q + ".norm2"))
+                if spec.small:      # BottleneckBlock, extractor.py:60-116: 1x1 -> 3x3(stride) -> 1x1
+                    convs = [get(q + ".conv1", 1, bn=q + ".norm1"), get(q + ".conv2", s, bn=q + ".norm2"),
+                             get(q + ".conv3", 1, bn=q + ".norm3")]
+                else:               # ResidualBlock, extractor.py:6-56: 3x3(stride) -> 3x3
+                    convs = [get(q + ".conv1", s, bn=q + ".norm1"), get(q + ".conv2", 1, bn=q + ".norm2")]
+                blk = dict(stride=s, convs=convs)
                 if s != 1:
                     blk["down"] = get(q + ".downsample.0", s, bn=q + ".downsample.1")
                 self.blocks.append(blk)
         w2, b2 = sd[p + ".conv2.weight"], sd[p + ".conv2.bias"]
-        if norm == "batch":            # cnet: split into the GRU state (tanh) and the context (relu)
-            self.conv2_net = ops.pack_conv(w2[:128], b2[:128])
-            self.conv2_inp = ops.pack_conv(w2[128:], b2[128:])
+        if out_split:               # cnet: GRU state (tanh) and context (relu), weighted_raft.py:217-219
+            self.conv2_net = ops.pack_conv(w2[:out_split], b2[:out_split])
+            self.conv2_inp = ops.pack_conv(w2[out_split:], b2[out_split:])
         else:
             self.conv2 = ops.pack_conv(w2, b2)
 
@@ -68,34 +91,37 @@ class RaftEngine:
         if precision not in ops.PRECISION:
             raise ValueError(f"precision must be one of {sorted(ops.PRECISION)}")
         self.precision = precision
-        if small:
-            raise NotImplementedError("the small model runs on woft_amd.engine_small")
         _lib.load()
         if not torch.cuda.is_available():
             raise _lib.WoftHipError("woft_amd needs a HIP device: there is no CPU fallback")
         sd = {k: v.detach().float().cpu() for k, v in state_dict.items()}
         self.weighted = weighted
-        self.radius, self.levels = 4, 4
-        self.fnet = _Enc(sd, "fnet", "instance")
-        self.cnet = _Enc(sd, "cnet", "batch")
+        self.spec = sp = _Spec(small)
+        self.small = small
+        self.radius, self.levels = sp.radius, sp.levels
+        self.fnet = _Enc(sd, "fnet", sp.fnorm, sp)
+        self.cnet = _Enc(sd, "cnet", sp.cnorm, sp, out_split=sp.hdim)
         u = "update_block."
         g = lambda n, **kw: ops.pack_conv(sd[u + n + ".weight"], sd[u + n + ".bias"], **kw)
+        cat = lambda a, b, s: torch.cat([sd[u + a + s], sd[u + b + s]], 0)
         self.convc1 = g("encoder.convc1")
-        self.convc2 = g("encoder.convc2")
         self.convf1 = g("encoder.convf1", flat_cs=4)
         self.convf2 = g("encoder.convf2")
         self.convm = g("encoder.conv")
-        cat = lambda a, b, s: torch.cat([sd[u + a + s], sd[u + b + s]], 0)
-        self.zr1 = ops.pack_conv(cat("gru.convz1", "gru.convr1", ".weight"), cat("gru.convz1", "gru.convr1", ".bias"),
-                                 padding=(0, 2))
-        self.q1 = g("gru.convq1", padding=(0, 2))
-        self.zr2 = ops.pack_conv(cat("gru.convz2", "gru.convr2", ".weight"), cat("gru.convz2", "gru.convr2", ".bias"),
-                                 padding=(2, 0))
-        self.q2 = g("gru.convq2", padding=(2, 0))
         self.fh1 = g("flow_head.conv1")
         self.fh2 = g("flow_head.conv2")
-        self.mk1 = g("mask.0")
-        self.mk2 = g("mask.2", scale=0.25)             # ".25 * self.mask(net)"  update.py:135
+        if small:
+            self.zr = [ops.pack_conv(cat("gru.convz", "gru.convr", ".weight"), cat("gru.convz", "gru.convr", ".bias"))]
+            self.q = [g("gru.convq")]
+        else:
+            self.convc2 = g("encoder.convc2")
+            self.zr = [ops.pack_conv(cat("gru.convz1", "gru.convr1", ".weight"),
+                                     cat("gru.convz1", "gru.convr1", ".bias"), padding=(0, 2)),
+                       ops.pack_conv(cat("gru.convz2", "gru.convr2", ".weight"),
+                                     cat("gru.convz2", "gru.convr2", ".bias"), padding=(2, 0))]
+            self.q = [g("gru.convq1", padding=(0, 2)), g("gru.convq2", padding=(2, 0))]
+            self.mk1 = g("mask.0")
+            self.mk2 = g("mask.2", scale=0.25)         # ".25 * self.mask(net)"  update.py:135
         if weighted:
             w = "weight_head.net."
             self.wh0 = ops.pack_conv(sd[w + "0.weight"], sd[w + "0.bias"], flat_cs=8)
@@ -105,7 +131,6 @@ class RaftEngine:
             self.wh6_b = float(sd[w + "6.bias"].item())
         self._plans = {}
 
-    # ------------------------------------------------------------------------------------
     def plan(self, hp, wp):
         key = (hp, wp)
         if key not in self._plans:
@@ -122,67 +147,75 @@ class _Plan:
         self.prec = eng.precision
         self.source_tag = None
         self.lookup_events = None      # bench hook: list collecting (start, end) HIP events per lookup launch
+        sp = eng.spec
         hf, wf = hp // 8, wp // 8
         self.hf, self.wf, self.P = hf, wf, hf * wf
         P = self.P
         dev = "cuda"
         z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+        cp = self._cp
 
         self.img = [new_act(1, hp, wp, 3, cs=4), new_act(1, hp, wp, 3, cs=4)]
         # feature maps: f1 (source) and f2 rows (target, zero padded to the GEMM N tile)
-        self.f1 = new_act(1, hf, wf, 256, zero=True)
+        self.f1 = new_act(1, hf, wf, sp.fdim, zero=True)
         self.dims, self.pitch, self.f2rows, self.f2act, self.vol = [], [], [], [], []
         self.f2hi, self.f2lo = [], []
         h, w = hf, wf
-        for _ in range(eng.levels):
+        for _ in range(sp.levels):
             self.dims.append((h, w))
             self.pitch.append(_ru(w, 4))
-            rows = z(_ru(h * w, 128), 256)
+            rows = z(_ru(h * w, 128), sp.fdim)
             self.f2rows.append(rows)
             self.f2hi.append(torch.zeros_like(rows, dtype=torch.bfloat16))
             self.f2lo.append(torch.zeros_like(rows, dtype=torch.bfloat16))
-            self.f2act.append(Act(rows[:h * w], 1, h, w, 256))
+            self.f2act.append(Act(rows[:h * w], 1, h, w, sp.fdim))
             self.vol.append(z(P, h * _ru(w, 4)))
             h, w = h // 2, w // 2
-        # context
-        self.net0 = new_act(1, hf, wf, 128, zero=True)
-        self.xbuf = new_act(1, hf, wf, 256, zero=True)        # [inp 128 | motion 126 | flow 2]
+        # context: GRU state and the GRU input buffer [inp | motion | flow | pad]
+        self.net0 = new_act(1, hf, wf, sp.hdim, zero=True)
+        self.xbuf = new_act(1, hf, wf, sp.xdim, zero=True)
         self._enc_scratch = {}
-        self.stats = (z(2 * math.ceil((hp // 2) * (wp // 2) / 64) * 128), z(2 * math.ceil((hp // 2) * (wp // 2) / 64) * 128))
+        n_stat = 2 * math.ceil((hp // 2) * (wp // 2) / 64) * 128
+        self.stats = (z(n_stat), z(n_stat))
         self.mean, self.rstd = z(256), z(256)
-        self.prog_f_src = self._fnet_program(self.img[0], self.f1)
-        self.prog_f_dst = self._fnet_program(self.img[1], self.f2act[0])
-        self.prog_c_src = self._cnet_program(self.img[0])
+        self.prog_f_src = self._encoder_program(eng.fnet, self.img[0], [(eng.fnet.conv2, self.f1, 0, EPI.EPI_LINEAR)])
+        self.prog_f_dst = self._encoder_program(eng.fnet, self.img[1],
+                                                [(eng.fnet.conv2, self.f2act[0], 0, EPI.EPI_LINEAR)])
+        self.prog_c_src = self._encoder_program(eng.cnet, self.img[0],
+                                                [(eng.cnet.conv2_net, self.net0, 0, EPI.EPI_TANH),
+                                                 (eng.cnet.conv2_inp, self.xbuf, 0, EPI.EPI_RELU)])
         self.prog_volume = self._volume_program()
 
         # update block
         self.coords = z(P, 2)
-        self.corr = new_act(1, hf, wf, 324, cs=352, zero=True)
-        self.c1 = new_act(1, hf, wf, 256, zero=True)
-        self.cf = new_act(1, hf, wf, 256, zero=True)
-        self.fl1 = new_act(1, hf, wf, 128, zero=True)
+        self.corr = new_act(1, hf, wf, sp.corr_c, cs=sp.corr_cs, zero=True)
+        self.c1 = new_act(1, hf, wf, 96 if sp.small else 256, zero=True)
+        self.cf = new_act(1, hf, wf, 128 if sp.small else 256, zero=True)     # [cor | flo]
+        self.fl1 = new_act(1, hf, wf, 64 if sp.small else 128, zero=True)
         self.flow4 = new_act(1, hf, wf, 2, cs=4, zero=True)
-        self.zbuf = new_act(1, hf, wf, 128, zero=True)
-        self.rh = new_act(1, hf, wf, 128, zero=True)
-        self.hA = new_act(1, hf, wf, 128, zero=True)
-        self.hB = new_act(1, hf, wf, 128, zero=True)
-        self.fh = new_act(1, hf, wf, 256, zero=True)
+        self.zbuf = new_act(1, hf, wf, sp.hdim, zero=True)
+        self.rh = new_act(1, hf, wf, sp.hdim, zero=True)
+        self.hA = new_act(1, hf, wf, sp.hdim, zero=True)
+        self.hB = new_act(1, hf, wf, sp.hdim, zero=True)
+        self.fh = new_act(1, hf, wf, 128 if sp.small else 256, zero=True)
         self.delta = new_act(1, hf, wf, 2, cs=4, zero=True)
-        self.mk = new_act(1, hf, wf, 256, zero=True)
-        self.mask = new_act(1, hf, wf, 576, zero=True)
-        self.lookup = ops.make_lookup_params(self.vol, self.dims, self.pitch, self.coords, self.corr.t, eng.radius)
+        self.lookup = ops.make_lookup_params(self.vol, self.dims, self.pitch, self.coords, self.corr.t, sp.radius)
         self.prog_iter_first = self._iter_program(first=True)
         self.prog_iter = self._iter_program(first=False)
-        cp = self._cp
-        self.prog_mask = [cp(self.hB, eng.mk1, self.mk, epi=EPI.EPI_RELU), cp(self.mk, eng.mk2, self.mask)]
+        self.prog_mask = []
+        if not sp.small:
+            self.mk = new_act(1, hf, wf, 256, zero=True)
+            self.mask = new_act(1, hf, wf, 576, zero=True)
+            self.prog_mask = [cp(self.hB, eng.mk1, self.mk, epi=EPI.EPI_RELU), cp(self.mk, eng.mk2, self.mask)]
         if eng.weighted:
-            self.x8 = new_act(P, 9, 9, 5, cs=8, zero=True)
-            self.a1 = new_act(P, 9, 9, 128)
-            self.a2 = new_act(P, 9, 9, 128)
+            n = sp.nwin
+            self.x8 = new_act(P, n, n, 5, cs=8, zero=True)
+            self.a1 = new_act(P, n, n, 128)
+            self.a2 = new_act(P, n, n, 128)
             self.wmean = z(P)
             self.wlow = z(P)
-            self.cs_ws = torch.zeros(256, 256, dtype=torch.float64, device=dev)
-            self.cs_tot = torch.zeros(256, dtype=torch.float64, device=dev)
+            self.cs_ws = torch.zeros(256, sp.fdim, dtype=torch.float64, device=dev)
+            self.cs_tot = torch.zeros(sp.fdim, dtype=torch.float64, device=dev)
             self.prog_wh = [cp(self.x8, eng.wh0, self.a1, epi=EPI.EPI_RELU),
                             cp(self.a1, eng.wh2, self.a2, epi=EPI.EPI_RELU),
                             cp(self.a2, eng.wh4, self.a1, epi=EPI.EPI_RELU)]
@@ -193,92 +226,92 @@ class _Plan:
 
     # ---- encoders ------------------------------------------------------------------------
     def _scratch(self, name, n, h, w, c):
-        key = (name, h, w, c)
+        cs = _ru(c, 32)                       # every encoder activation is a conv input: whole K chunks
+        key = (name, h, w, cs)
         if key not in self._enc_scratch:
-            self._enc_scratch[key] = new_act(n, h, w, c)
+            self._enc_scratch[key] = new_act(n, h, w, c, cs=cs, zero=True)
         return self._enc_scratch[key]
 
-    def _fnet_program(self, img, fmap_out):
-        """InstanceNorm encoder: conv (+ partial statistics) -> finalize -> normalise/relu(/residual)."""
-        e = self.eng.fnet
+    def _encoder_program(self, e, img, outputs):
+        """extractor.py:168-192 / 244-267.  InstanceNorm: conv (+ partial statistics) -> finalize ->
+        normalise/relu(/residual) kernels.  BatchNorm(eval, folded) / no norm: everything in conv epilogues."""
         prog = []
+        inorm = e.norm == "instance"
+        tag = "i" if inorm else "c"
 
-        def conv_norm(x, pc, name, mode, res=None):
+        def layer(x, pc, name, relu, res=None):
+            """-> relu?(norm(conv(x)))  or, with res,  relu(res + relu(norm(conv(x))))"""
             ho, wo = pc.out_hw(x.h, x.w)
-            raw = self._scratch("raw_" + name, 1, ho, wo, pc.cout)
+            out = self._scratch(f"{tag}_{name}", 1, ho, wo, pc.cout)
+            if not inorm:
+                epi = EPI.EPI_RELU_RES_RELU if res is not None else (EPI.EPI_RELU if relu else EPI.EPI_LINEAR)
+                prog.append(("conv", self._cp(x, pc, out, epi=epi, e0=res)))
+                return out
+            raw = self._scratch(f"{tag}_raw_{name}", 1, ho, wo, pc.cout)
             p = self._cp(x, pc, raw, stats=self.stats)
             rows = 2 * math.ceil(p._m / p.tile_m)
-            out = self._scratch("act_" + name, 1, ho, wo, pc.cout)
             prog.append(("conv", p))
-            prog.append(("fin", (rows, pc.cout_pad, pc.cout, p._m)))
-            prog.append(("apply", (raw, out, mode, res)))
+            prog.append(("fin", (rows, pc.cout_pad, pc.cout, raw.cs, p._m)))
+            prog.append(("apply", (raw, out, 2 if res is not None else (1 if relu else 0), res)))
             return out
 
-        x = conv_norm(img, e.conv1, "c1", 1)
+        x = layer(img, e.conv1, "c1", True)
         for i, blk in enumerate(e.blocks):
-            y = conv_norm(x, blk["conv1"], f"b{i}a", 1)
-            res = x
-            if blk["stride"] != 1:
-                res = conv_norm(x, blk["down"], f"b{i}d", 0)
-            x = conv_norm(y, blk["conv2"], f"b{i}b", 2, res=res)
-        prog.append(("conv", self._cp(x, e.conv2, fmap_out)))
-        return prog
-
-    def _cnet_program(self, img):
-        """BatchNorm(eval)-folded encoder: every norm/relu/residual lives in a conv epilogue."""
-        e = self.eng.cnet
-        prog = []
-
-        def conv(x, pc, name, **kw):
-            ho, wo = pc.out_hw(x.h, x.w)
-            out = self._scratch("c_" + name, 1, ho, wo, pc.cout)
-            prog.append(("conv", self._cp(x, pc, out, **kw)))
-            return out
-
-        x = conv(img, e.conv1, "c1", epi=EPI.EPI_RELU)
-        for i, blk in enumerate(e.blocks):
-            y = conv(x, blk["conv1"], f"b{i}a", epi=EPI.EPI_RELU)
-            res = x if blk["stride"] == 1 else conv(x, blk["down"], f"b{i}d")
-            x = conv(y, blk["conv2"], f"b{i}b", epi=EPI.EPI_RELU_RES_RELU, e0=res)
-        prog.append(("conv", self._cp(x, e.conv2_net, self.net0, epi=EPI.EPI_TANH)))
-        prog.append(("conv", self._cp(x, e.conv2_inp, self.xbuf, co_off=0, epi=EPI.EPI_RELU)))
+            y = x
+            for k, pc in enumerate(blk["convs"][:-1]):
+                y = layer(y, pc, f"b{i}_{k}", True)
+            res = x if blk["stride"] == 1 else layer(x, blk["down"], f"b{i}_d", False)
+            x = layer(y, blk["convs"][-1], f"b{i}_o", True, res=res)
+        for pc, out, co_off, epi in outputs:
+            prog.append(("conv", self._cp(x, pc, out, co_off=co_off, epi=epi)))
         return prog
 
     def _volume_program(self):
+        sp = self.eng.spec
         prog = []
-        for l in range(self.eng.levels):
+        for l in range(sp.levels):
             if l > 0:
                 prog.append(("pool", (self.f2act[l - 1], self.f2act[l])))
             h, w = self.dims[l]
             if self.prec != "fp32":
                 prog.append(("split", (self.f2rows[l], self.f2hi[l], self.f2lo[l] if self.prec == "bf16x3" else None)))
             prog.append(("conv", ops.corr_volume(self.f1, self.f2rows[l], h * w, self.vol[l], w, self.pitch[l],
-                                                 1.0 / math.sqrt(256.0), precision=self.prec,
+                                                 1.0 / math.sqrt(float(sp.fdim)), precision=self.prec,
                                                  f2_hi=self.f2hi[l], f2_lo=self.f2lo[l])))
         return prog
 
-    # ---- one refinement iteration (update.py:127-136, weighted_raft.py:228-237) -----------
+    # ---- one refinement iteration (update.py:106-112,127-136; weighted_raft.py:228-237) ----
     def _iter_program(self, first):
-        e, cp = self.eng, self._cp
+        e, cp, sp = self.eng, self._cp, self.eng.spec
+        hd = sp.hdim
         h_in = self.net0 if first else self.hB
-        return [
-            ("lookup", self.lookup),
-            ("conv", cp(self.corr, e.convc1, self.c1, epi=EPI.EPI_RELU)),
-            ("conv", cp(self.c1, e.convc2, self.cf, co_off=0, epi=EPI.EPI_RELU)),
-            ("conv", cp(self.flow4, e.convf1, self.fl1, epi=EPI.EPI_RELU)),
-            ("conv", cp(self.fl1, e.convf2, self.cf, co_off=192, epi=EPI.EPI_RELU)),
-            ("conv", cp(self.cf, e.convm, self.xbuf, co_off=128, epi=EPI.EPI_RELU)),
-            ("conv", cp(h_in, e.zr1, self.zbuf, x2=self.xbuf, c_split=128, epi=EPI.EPI_GRU_ZR, split=128, e0=h_in,
-                        out1=self.rh)),
-            ("conv", cp(self.rh, e.q1, self.hA, x2=self.xbuf, c_split=128, epi=EPI.EPI_GRU_Q, e0=h_in, e1=self.zbuf)),
-            ("conv", cp(self.hA, e.zr2, self.zbuf, x2=self.xbuf, c_split=128, epi=EPI.EPI_GRU_ZR, split=128,
-                        e0=self.hA, out1=self.rh)),
-            ("conv", cp(self.rh, e.q2, self.hB, x2=self.xbuf, c_split=128, epi=EPI.EPI_GRU_Q, e0=self.hA,
-                        e1=self.zbuf)),
-            ("conv", cp(self.hB, e.fh1, self.fh, epi=EPI.EPI_RELU)),
-            ("conv", cp(self.fh, e.fh2, self.delta)),
-            ("coords", None),
-        ]
+        prog = [("lookup", self.lookup)]
+        if sp.small:            # SmallMotionEncoder update.py:71-77: cor(96) | flo(32) -> 80, cat flow
+            prog += [("conv", cp(self.corr, e.convc1, self.cf, co_off=0, epi=EPI.EPI_RELU)),
+                     ("conv", cp(self.flow4, e.convf1, self.fl1, epi=EPI.EPI_RELU)),
+                     ("conv", cp(self.fl1, e.convf2, self.cf, co_off=96, epi=EPI.EPI_RELU)),
+                     ("conv", cp(self.cf, e.convm, self.xbuf, co_off=sp.cdim, epi=EPI.EPI_RELU))]
+        else:                   # BasicMotionEncoder update.py:89-97: cor(192) | flo(64) -> 126, cat flow
+            prog += [("conv", cp(self.corr, e.convc1, self.c1, epi=EPI.EPI_RELU)),
+                     ("conv", cp(self.c1, e.convc2, self.cf, co_off=0, epi=EPI.EPI_RELU)),
+                     ("conv", cp(self.flow4, e.convf1, self.fl1, epi=EPI.EPI_RELU)),
+                     ("conv", cp(self.fl1, e.convf2, self.cf, co_off=192, epi=EPI.EPI_RELU)),
+                     ("conv", cp(self.cf, e.convm, self.xbuf, co_off=sp.cdim, epi=EPI.EPI_RELU))]
+        # GRU half steps: z|r conv (sigmoid, r*h fused), q conv (tanh + state blend fused)
+        states = [h_in, self.hA, self.hB] if len(e.zr) == 2 else [h_in, self.hB]
+        if len(e.zr) == 1 and not first:
+            states = [self.hB, self.hA]          # single-step GRU: ping-pong hB -> hA, copied back below
+        for k, (zr, q) in enumerate(zip(e.zr, e.q)):
+            hi, ho = states[k], states[k + 1]
+            prog += [("conv", cp(hi, zr, self.zbuf, x2=self.xbuf, c_split=hd, epi=EPI.EPI_GRU_ZR, split=hd, e0=hi,
+                                 out1=self.rh)),
+                     ("conv", cp(self.rh, q, ho, x2=self.xbuf, c_split=hd, epi=EPI.EPI_GRU_Q, e0=hi, e1=self.zbuf))]
+        if len(e.zr) == 1 and not first:
+            prog.append(("copy", (self.hA.t, self.hB.t)))
+        prog += [("conv", cp(self.hB, e.fh1, self.fh, epi=EPI.EPI_RELU)),
+                 ("conv", cp(self.fh, e.fh2, self.delta)),
+                 ("coords", None)]
+        return prog
 
     # ---- execution ------------------------------------------------------------------------
     def run(self, prog):
@@ -286,8 +319,8 @@ class _Plan:
             if kind == "conv":
                 ops.run_conv(a)
             elif kind == "fin":
-                rows, ld, c, count = a
-                ops.inorm_finalize(self.stats, rows, ld, c, count, self.mean, self.rstd)
+                rows, ld, c, c_pad, count = a
+                ops.inorm_finalize(self.stats, rows, ld, c, count, self.mean, self.rstd, channels_pad=c_pad)
             elif kind == "apply":
                 raw, out, mode, res = a
                 ops.inorm_apply(raw, self.mean, self.rstd, out, mode, res=res)
@@ -297,9 +330,12 @@ class _Plan:
                 ops.split_bf16(a[0], a[1], a[2])
             elif kind == "lookup":
                 self._lookup(a)
+            elif kind == "copy":
+                a[1].copy_(a[0])
             elif kind == "coords":
+                off = self.eng.spec.flow_off
                 ops.coords_update(self.coords, self.delta.t, self.delta.cs, self.wf, self.flow4.t,
-                                  self.xbuf.t[:, 254:], self.xbuf.cs)
+                                  self.xbuf.t[:, off:], self.xbuf.cs)
             else:
                 raise ValueError(kind)
 
@@ -323,12 +359,13 @@ class _Plan:
 
     def flow(self, iters, crop, h, w, flow_up=None, dst=None, wout=None, do_sigmoid=False, trace=None):
         """Target features -> volume -> `iters` refinements -> full-resolution outputs."""
-        e = self.eng
+        e, sp = self.eng, self.eng.spec
         if iters < 1:
             raise ValueError("iters must be >= 1")
         self.run(self.prog_f_dst)
         self.run(self.prog_volume)
-        ops.coords_init(self.coords, self.hf, self.wf, self.flow4.t, self.xbuf.t[:, 254:], self.xbuf.cs)
+        off = sp.flow_off
+        ops.coords_init(self.coords, self.hf, self.wf, self.flow4.t, self.xbuf.t[:, off:], self.xbuf.cs)
         for it in range(iters):
             self.run(self.prog_iter_first if it == 0 else self.prog_iter)
             if trace is not None:
@@ -339,15 +376,21 @@ class _Plan:
         if e.weighted:
             self._lookup(self.lookup)                                # final lookup, weighted_raft.py:266
             lib = _lib.load()
-            _lib.check(lib.woft_colsum(_lib.ptr(self.f2act[0].t), self.P, 256, _lib.ptr(self.cs_ws), 256,
+            n = sp.nwin
+            _lib.check(lib.woft_colsum(_lib.ptr(self.f2act[0].t), self.P, sp.fdim, _lib.ptr(self.cs_ws), 256,
                                        _lib.ptr(self.cs_tot), _lib.stream_ptr()), "woft_colsum")
-            _lib.check(lib.woft_wh_pack(_lib.ptr(self.corr.t), self.corr.cs, _lib.ptr(self.f1.t), 256,
-                                        _lib.ptr(self.cs_tot), 1.0 / (16.0 * self.P), self.P, 9, _lib.ptr(self.wmean),
-                                        _lib.ptr(self.x8.t), _lib.stream_ptr()), "woft_wh_pack")
+            _lib.check(lib.woft_wh_pack(_lib.ptr(self.corr.t), self.corr.cs, _lib.ptr(self.f1.t), sp.fdim,
+                                        _lib.ptr(self.cs_tot), 1.0 / (math.sqrt(float(sp.fdim)) * self.P), self.P, n,
+                                        _lib.ptr(self.wmean), _lib.ptr(self.x8.t), _lib.stream_ptr()), "woft_wh_pack")
             for p in self.prog_wh:
                 ops.run_conv(p)
-            _lib.check(lib.woft_wh_reduce(_lib.ptr(self.a1.t), 128, 81, _lib.ptr(e.wh6_w), e.wh6_b, self.P,
+            _lib.check(lib.woft_wh_reduce(_lib.ptr(self.a1.t), 128, n * n, _lib.ptr(e.wh6_w), e.wh6_b, self.P,
                                           _lib.ptr(self.wlow), _lib.stream_ptr()), "woft_wh_reduce")
             wlow = self.wlow
-        ops.convex_upsample(self.coords, wlow, self.mask.t, self.hf, self.wf, crop, h, w, flow_up=flow_up, dst=dst,
-                            wout=wout if e.weighted else None, do_sigmoid=do_sigmoid)
+        wout = wout if e.weighted else None
+        if sp.small:                                                 # no mask head: bilinear x8 (utils.py:82-84)
+            ops.upflow8(self.coords, wlow, self.hf, self.wf, crop, h, w, flow_up=flow_up, dst=dst, wout=wout,
+                        do_sigmoid=do_sigmoid)
+        else:
+            ops.convex_upsample(self.coords, wlow, self.mask.t, self.hf, self.wf, crop, h, w, flow_up=flow_up,
+                                dst=dst, wout=wout, do_sigmoid=do_sigmoid)

@@ -54,11 +54,7 @@ class RAFTWrapper:
         # `mixed_precision=True` (autocast in the reference, weighted_raft.py:204,215,233) selects "bf16".
         self.precision = os.environ.get("WOFT_PRECISION") or self.C.precision or \
             ("bf16" if cp.mixed_precision else "fp32")
-        if small:
-            from .engine_small import RaftEngineSmall
-            self.engine = RaftEngineSmall(state_dict, weighted=weighted, precision=self.precision)
-        else:
-            self.engine = RaftEngine(state_dict, weighted=weighted, precision=self.precision)
+        self.engine = RaftEngine(state_dict, small=small, weighted=weighted, precision=self.precision)
         self._pinned = None
         self._pinned_key = None
         self._out = {}

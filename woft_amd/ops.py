@@ -207,15 +207,15 @@ def conv2d(x, pc, c_out_stride=None, **kw):
     return out
 
 
-def inorm_finalize(stats, n_part, ld, channels, count, mean, rstd, eps=1e-5):
-    check(_lib.load().woft_inorm_finalize(ptr(stats[0]), ptr(stats[1]), n_part, ld, channels, count, eps,
-                                          ptr(mean), ptr(rstd), stream_ptr()), "woft_inorm_finalize")
+def inorm_finalize(stats, n_part, ld, channels, count, mean, rstd, eps=1e-5, channels_pad=None):
+    check(_lib.load().woft_inorm_finalize(ptr(stats[0]), ptr(stats[1]), n_part, ld, channels, channels_pad or channels,
+                                          count, eps, ptr(mean), ptr(rstd), stream_ptr()), "woft_inorm_finalize")
 
 
 def inorm_apply(x, mean, rstd, out, mode, res=None):
-    assert x.cs == x.c and out.cs == x.c
+    assert out.cs == x.cs and (res is None or res.cs == x.cs)
     check(_lib.load().woft_inorm_apply(ptr(x.t), ptr(mean), ptr(rstd), ptr(res.t) if res is not None else None,
-                                       ptr(out.t), x.n_pix, x.c, mode, stream_ptr()), "woft_inorm_apply")
+                                       ptr(out.t), x.n_pix, x.cs, mode, stream_ptr()), "woft_inorm_apply")
 
 
 def preprocess(img_u8, out, hp, wp, pad_top, pad_left):
