@@ -108,12 +108,14 @@ int woft_preprocess_bgr_u8(const uint8_t* img, int32_t h, int32_t w, float* out,
 int woft_avgpool2_nhwc(const float* in, int32_t h, int32_t w, int32_t c, float* out, void* stream);
 
 /* Correlation lookup, corr.py:29-59 + utils/utils.py:59-73.
- * vol[l]: [P][hl][pitch_l] fp32 (level l of the pyramid), coords: [P][2] (x,y) at level 0.
+ * vol[l]: level l of the pyramid as [P][ht_l][wt_l][4][4] fp32: the target plane of each source pixel
+ * in 4x4 tiles (64 contiguous bytes), ht = ceil(H_l/4), wt = ceil(W_l/4), zeros beyond the map.  The
+ * producer is the correlation GEMM run against woft_tile_rows(fmap2_l).  coords: [P][2] (x,y) at level 0.
  * out: [P][ldo] with channel l*(2r+1)^2 + i*(2r+1) + j  <-  sample at (x/2^l + i - r, y/2^l + j - r). */
 typedef struct woft_lookup_params {
     const float* vol[4];
-    int32_t hl[4], wl[4], pitch[4];
-    int64_t plane[4];       /* floats per source pixel at level l */
+    int32_t ht[4], wt[4];   /* tiles per column / row at level l */
+    int64_t plane[4];       /* floats per source pixel at level l (>= ht*wt*16) */
     int32_t levels, radius;
     const float* coords;
     int64_t n_pix;
@@ -121,6 +123,9 @@ typedef struct woft_lookup_params {
     int32_t ldo;
 } woft_lookup_params;
 int woft_corr_lookup(const woft_lookup_params* p, void* stream);
+/* NHWC map [h][w][c] -> its rows in 4x4-tile order [(ceil(h/4)*ceil(w/4)*16)][c], zero rows outside the map:
+ * the B operand of the correlation GEMM that yields the tiled volume layout above. */
+int woft_tile_rows(const float* in, int32_t h, int32_t w, int32_t c, float* out, void* stream);
 
 /* coords1 += delta; flow = coords1 - coords0 (weighted_raft.py:232,237).
  * delta: [P][ld_delta] (first two channels); flow4: [P][4] = (fx, fy, 0, 0);

@@ -185,31 +185,29 @@ def test_preprocess_and_pool(ops):
 # correlation volume + lookup
 # ------------------------------------------------------------------------------------------
 def _build_pyramid_gpu(ops, f1, f2, precision="fp32"):
-    """f1, f2: (1, C, H, W) cpu tensors -> volumes [P][hl][pitch] on the GPU via the conv/GEMM kernel."""
+    """f1, f2: (1, C, H, W) cpu tensors -> tiled volumes [P][ht*wt*16] on the GPU via tile_rows + conv/GEMM."""
     _, c, h, w = f1.shape
     a1, a2 = ops.act_from_nchw(f1), ops.act_from_nchw(f2)
-    vols, dims, pitches = [], [], []
+    vols, dims = [], []
     cur = a2
     for l in range(4):
         hl, wl = cur.h, cur.w
-        pitch = ops._round_up(wl, 4)
-        rows = torch.zeros(ops._round_up(hl * wl, 128), c, device="cuda")
-        rows[:hl * wl] = cur.t
-        vol = torch.zeros(h * w, hl * pitch, device="cuda")
+        n = ops.tiled_dims(hl, wl)[2]
+        rows = torch.zeros(ops._round_up(n, 128), c, device="cuda")
+        ops.tile_rows(cur, rows)
+        vol = torch.zeros(h * w, n, device="cuda")
         hi, lo = torch.zeros_like(rows, dtype=torch.bfloat16), torch.zeros_like(rows, dtype=torch.bfloat16)
         if precision != "fp32":
             ops.split_bf16(rows, hi, lo)
-        ops.run_conv(ops.corr_volume(a1, rows, hl * wl, vol, wl, pitch, 1.0 / math.sqrt(c), precision=precision,
-                                     f2_hi=hi, f2_lo=lo))
+        ops.run_conv(ops.corr_volume(a1, rows, n, vol, 1.0 / math.sqrt(c), precision=precision, f2_hi=hi, f2_lo=lo))
         vols.append(vol)
         dims.append((hl, wl))
-        pitches.append(pitch)
         if l < 3:
             nxt = ops.new_act(1, hl // 2, wl // 2, c)
             ops.avgpool2(cur, nxt)
             cur = nxt
     torch.cuda.synchronize()
-    return vols, dims, pitches
+    return vols, dims
 
 
 @pytest.mark.parametrize("h,w,precision,tol", [(16, 20, "fp32", 3e-5), (17, 25, "fp32", 3e-5), (17, 25, "bf16x3", 2e-4),
@@ -217,11 +215,13 @@ def _build_pyramid_gpu(ops, f1, f2, precision="fp32"):
 def test_corr_volume_and_lookup(ops, h, w, precision, tol):
     f1, f2 = _rand(1, 256, h, w, seed=31), _rand(1, 256, h, w, seed=32)
     pyr = raft_ref.corr_pyramid(f1, f2)
-    vols, dims, pitches = _build_pyramid_gpu(ops, f1, f2, precision)
+    vols, dims = _build_pyramid_gpu(ops, f1, f2, precision)
     for l in range(4):
         hl, wl = dims[l]
-        got = vols[l].reshape(h * w, hl, pitches[l])[:, :, :wl]
-        _close(got, pyr[l][:, 0], tol, what=f"volume level {l}")
+        _close(ops.untile_planes(vols[l], hl, wl), pyr[l][:, 0], tol, what=f"volume level {l}")
+        # the padding entries of the tiled layout are exact zeros (the lookup relies on it)
+        full = ops.tile_planes(ops.untile_planes(vols[l], hl, wl))
+        assert torch.equal(full, vols[l][:, :full.shape[1]])
     if precision != "fp32":
         return
     coords = raft_ref.coords_grid(1, h, w) + _rand(1, 2, h, w, seed=33, scale=6.0)
@@ -230,36 +230,38 @@ def test_corr_volume_and_lookup(ops, h, w, precision, tol):
     ref = raft_ref.corr_lookup(pyr, coords, 4)
     cg = coords[0].permute(1, 2, 0).reshape(h * w, 2).contiguous().cuda()
     out = torch.zeros(h * w, 352, device="cuda")
-    ops.run_lookup(ops.make_lookup_params(vols, dims, pitches, cg, out, 4))
+    ops.run_lookup(ops.make_lookup_params(vols, dims, cg, out, 4))
     torch.cuda.synchronize()
     got = out[:, :324].reshape(1, h, w, 324).permute(0, 3, 1, 2)
     _close(got, ref, 1e-4, what="lookup")
     assert float(out[:, 324:].abs().max()) == 0.0
 
 
-def test_lookup_golden_handmade(ops, golden_dir):
+@pytest.mark.parametrize("radius", [4, 3])
+def test_lookup_golden_handmade(ops, golden_dir, radius):
     g = np.load(golden_dir / "lookup_handmade.npz")
     v = torch.from_numpy(g["vol0"])
     P = v.shape[0]
-    vols, dims, pitches = [], [], []
+    pyr, vols, dims = [], [], []
     for l in range(4):
-        hl, wl = v.shape[-2:]
-        pitch = ops._round_up(wl, 4)
-        vv = torch.zeros(P, hl, pitch)
-        vv[:, :, :wl] = v[:, 0]
-        vols.append(vv.reshape(P, hl * pitch).cuda())
-        dims.append((hl, wl))
-        pitches.append(pitch)
+        pyr.append(v)
+        vols.append(ops.tile_planes(v[:, 0]).cuda())
+        dims.append(tuple(v.shape[-2:]))
         v = F.avg_pool2d(v, 2, stride=2)
     coords = torch.from_numpy(g["coords"])                       # (2, h1, w1)
     h1, w1 = coords.shape[1:]
     cg = coords.permute(1, 2, 0).reshape(P, 2).contiguous().cuda()
-    out = torch.zeros(P, 324, device="cuda")
-    ops.run_lookup(ops.make_lookup_params(vols, dims, pitches, cg, out, 4))
+    nch = 4 * (2 * radius + 1) ** 2
+    out = torch.zeros(P, nch, device="cuda")
+    ops.run_lookup(ops.make_lookup_params(vols, dims, cg, out, radius))
     torch.cuda.synchronize()
-    got = out.reshape(1, h1, w1, 324).permute(0, 3, 1, 2)
-    _close(got, torch.from_numpy(g["out"]), 1e-5 * float(np.abs(g["out"]).max()), what="lookup golden")
-    assert abs(float(got[0, 1, 0, 0]) - 304.0) < 1e-3          # x-major window order pin
+    got = out.reshape(1, h1, w1, nch).permute(0, 3, 1, 2)
+    if radius == 4:         # golden vector from the imported reference
+        ref = torch.from_numpy(g["out"])
+        assert abs(float(got[0, 1, 0, 0]) - 304.0) < 1e-3      # x-major window order pin
+    else:                   # radius 3 (small model): the oracle's lookup on the same pyramid
+        ref = raft_ref.corr_lookup(pyr, coords[None], 3)
+    _close(got, ref, 1e-5 * float(ref.abs().max()), what="lookup golden")
 
 
 def test_coords_update(ops):

@@ -19,18 +19,16 @@ def main():
     a = ap.parse_args()
     hf, wf = a.hf, a.wf
     P = hf * wf
-    vols, dims, pitches = [], [], []
+    vols, dims = [], []
     h, w = hf, wf
     for l in range(4):
-        pitch = (w + 3) // 4 * 4
-        vols.append(torch.randn(P, h * pitch, device="cuda"))
+        vols.append(torch.randn(P, ops.tiled_dims(h, w)[2], device="cuda"))
         dims.append((h, w))
-        pitches.append(pitch)
         h, w = h // 2, w // 2
     idx = torch.arange(P, device="cuda")
     coords = torch.stack([idx % wf, idx // wf], 1).float() + (torch.rand(P, 2, device="cuda") * 2 - 1) * a.flow
     out = torch.zeros(P, 352, device="cuda")
-    lp = ops.make_lookup_params(vols, dims, pitches, coords.contiguous(), out, 4)
+    lp = ops.make_lookup_params(vols, dims, coords.contiguous(), out, 4)
     for _ in range(3):
         ops.run_lookup(lp)
     torch.cuda.synchronize()

@@ -32,7 +32,7 @@ class ConvParams(C.Structure):
 
 class LookupParams(C.Structure):
     _fields_ = [
-        ("vol", vp * 4), ("hl", i32 * 4), ("wl", i32 * 4), ("pitch", i32 * 4), ("plane", i64 * 4),
+        ("vol", vp * 4), ("ht", i32 * 4), ("wt", i32 * 4), ("plane", i64 * 4),
         ("levels", i32), ("radius", i32), ("coords", vp), ("n_pix", i64), ("out", vp), ("ldo", i32),
     ]
 
@@ -47,6 +47,7 @@ _SIGS = {
     "woft_preprocess_bgr_u8": (i32, [vp, i32, i32, vp, i32, i32, i32, i32, vp]),
     "woft_avgpool2_nhwc": (i32, [vp, i32, i32, i32, vp, vp]),
     "woft_corr_lookup": (i32, [C.POINTER(LookupParams), vp]),
+    "woft_tile_rows": (i32, [vp, i32, i32, i32, vp, vp]),
     "woft_coords_update": (i32, [vp, vp, i32, i32, i64, vp, vp, i32, vp]),
     "woft_coords_init": (i32, [vp, i32, i32, vp, vp, i32, vp]),
     "woft_colsum": (i32, [vp, i64, i32, vp, i32, vp, vp]),

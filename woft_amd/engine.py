@@ -158,18 +158,20 @@ class _Plan:
         self.img = [new_act(1, hp, wp, 3, cs=4), new_act(1, hp, wp, 3, cs=4)]
         # feature maps: f1 (source) and f2 rows (target, zero padded to the GEMM N tile)
         self.f1 = new_act(1, hf, wf, sp.fdim, zero=True)
-        self.dims, self.pitch, self.f2rows, self.f2act, self.vol = [], [], [], [], []
+        # target feature pyramid: linear NHWC maps (f2act) and their rows in 4x4-tile order (f2rows, the B
+        # operand of the correlation GEMM, zero padded to the N tile) -> volumes in the tiled layout
+        self.dims, self.f2rows, self.f2act, self.vol = [], [], [], []
         self.f2hi, self.f2lo = [], []
         h, w = hf, wf
         for _ in range(sp.levels):
             self.dims.append((h, w))
-            self.pitch.append(_ru(w, 4))
-            rows = z(_ru(h * w, 128), sp.fdim)
+            n = ops.tiled_dims(h, w)[2]
+            rows = z(_ru(n, 128), sp.fdim)
             self.f2rows.append(rows)
             self.f2hi.append(torch.zeros_like(rows, dtype=torch.bfloat16))
             self.f2lo.append(torch.zeros_like(rows, dtype=torch.bfloat16))
-            self.f2act.append(Act(rows[:h * w], 1, h, w, sp.fdim))
-            self.vol.append(z(P, h * _ru(w, 4)))
+            self.f2act.append(new_act(1, h, w, sp.fdim, zero=True))
+            self.vol.append(z(P, n))
             h, w = h // 2, w // 2
         # context: GRU state and the GRU input buffer [inp | motion | flow | pad]
         self.net0 = new_act(1, hf, wf, sp.hdim, zero=True)
@@ -199,7 +201,7 @@ class _Plan:
         self.hB = new_act(1, hf, wf, sp.hdim, zero=True)
         self.fh = new_act(1, hf, wf, 128 if sp.small else 256, zero=True)
         self.delta = new_act(1, hf, wf, 2, cs=4, zero=True)
-        self.lookup = ops.make_lookup_params(self.vol, self.dims, self.pitch, self.coords, self.corr.t, sp.radius)
+        self.lookup = ops.make_lookup_params(self.vol, self.dims, self.coords, self.corr.t, sp.radius)
         self.prog_iter_first = self._iter_program(first=True)
         self.prog_iter = self._iter_program(first=False)
         self.prog_mask = []
@@ -272,10 +274,10 @@ class _Plan:
         for l in range(sp.levels):
             if l > 0:
                 prog.append(("pool", (self.f2act[l - 1], self.f2act[l])))
-            h, w = self.dims[l]
+            prog.append(("tile", (self.f2act[l], self.f2rows[l])))
             if self.prec != "fp32":
                 prog.append(("split", (self.f2rows[l], self.f2hi[l], self.f2lo[l] if self.prec == "bf16x3" else None)))
-            prog.append(("conv", ops.corr_volume(self.f1, self.f2rows[l], h * w, self.vol[l], w, self.pitch[l],
+            prog.append(("conv", ops.corr_volume(self.f1, self.f2rows[l], self.vol[l].shape[1], self.vol[l],
                                                  1.0 / math.sqrt(float(sp.fdim)), precision=self.prec,
                                                  f2_hi=self.f2hi[l], f2_lo=self.f2lo[l])))
         return prog
@@ -328,6 +330,8 @@ class _Plan:
                 ops.avgpool2(a[0], a[1])
             elif kind == "split":
                 ops.split_bf16(a[0], a[1], a[2])
+            elif kind == "tile":
+                ops.tile_rows(a[0], a[1])
             elif kind == "lookup":
                 self._lookup(a)
             elif kind == "copy":

@@ -232,8 +232,8 @@ def split_bf16(x, hi, lo=None):
     check(_lib.load().woft_split_bf16(ptr(x), x.numel(), ptr(hi), ptr(lo), stream_ptr()), "woft_split_bf16")
 
 
-def corr_volume(f1, f2_rows, n_q, out, wq, pitch, alpha, precision=0, f2_hi=None, f2_lo=None):
-    """out[p][ (q // wq) * pitch + q % wq ] = alpha * <f1[p], f2_rows[q]>, q < n_q.
+def corr_volume(f1, f2_rows, n_q, out, alpha, precision=0, f2_hi=None, f2_lo=None):
+    """out[p][q] = alpha * <f1[p], f2_rows[q]>, q < n_q (rows of f2 already in the order the volume wants).
     f1: Act (P, C); f2_rows: tensor (rows_pad, C) zero padded to a multiple of 128 rows;
     f2_hi / f2_lo: its bf16 split (ops.split_bf16) for the bf16 precisions."""
     p = ConvParams()
@@ -246,20 +246,48 @@ def corr_volume(f1, f2_rows, n_q, out, wq, pitch, alpha, precision=0, f2_hi=None
     p.wgt_hi, p.wgt_lo, p.precision = ptr(f2_hi), ptr(f2_lo), PRECISION.get(precision, precision)
     p.cout, p.cout_pad = n_q, f2_rows.shape[0]
     p.out, p.ldo, p.co_off = ptr(out), out.shape[1], 0
-    p.out_w, p.out_pitch = (wq, pitch) if pitch != wq else (0, 0)
+    p.out_w, p.out_pitch = 0, 0
     p.epi = _lib.EPI_LINEAR
     p.tile_m, p.tile_n = (128, 128) if f2_rows.shape[0] % 128 == 0 else (128, 64)
     p._keep = (f1, f2_rows, out, f2_hi, f2_lo)
     return p
 
 
-def make_lookup_params(vols, dims, pitches, coords, out, radius):
+def tiled_dims(h, w):
+    """(tile rows, tile cols, floats per plane) of an h x w map in the 4x4-tiled volume layout."""
+    ht, wt = (h + 3) // 4, (w + 3) // 4
+    return ht, wt, ht * wt * 16
+
+
+def tile_rows(x, out):
+    """x: Act (1, h, w, c) -> out rows in 4x4-tile order (first ht*wt*16 rows of `out`)."""
+    check(_lib.load().woft_tile_rows(ptr(x.t), x.h, x.w, x.cs, ptr(out), stream_ptr()), "woft_tile_rows")
+
+
+def tile_planes(planes):
+    """(P, h, w) tensor of per-source-pixel planes -> (P, ht*wt*16) in the tiled layout (test helper)."""
+    P, h, w = planes.shape
+    ht, wt, n = tiled_dims(h, w)
+    pad = torch.zeros(P, ht * 4, wt * 4, dtype=planes.dtype, device=planes.device)
+    pad[:, :h, :w] = planes
+    return pad.reshape(P, ht, 4, wt, 4).permute(0, 1, 3, 2, 4).reshape(P, n).contiguous()
+
+
+def untile_planes(vol, h, w):
+    """inverse of tile_planes: (P, >= ht*wt*16) -> (P, h, w)."""
+    ht, wt, n = tiled_dims(h, w)
+    P = vol.shape[0]
+    return vol[:, :n].reshape(P, ht, wt, 4, 4).permute(0, 1, 3, 2, 4).reshape(P, ht * 4, wt * 4)[:, :h, :w]
+
+
+def make_lookup_params(vols, dims, coords, out, radius):
+    """vols[l]: (P, plane_l) tiled volumes; dims[l] = (H_l, W_l)."""
     p = LookupParams()
     for l, v in enumerate(vols):
         p.vol[l] = ptr(v)
-        p.hl[l], p.wl[l] = dims[l]
-        p.pitch[l] = pitches[l]
-        p.plane[l] = dims[l][0] * pitches[l]
+        p.ht[l], p.wt[l], n = tiled_dims(*dims[l])
+        assert v.shape[1] >= n
+        p.plane[l] = v.shape[1]
     p.levels, p.radius = len(vols), radius
     p.coords, p.n_pix, p.out, p.ldo = ptr(coords), coords.shape[0], ptr(out), out.shape[1]
     p._keep = (vols, coords, out)
