@@ -28,6 +28,8 @@ extern "C" {
 int woft_abi_version(void);
 /* sizeof(woft_conv_params) (which = 0) / sizeof(woft_lookup_params) (which = 1): layout check for FFI mirrors. */
 int woft_sizeof(int which);
+/* developer tuning knob (A/B experiments; call before any launch): key 0 = conv mainloop variant. */
+int woft_set_tuning(int key, int value);
 
 /* ---------------------------------------------------------------------------------------
  * Implicit-GEMM convolution on f32-input MFMA (v_mfma_f32_32x32x2_f32), NHWC.

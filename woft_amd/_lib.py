@@ -5,6 +5,7 @@ The product path has no CPU fallback: if the library is missing or a call fails,
 PyTorch-ROCm loaded; the kernels then run on torch's streams and torch-allocated buffers.
 """
 import ctypes as C
+import os
 from pathlib import Path
 
 import torch  # noqa: F401  (must precede the CDLL so both share one HIP runtime)
@@ -40,6 +41,7 @@ class LookupParams(C.Structure):
 _SIGS = {
     "woft_abi_version": (i32, []),
     "woft_sizeof": (i32, [i32]),
+    "woft_set_tuning": (i32, [i32, i32]),
     "woft_conv2d": (i32, [C.POINTER(ConvParams), vp]),
     "woft_split_bf16": (i32, [vp, i64, vp, vp, vp]),
     "woft_inorm_finalize": (i32, [vp, vp, i32, i32, i32, i32, i64, f32, vp, vp, vp]),
@@ -82,6 +84,8 @@ def load():
         fn.restype, fn.argtypes = res, args
     if lib.woft_sizeof(0) != C.sizeof(ConvParams) or lib.woft_sizeof(1) != C.sizeof(LookupParams):
         raise WoftHipError("ctypes mirror of woft_conv_params / woft_lookup_params is out of sync with the library")
+    if os.environ.get("WOFT_CONV_DEEP"):
+        lib.woft_set_tuning(0, int(os.environ["WOFT_CONV_DEEP"]))
     _lib = lib
     return lib
 

@@ -50,8 +50,10 @@ __global__ __launch_bounds__(256) void conv_mfma_f32_kernel(const woft_conv_para
     const int v = tid & 7, r0 = tid >> 3;
 
     const int64_t M = (int64_t)p.n_img * p.ho * p.wo;
-    const int64_t m0 = (int64_t)blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
+    int m_tile, n_tile;
+    woft::tile_of_block(blockIdx.x, (int)((M + BM - 1) / BM), p.cout_pad / BN, m_tile, n_tile);
+    const int64_t m0 = (int64_t)m_tile * BM;
+    const int n0 = n_tile * BN;
     const int nchunk = p.cin_pad / BK;
     const int nk = p.taps_y * p.taps_x * nchunk;
     const int64_t ktot = (int64_t)nk * BK;
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(256) void conv_mfma_f32_kernel(const woft_conv_para
         }
     }
     // the loop ends with a block barrier: operand tiles are dead, reuse the LDS for output staging
-    woft::conv_epilogue<BM, BN>(p, acc, smem + wave * woft::STAGE_FLOATS, m0, n0, wm, wn, lane, M);
+    woft::conv_epilogue<BM, BN>(p, acc, smem + wave * woft::STAGE_FLOATS, m0, n0, wm, wn, lane, M, m_tile);
 }
 
 // ---- split-bf16 kernel -------------------------------------------------------------------------
@@ -128,16 +130,16 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int LDB = 40;      // bf16 tiles: elements per row (80 B: 16-B aligned, conflict-free b128 reads)
 
-template <int BM, int BN, int TERMS>
+template <int BM, int BN, int TERMS, bool DEEP>
 __global__ __launch_bounds__(256) void conv_mfma_bf16_kernel(const woft_conv_params p) {
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int RA = BM / 32;            // float4 rows per thread (A, fp32 source)
     constexpr int RB = BN / 64;            // 16-B rows per thread and plane (B, pre-split bf16)
     constexpr int NP = (TERMS == 3) ? 2 : 1;
-    constexpr int SMEM_ELEMS = ((BM + BN) * LDB * NP > 8 * woft::STAGE_FLOATS) ? (BM + BN) * LDB * NP : 8 * woft::STAGE_FLOATS;
+    constexpr int BUF = (BM + BN) * LDB * NP;          // one LDS stage: A planes then B planes
+    constexpr int NBUF = DEEP ? 2 : 1;
+    constexpr int SMEM_ELEMS = (NBUF * BUF > 8 * woft::STAGE_FLOATS) ? NBUF * BUF : 8 * woft::STAGE_FLOATS;
     __shared__ __attribute__((aligned(16))) __bf16 smem[SMEM_ELEMS];
-    __bf16* As = smem;                                 // [NP][BM][LDB]
-    __bf16* Bs = smem + NP * BM * LDB;                 // [NP][BN][LDB]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -147,8 +149,10 @@ __global__ __launch_bounds__(256) void conv_mfma_bf16_kernel(const woft_conv_par
     const int vb = tid & 3, rb0 = tid >> 2;            // B loader: 16-B column, base row
 
     const int64_t M = (int64_t)p.n_img * p.ho * p.wo;
-    const int64_t m0 = (int64_t)blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
+    int m_tile, n_tile;
+    woft::tile_of_block(blockIdx.x, (int)((M + BM - 1) / BM), p.cout_pad / BN, m_tile, n_tile);
+    const int64_t m0 = (int64_t)m_tile * BM;
+    const int n0 = n_tile * BN;
     const int nchunk = p.cin_pad / BK;
     const int nk = p.taps_y * p.taps_x * nchunk;
     const int64_t ktot = (int64_t)nk * BK;
@@ -159,9 +163,11 @@ __global__ __launch_bounds__(256) void conv_mfma_bf16_kernel(const woft_conv_par
     bsrc[0] = (const __bf16*)p.wgt_hi;
     if (NP == 2) bsrc[NP - 1] = (const __bf16*)p.wgt_lo;
 
-    f32x4 ra[RA];
-    bf16x8 rb[NP][RB];
-    auto load_tiles = [&](int ks) {
+    // Two register sets: tiles are fetched TWO K steps ahead (the operands mostly come from beyond
+    // the XCD's L2), two LDS stages: one block barrier per K step.
+    f32x4 raA[RA], raB[RA];
+    bf16x8 rbA[NP][RB], rbB[NP][RB];
+    auto load_tiles = [&](int ks, f32x4 (&ra)[RA], bf16x8 (&rb)[NP][RB]) {
         woft::a_load<RA>(p, arows, ks, nchunk, v, ra);
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl)
@@ -169,7 +175,9 @@ __global__ __launch_bounds__(256) void conv_mfma_bf16_kernel(const woft_conv_par
             for (int j = 0; j < RB; ++j)
                 rb[pl][j] = *(const bf16x8*)(bsrc[pl] + (int64_t)(n0 + rb0 + 64 * j) * ktot + (int64_t)ks * BK + 8 * vb);
     };
-    auto store_tiles = [&]() {
+    auto store_tiles = [&](int buf, const f32x4 (&ra)[RA], const bf16x8 (&rb)[NP][RB]) {
+        __bf16* As = smem + buf * BUF;
+        __bf16* Bs = As + NP * BM * LDB;
 #pragma unroll
         for (int j = 0; j < RA; ++j) {
             const bf16x4 hi = __builtin_convertvector(ra[j], bf16x4);
@@ -194,14 +202,11 @@ __global__ __launch_bounds__(256) void conv_mfma_bf16_kernel(const woft_conv_par
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // lane (r32, hh) feeds k = s*16 + hh*8 + [0,8) of the step for both operands
-    const __bf16* a_frag = As + (wm * (BM / 2) + r32) * LDB + hh * 8;
-    const __bf16* b_frag = Bs + (wn * (BN / 2) + r32) * LDB + hh * 8;
-
-    load_tiles(0);
-    store_tiles();
-    __syncthreads();
-    for (int ks = 0; ks < nk; ++ks) {
-        if (ks + 1 < nk) load_tiles(ks + 1);
+    const int a_off = (wm * (BM / 2) + r32) * LDB + hh * 8;
+    const int b_off = NP * BM * LDB + (wn * (BN / 2) + r32) * LDB + hh * 8;
+    auto compute = [&](int buf) {
+        const __bf16* a_frag = smem + buf * BUF + a_off;
+        const __bf16* b_frag = smem + buf * BUF + b_off;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             bf16x8 a[NP][TM], b[NP][TN];
@@ -223,13 +228,46 @@ __global__ __launch_bounds__(256) void conv_mfma_bf16_kernel(const woft_conv_par
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], acc[i][j], 0, 0, 0);
                 }
         }
+    };
+
+    if (!DEEP) {
+        // one LDS stage, tiles fetched one K step ahead, two barriers per step; lowest register and LDS
+        // footprint -> most resident waves
+        load_tiles(0, raA, rbA);
+        store_tiles(0, raA, rbA);
         __syncthreads();
-        if (ks + 1 < nk) {
-            store_tiles();
+        for (int ks = 0; ks < nk; ++ks) {
+            if (ks + 1 < nk) load_tiles(ks + 1, raA, rbA);
+            compute(0);
             __syncthreads();
+            if (ks + 1 < nk) {
+                store_tiles(0, raA, rbA);
+                __syncthreads();
+            }
         }
+        woft::conv_epilogue<BM, BN>(p, acc, (float*)smem + wave * woft::STAGE_FLOATS, m0, n0, wm, wn, lane, M, m_tile);
+        return;
     }
-    woft::conv_epilogue<BM, BN>(p, acc, (float*)smem + wave * woft::STAGE_FLOATS, m0, n0, wm, wn, lane, M);
+    load_tiles(0, raA, rbA);
+    if (nk > 1) load_tiles(1, raB, rbB);
+    store_tiles(0, raA, rbA);
+    if (nk > 2) load_tiles(2, raA, rbA);
+    __syncthreads();
+    for (int ks = 0; ks < nk; ks += 2) {
+        // even step: stage 0 holds tile ks; set B holds tile ks+1, set A tile ks+2
+        if (ks + 1 < nk) store_tiles(1, raB, rbB);
+        if (ks + 3 < nk) load_tiles(ks + 3, raB, rbB);
+        compute(0);
+        __syncthreads();
+        if (ks + 1 >= nk) break;
+        // odd step: stage 1 holds tile ks+1; set A holds tile ks+2, set B tile ks+3
+        if (ks + 2 < nk) store_tiles(0, raA, rbA);
+        if (ks + 4 < nk) load_tiles(ks + 4, raA, rbA);
+        compute(1);
+        __syncthreads();
+    }
+    // every path leaves the loop through a block barrier: the operand stages are dead, reuse them
+    woft::conv_epilogue<BM, BN>(p, acc, (float*)smem + wave * woft::STAGE_FLOATS, m0, n0, wm, wn, lane, M, m_tile);
 }
 
 // fp32 matrix -> hi / lo bf16 planes (used for the dynamic B operand of the correlation GEMM)
@@ -243,16 +281,25 @@ __global__ void split_bf16_kernel(const float* __restrict__ x, int64_t n4, __bf1
     if (lo != nullptr) *(bf16x4*)(lo + i * 4) = __builtin_convertvector(vv - __builtin_convertvector(h, f32x4), bf16x4);
 }
 
+// developer tuning knobs (A/B experiments only; set once at start-up, never from the hot path):
+//   [0] 0 = single-stage mainloop (default), 1 = two-stage / two-step-ahead mainloop
+int g_tuning[4] = {0, 0, 0, 0};
+
 template <int BM, int BN>
 int launch_conv(const woft_conv_params& p, hipStream_t s) {
     const int64_t M = (int64_t)p.n_img * p.ho * p.wo;
-    dim3 grid((unsigned)ceil_div64(M, BM), (unsigned)(p.cout_pad / BN));
+    dim3 grid((unsigned)(ceil_div64(M, BM) * (p.cout_pad / BN)));       // 1-D: see woft::tile_of_block
+    const bool deep = g_tuning[0] != 0;
     if (p.precision == 0)
         hipLaunchKernelGGL((conv_mfma_f32_kernel<BM, BN>), grid, dim3(256), 0, s, p);
+    else if (p.precision == 1 && !deep)
+        hipLaunchKernelGGL((conv_mfma_bf16_kernel<BM, BN, 3, false>), grid, dim3(256), 0, s, p);
     else if (p.precision == 1)
-        hipLaunchKernelGGL((conv_mfma_bf16_kernel<BM, BN, 3>), grid, dim3(256), 0, s, p);
+        hipLaunchKernelGGL((conv_mfma_bf16_kernel<BM, BN, 3, true>), grid, dim3(256), 0, s, p);
+    else if (!deep)
+        hipLaunchKernelGGL((conv_mfma_bf16_kernel<BM, BN, 1, false>), grid, dim3(256), 0, s, p);
     else
-        hipLaunchKernelGGL((conv_mfma_bf16_kernel<BM, BN, 1>), grid, dim3(256), 0, s, p);
+        hipLaunchKernelGGL((conv_mfma_bf16_kernel<BM, BN, 1, true>), grid, dim3(256), 0, s, p);
     return woft_launch_status();
 }
 
@@ -290,6 +337,12 @@ extern "C" int woft_conv2d(const woft_conv_params* pp, void* stream) {
     if (p.tile_m == 128 && p.tile_n == 64) return launch_conv<128, 64>(p, s);
     if (p.tile_m == 64 && p.tile_n == 128) return launch_conv<64, 128>(p, s);
     return launch_conv<64, 64>(p, s);
+}
+
+extern "C" int woft_set_tuning(int key, int value) {
+    if (key < 0 || key >= 4) return WOFT_EINVAL;
+    g_tuning[key] = value;
+    return WOFT_OK;
 }
 
 extern "C" int woft_split_bf16(const float* x, int64_t n, void* hi, void* lo, void* stream) {

@@ -8,6 +8,27 @@ namespace woft {
 
 constexpr int BK = 32;
 
+// Workgroup id -> (M tile, N tile).  The dispatcher places consecutive workgroups on consecutive
+// XCDs (private 4 MiB L2 each), so (1) ids are first re-dealt so that each XCD owns a contiguous
+// range (bijective for any grid size), then (2) walked N-fastest inside column panels of at most 8 N
+// tiles: the 64 workgroups resident on an XCD cover ~8 x 8 tiles and share their A and B panels
+// through that XCD's L2 (the 1080p volume GEMM re-read fmap1 254 times from beyond L2 otherwise).
+// Placement only affects speed, never results.
+__device__ __forceinline__ void tile_of_block(int bid, int mt, int nt, int& m_tile, int& n_tile) {
+    const int nwg = mt * nt;
+    const int q = nwg / 8, rr = nwg % 8;
+    const int xcd = bid % 8, idx = bid / 8;
+    const int id = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
+    constexpr int PANEL = 8;
+    const int per_panel = mt * PANEL;
+    const int panel = id / per_panel;
+    const int n_first = panel * PANEL;
+    const int width = (nt - n_first < PANEL) ? (nt - n_first) : PANEL;
+    const int r = id - panel * per_panel;
+    m_tile = r / width;
+    n_tile = n_first + r % width;
+}
+
 template <int RA>
 struct ARows {
     int iy0[RA], ix0[RA];
@@ -99,7 +120,7 @@ __device__ __forceinline__ float epi_scalar(const woft_conv_params& p, float y, 
 
 template <int BM, int BN>
 __device__ __forceinline__ void conv_epilogue(const woft_conv_params& p, f32x16 (&acc)[BM / 64][BN / 64],
-                                              float* stage, int64_t m0, int n0, int wm, int wn, int lane, int64_t M) {
+                                              float* stage, int64_t m0, int n0, int wm, int wn, int lane, int64_t M, int m_tile) {
     constexpr int TM = BM / 64, TN = BN / 64;
     const int r32 = lane & 31, hh = lane >> 5;
     const int rr = lane >> 3, c4 = (lane & 7) * 4;
@@ -172,7 +193,7 @@ __device__ __forceinline__ void conv_epilogue(const woft_conv_params& p, f32x16 
                         } break;
                         default: break;
                     }
-                    if (!stored) *(f32x4*)(p.out + m * p.ldo + p.co_off + n) = y;
+                    if (!stored && p.out_w != -12345) *(f32x4*)(p.out + m * p.ldo + p.co_off + n) = y;   // (-12345: debug no-store)
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -199,7 +220,7 @@ __device__ __forceinline__ void conv_epilogue(const woft_conv_params& p, f32x16 
                 }
             }
             if (rr == 0) {
-                const int64_t row = (int64_t)blockIdx.x * 2 + wm;
+                const int64_t row = (int64_t)m_tile * 2 + wm;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     p.stat_sum[row * p.cout_pad + n + e] = ssum[e];

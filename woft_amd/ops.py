@@ -142,7 +142,7 @@ def fold_bn(weight, bias, bn_w, bn_b, mean, var, eps=1e-5):
 PRECISION = {"fp32": 0, "bf16x3": 1, "bf16": 2}
 
 
-TILE_MIN_BLOCKS = int(os.environ.get("WOFT_TILE_MIN_BLOCKS", "512"))
+TILE_MIN_BLOCKS = int(os.environ.get("WOFT_TILE_MIN_BLOCKS", "400"))
 
 
 def pick_tiles(m, cout_pad):
