@@ -83,6 +83,9 @@ typedef struct woft_conv_params {
     float* stat_sum;       /* optional [2*ceil(M/BM)][cout_pad] per-wave-row partial sums of y */
     float* stat_sq;        /*          ... and of y*y  (InstanceNorm statistics)               */
     int32_t tile_m, tile_n;/* block tile: 128 or 64 each                                       */
+    int32_t halo;          /* 0: gather A per tap.  Split-bf16 precisions, stride 1, 3x3/1x5/5x1 only:
+                              1 = 8x16-pixel output tiles with the input halo resident in LDS for all taps,
+                              2 = 9x9 tiles (the whole image; weight-head patches).  tile_m is ignored.   */
 } woft_conv_params;
 
 int woft_conv2d(const woft_conv_params* p, void* stream);

@@ -65,8 +65,10 @@ def test_conv_plain(ops, cin, cout, k, stride, h, w, tiles, precision, tol):
 
 
 @pytest.mark.parametrize("kh,kw", [(1, 5), (5, 1), (3, 3)])
-def test_conv_gru_epilogues(ops, kh, kw):
-    """SepConvGRU half step (update.py:45-60) from two convs with two-source inputs."""
+@pytest.mark.parametrize("precision,tol", [("fp32", 1.0), ("bf16x3", 4.0)])
+def test_conv_gru_epilogues(ops, kh, kw, precision, tol):
+    """SepConvGRU half step (update.py:45-60) from two convs with two-source inputs
+    (bf16x3 runs the LDS-halo kernel: 18x22 is not a multiple of the 8x16 tile)."""
     n, h, w = 1, 18, 22
     hprev = torch.tanh(_rand(n, 128, h, w, seed=4))
     xin = _rand(n, 256, h, w, seed=5)
@@ -82,12 +84,51 @@ def test_conv_gru_epilogues(ops, kh, kw):
     pq = ops.pack_conv(wq, bq, padding=pad)
     ha, xa = ops.act_from_nchw(hprev), ops.act_from_nchw(xin)
     zb, rh, hn = (ops.new_act(n, h, w, 128, zero=True) for _ in range(3))
-    ops.run_conv(ops.conv_params(ha, pzr, zb, x2=xa, c_split=128, epi=ops._lib.EPI_GRU_ZR, split=128, e0=ha, out1=rh))
-    ops.run_conv(ops.conv_params(rh, pq, hn, x2=xa, c_split=128, epi=ops._lib.EPI_GRU_Q, e0=ha, e1=zb))
+    pzr_p = ops.conv_params(ha, pzr, zb, x2=xa, c_split=128, epi=ops._lib.EPI_GRU_ZR, split=128, e0=ha, out1=rh,
+                            precision=precision)
+    assert pzr_p.halo == (1 if precision != "fp32" else 0)
+    ops.run_conv(pzr_p)
+    ops.run_conv(ops.conv_params(rh, pq, hn, x2=xa, c_split=128, epi=ops._lib.EPI_GRU_Q, e0=ha, e1=zb,
+                                 precision=precision))
     torch.cuda.synchronize()
-    _close(zb.nchw(), z, 2e-5, what="z")
-    _close(rh.nchw(), r * hprev, 2e-5, what="r*h")
-    _close(hn.nchw(), ref, 3e-5, what="h")
+    _close(zb.nchw(), z, 2e-5 * tol, what="z")
+    _close(rh.nchw(), r * hprev, 2e-5 * tol, what="r*h")
+    _close(hn.nchw(), ref, 3e-5 * tol, what="h")
+
+
+@pytest.mark.parametrize("precision,tol", [("bf16x3", 2e-4), ("bf16", 5e-2)])
+def test_conv_halo_patches_and_fallback(ops, precision, tol):
+    """3x3 128->128 on batches of 9x9 patches (weight head layers 2/3, weighted_raft.py:336-340): the
+    whole-patch LDS-halo kernel; and the same conv with the halo disabled must agree with it."""
+    x = F.relu(_rand(41, 128, 9, 9, seed=40))
+    wt = _rand(128, 128, 3, 3, seed=41, scale=1 / math.sqrt(128 * 9))
+    b = _rand(128, seed=42, scale=0.1)
+    ref = F.relu(F.conv2d(x, wt, b, padding=1))
+    pc = ops.pack_conv(wt, b)
+    xa = ops.act_from_nchw(x)
+    o1, o2 = ops.new_act(41, 9, 9, 128, zero=True), ops.new_act(41, 9, 9, 128, zero=True)
+    p1 = ops.conv_params(xa, pc, o1, epi=ops._lib.EPI_RELU, precision=precision)
+    p2 = ops.conv_params(xa, pc, o2, epi=ops._lib.EPI_RELU, precision=precision, halo=0)
+    assert p1.halo == 2 and p2.halo == 0
+    ops.run_conv(p1)
+    ops.run_conv(p2)
+    torch.cuda.synchronize()
+    _close(o1.nchw(), ref, tol, what="halo 9x9")
+    _close(o2.nchw(), ref, tol, what="gather")
+    _close(o1.nchw(), o2.nchw(), 2e-5, what="halo vs gather (same arithmetic, other order)")
+    # image-sized input, ragged against the 8x16 tile, cout 126 written at an offset (update.py:86,97)
+    x = _rand(1, 256, 19, 37, seed=43)
+    wt = _rand(126, 256, 3, 3, seed=44, scale=1 / math.sqrt(256 * 9))
+    b = _rand(126, seed=45, scale=0.1)
+    ref = F.relu(F.conv2d(x, wt, b, padding=1))
+    big = ops.new_act(1, 19, 37, 256, zero=True)
+    p3 = ops.conv_params(ops.act_from_nchw(x), ops.pack_conv(wt, b), big, co_off=128, epi=ops._lib.EPI_RELU,
+                         precision=precision)
+    assert p3.halo == 1
+    ops.run_conv(p3)
+    torch.cuda.synchronize()
+    _close(big.nchw()[:, 128:254], ref, tol, what="halo 8x16 ragged")
+    assert float(big.t[:, :128].abs().max()) == 0.0 and float(big.t[:, 254:].abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("precision,tol", [("fp32", 1.0), ("bf16x3", 6.0)])
@@ -139,8 +180,8 @@ def test_residual_epilogue_and_bn_fold(ops):
     _close(out.nchw(), ref, 2e-5, what="bn-fold residual")
 
 
-@pytest.mark.parametrize("tiles", [(64, 64), (128, 64)])
-def test_instance_norm(ops, tiles):
+@pytest.mark.parametrize("tiles,precision", [((64, 64), "fp32"), ((128, 64), "fp32"), ((64, 64), "bf16x3")])
+def test_instance_norm(ops, tiles, precision):
     x = _rand(1, 64, 30, 44, seed=26)
     wt = _rand(64, 64, 3, 3, seed=27, scale=0.05)
     b = _rand(64, seed=28, scale=0.3)
@@ -148,10 +189,11 @@ def test_instance_norm(ops, tiles):
     y = F.conv2d(x, wt, b, padding=1)
     pc = ops.pack_conv(wt, b)
     m = 30 * 44
-    rows = 2 * math.ceil(m / tiles[0])
-    stats = (torch.zeros(rows * pc.cout_pad, device="cuda"), torch.zeros(rows * pc.cout_pad, device="cuda"))
     raw = ops.new_act(1, 30, 44, 64, zero=True)
-    ops.run_conv(ops.conv_params(ops.act_from_nchw(x), pc, raw, stats=stats, tiles=tiles))
+    stats = (torch.zeros(64 * pc.cout_pad, device="cuda"), torch.zeros(64 * pc.cout_pad, device="cuda"))
+    cp = ops.conv_params(ops.act_from_nchw(x), pc, raw, stats=stats, tiles=tiles, precision=precision)
+    rows = 2 * cp._m_tiles
+    ops.run_conv(cp)
     mean, rstd = torch.zeros(64, device="cuda"), torch.zeros(64, device="cuda")
     mean += 7.0
     ops.inorm_finalize(stats, rows, pc.cout_pad, 64, m, mean, rstd)
@@ -160,7 +202,7 @@ def test_instance_norm(ops, tiles):
                       (2, F.relu(res + F.relu(F.instance_norm(y))))):
         ops.inorm_apply(raw, mean, rstd, out, mode, res=ops.act_from_nchw(res) if mode == 2 else None)
         torch.cuda.synchronize()
-        _close(out.nchw(), ref, 3e-5, what=f"instance norm mode {mode}")
+        _close(out.nchw(), ref, 3e-5 if precision == "fp32" else 2e-4, what=f"instance norm mode {mode}")
 
 
 def test_preprocess_and_pool(ops):

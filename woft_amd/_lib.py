@@ -27,7 +27,7 @@ class ConvParams(C.Structure):
         ("cout", i32), ("cout_pad", i32), ("out", vp), ("ldo", i64), ("co_off", i32),
         ("out_w", i32), ("out_pitch", i32), ("epi", i32), ("split", i32),
         ("e0", vp), ("e1", vp), ("lde0", i32), ("lde1", i32), ("out1", vp), ("ldo1", i32),
-        ("stat_sum", vp), ("stat_sq", vp), ("tile_m", i32), ("tile_n", i32),
+        ("stat_sum", vp), ("stat_sq", vp), ("tile_m", i32), ("tile_n", i32), ("halo", i32),
     ]
 
 

@@ -270,6 +270,199 @@ __global__ __launch_bounds__(256) void conv_mfma_bf16_kernel(const woft_conv_par
     woft::conv_epilogue<BM, BN>(p, acc, (float*)smem + wave * woft::STAGE_FLOATS, m0, n0, wm, wn, lane, M, m_tile);
 }
 
+// ---- split-bf16 kernel with an LDS-resident input halo -----------------------------------------
+// Stride-1 multi-tap convolutions (3x3, 1x5, 5x1): the workgroup's M tile is a TY x TX patch of output
+// pixels of one image; for every 32-channel chunk the (TY+kh-1) x (TX+kw-1) input halo is converted
+// and written to LDS ONCE and all kh*kw taps read their A fragments from it at shifted rows, so the
+// A-side L2->LDS traffic, the fp32->bf16 splitting and the LDS writes drop by the number of taps;
+// only the weight tile is re-staged per tap.  TY x TX = 8 x 16 for images, 9 x 9 (= the whole image)
+// for the weight head's patches (weighted_raft.py:363-376).
+struct HaloRows {
+    int img, y0, x0, ho, wo;
+    template <int TX_>
+    __device__ __forceinline__ int64_t at(int row, int npix) const {
+        if (row >= npix) return -1;
+        const int y = y0 + row / TX_, x = x0 + row % TX_;
+        return (y < ho && x < wo) ? ((int64_t)img * ho + y) * wo + x : -1;
+    }
+};
+template <int TX_, int NPIX_>
+struct HaloRowMap {
+    HaloRows h;
+    __device__ __forceinline__ int64_t operator()(int row) const { return h.at<TX_>(row, NPIX_); }
+};
+
+template <int TY, int TX, int BN, int TERMS>
+__global__ __launch_bounds__(256) void conv_halo_bf16_kernel(const woft_conv_params p) {
+    constexpr int NPIX = TY * TX;
+    constexpr int BM = (NPIX + 31) / 32 * 32;
+    constexpr int WM = (BM % 64 == 0) ? 2 : 1, WN = 4 / WM;
+    constexpr int WROWS = BM / WM, WCOLS = BN / WN;
+    constexpr int TM = WROWS / 32, TN = WCOLS / 32;
+    static_assert(WCOLS % 32 == 0 && TN >= 1, "N tile too narrow for this wave layout");
+    constexpr int NP = (TERMS == 3) ? 2 : 1;
+    constexpr int H33 = (TY + 2) * (TX + 2), H15 = TY * (TX + 4), H51 = (TY + 4) * TX;
+    constexpr int HROWS = (H33 > H15 ? (H33 > H51 ? H33 : H51) : (H15 > H51 ? H15 : H51));
+    constexpr int RH = (HROWS + 31) / 32;  // halo rows per thread
+    constexpr int RB = BN / 64;
+    constexpr int A_ELEMS = NP * HROWS * LDB, B_ELEMS = NP * BN * LDB;
+    constexpr int SMEM_ELEMS = (A_ELEMS + B_ELEMS > 8 * woft::STAGE_FLOATS) ? A_ELEMS + B_ELEMS : 8 * woft::STAGE_FLOATS;
+    __shared__ __attribute__((aligned(16))) __bf16 smem[SMEM_ELEMS];
+    __bf16* As = smem;
+    __bf16* Bs = smem + A_ELEMS;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int r32 = lane & 31, hh = lane >> 5;
+    const int v = tid & 7, r0 = tid >> 3;
+    const int vb = tid & 3, rb0 = tid >> 2;
+
+    const int tyn = (p.ho + TY - 1) / TY, txn = (p.wo + TX - 1) / TX;
+    int m_tile, n_tile;
+    woft::tile_of_block(blockIdx.x, p.n_img * tyn * txn, p.cout_pad / BN, m_tile, n_tile);
+    const int img = m_tile / (tyn * txn);
+    const int trem = m_tile - img * (tyn * txn);
+    const int y0 = (trem / txn) * TY, x0 = (trem % txn) * TX;
+    const int n0 = n_tile * BN;
+    const int taps = p.taps_y * p.taps_x;
+    const int nchunk = p.cin_pad / BK;
+    const int nk = taps * nchunk;
+    const int64_t ktot = (int64_t)nk * BK;
+    const int HX = TX + p.taps_x - 1;
+    const int hrows = (TY + p.taps_y - 1) * HX;
+
+    // halo pixels owned by this thread (rows r0 + 32 j): global pixel index or -1 (zero fill)
+    int64_t hpix[RH];
+#pragma unroll
+    for (int j = 0; j < RH; ++j) {
+        const int h = r0 + 32 * j;
+        const int hy = h / HX, hx = h - hy * HX;
+        const int iy = y0 + hy - p.pad_y, ix = x0 + hx - p.pad_x;
+        const bool ok = h < hrows && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w;
+        hpix[j] = ok ? ((int64_t)img * p.h + iy) * p.w + ix : -1;
+    }
+    const __bf16* bsrc[NP];
+    bsrc[0] = (const __bf16*)p.wgt_hi;
+    if (NP == 2) bsrc[NP - 1] = (const __bf16*)p.wgt_lo;
+
+    f32x4 rh[RH];
+    bf16x8 rb[NP][RB];
+    auto load_halo = [&](int chunk) {
+        const int c0 = chunk * BK;
+        const bool second = (p.in1 != nullptr) && (c0 >= p.c_split);
+        const float* src = second ? p.in1 : p.in0;
+        const int cs = second ? p.cs1 : p.cs0;
+        const int cc = (second ? c0 - p.c_split : c0) + 4 * v;
+#pragma unroll
+        for (int j = 0; j < RH; ++j) {
+            f32x4 val = {0.f, 0.f, 0.f, 0.f};
+            if (hpix[j] >= 0) val = *(const f32x4*)(src + hpix[j] * cs + cc);
+            rh[j] = val;
+        }
+    };
+    auto store_halo = [&]() {
+#pragma unroll
+        for (int j = 0; j < RH; ++j) {
+            const int h = r0 + 32 * j;
+            if (h >= HROWS) continue;
+            const bf16x4 hi = __builtin_convertvector(rh[j], bf16x4);
+            *(bf16x4*)(As + h * LDB + 4 * v) = hi;
+            if (NP == 2) {
+                const f32x4 rem = rh[j] - __builtin_convertvector(hi, f32x4);
+                *(bf16x4*)(As + HROWS * LDB + h * LDB + 4 * v) = __builtin_convertvector(rem, bf16x4);
+            }
+        }
+    };
+    auto load_b = [&](int ks) {
+        const int chunk = ks / taps, tap = ks - chunk * taps;
+        const int64_t koff = (int64_t)tap * p.cin_pad + chunk * BK + 8 * vb;
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+            for (int j = 0; j < RB; ++j) rb[pl][j] = *(const bf16x8*)(bsrc[pl] + (int64_t)(n0 + rb0 + 64 * j) * ktot + koff);
+    };
+    auto store_b = [&]() {
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+            for (int j = 0; j < RB; ++j) *(bf16x8*)(Bs + pl * BN * LDB + (rb0 + 64 * j) * LDB + 8 * vb) = rb[pl][j];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // A fragment rows: output pixel (ty, tx) of the tile reads halo row (ty + ky) * HX + (tx + kx)
+    int abase[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int ml = wm * WROWS + i * 32 + r32;
+        abase[i] = (ml < NPIX) ? (ml / TX) * HX + (ml % TX) : 0;
+    }
+    const __bf16* b_frag = Bs + (wn * WCOLS + r32) * LDB + hh * 8;
+
+    load_halo(0);
+    load_b(0);
+    store_halo();
+    store_b();
+    __syncthreads();
+    for (int ks = 0; ks < nk; ++ks) {
+        const int chunk = ks / taps, tap = ks - chunk * taps;
+        const bool nxt = ks + 1 < nk;
+        const bool new_chunk = nxt && (tap + 1 == taps);
+        if (nxt) load_b(ks + 1);
+        if (new_chunk) load_halo(chunk + 1);
+        const int ky = tap / p.taps_x, kx = tap - ky * p.taps_x;
+        const int toff = (ky * HX + kx) * LDB + hh * 8;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 a[NP][TM], b[NP][TN];
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[pl][i] = *(const bf16x8*)(As + pl * HROWS * LDB + abase[i] * LDB + toff + s * 16);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[pl][j] = *(const bf16x8*)(b_frag + pl * BN * LDB + j * 32 * LDB + s * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if (NP == 2) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[NP - 1][i], b[0][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[NP - 1][j], acc[i][j], 0, 0, 0);
+                    }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], acc[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+        if (nxt) {
+            store_b();
+            if (new_chunk) store_halo();
+            __syncthreads();
+        }
+    }
+    const HaloRowMap<TX, NPIX> rowmap{HaloRows{img, y0, x0, p.ho, p.wo}};
+    woft::conv_epilogue_t<TM, TN, WROWS, WCOLS>(p, acc, (float*)smem + wave * woft::STAGE_FLOATS, rowmap, n0, wm, wn,
+                                                lane, m_tile);
+}
+
+template <int TY, int TX, int BN>
+int launch_halo(const woft_conv_params& p, hipStream_t s) {
+    const int tyn = (p.ho + TY - 1) / TY, txn = (p.wo + TX - 1) / TX;
+    dim3 grid((unsigned)((int64_t)p.n_img * tyn * txn * (p.cout_pad / BN)));
+    if (p.precision == 1)
+        hipLaunchKernelGGL((conv_halo_bf16_kernel<TY, TX, BN, 3>), grid, dim3(256), 0, s, p);
+    else
+        hipLaunchKernelGGL((conv_halo_bf16_kernel<TY, TX, BN, 1>), grid, dim3(256), 0, s, p);
+    return woft_launch_status();
+}
+
 // fp32 matrix -> hi / lo bf16 planes (used for the dynamic B operand of the correlation GEMM)
 __global__ void split_bf16_kernel(const float* __restrict__ x, int64_t n4, __bf16* __restrict__ hi,
                                   __bf16* __restrict__ lo) {
@@ -333,6 +526,16 @@ extern "C" int woft_conv2d(const woft_conv_params* pp, void* stream) {
     if (p.out1 != nullptr && (p.ldo1 % 4 != 0 || p.split % 4 != 0)) return WOFT_EINVAL;
     if ((p.stat_sum == nullptr) != (p.stat_sq == nullptr)) return WOFT_EINVAL;
     hipStream_t s = (hipStream_t)stream;
+    if (p.halo != 0) {
+        // LDS-halo kernels: split-bf16 precisions, stride 1, multi-tap, non-flat, same-size output
+        if (p.precision == 0 || p.flat || p.stride != 1 || p.taps_y * p.taps_x < 2) return WOFT_EINVAL;
+        if (p.taps_y + p.taps_x > 6 || p.taps_y > 5 || p.taps_x > 5) return WOFT_EINVAL;      // 3x3, 1x5, 5x1 (and smaller)
+        if (p.ho != p.h + 2 * p.pad_y - p.taps_y + 1 || p.wo != p.w + 2 * p.pad_x - p.taps_x + 1) return WOFT_EINVAL;
+        if (p.halo == 1 && p.tile_n == 128) return launch_halo<8, 16, 128>(p, s);
+        if (p.halo == 1 && p.tile_n == 64) return launch_halo<8, 16, 64>(p, s);
+        if (p.halo == 2 && p.tile_n == 128 && p.ho == 9 && p.wo == 9) return launch_halo<9, 9, 128>(p, s);
+        return WOFT_EINVAL;
+    }
     if (p.tile_m == 128 && p.tile_n == 128) return launch_conv<128, 128>(p, s);
     if (p.tile_m == 128 && p.tile_n == 64) return launch_conv<128, 64>(p, s);
     if (p.tile_m == 64 && p.tile_n == 128) return launch_conv<64, 128>(p, s);

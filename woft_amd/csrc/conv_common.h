@@ -118,10 +118,15 @@ __device__ __forceinline__ float epi_scalar(const woft_conv_params& p, float y, 
     }
 }
 
-template <int BM, int BN>
-__device__ __forceinline__ void conv_epilogue(const woft_conv_params& p, f32x16 (&acc)[BM / 64][BN / 64],
-                                              float* stage, int64_t m0, int n0, int wm, int wn, int lane, int64_t M, int m_tile) {
-    constexpr int TM = BM / 64, TN = BN / 64;
+// RowMap: local row of the workgroup tile -> global output pixel index m, or -1 (no such pixel)
+struct LinearRows {
+    int64_t m0, M;
+    __device__ __forceinline__ int64_t operator()(int row) const { const int64_t m = m0 + row; return m < M ? m : -1; }
+};
+
+template <int TM, int TN, int WROWS, int WCOLS, typename RowMap>
+__device__ __forceinline__ void conv_epilogue_t(const woft_conv_params& p, f32x16 (&acc)[TM][TN], float* stage,
+                                                const RowMap& rowmap, int n0, int wm, int wn, int lane, int m_tile) {
     const int r32 = lane & 31, hh = lane >> 5;
     const int rr = lane >> 3, c4 = (lane & 7) * 4;
     const bool do_stats = p.stat_sum != nullptr;
@@ -129,7 +134,7 @@ __device__ __forceinline__ void conv_epilogue(const woft_conv_params& p, f32x16 
     const bool vec_out = (p.out_pitch == 0) && (p.ldo % 4 == 0) && (p.co_off % 4 == 0);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * (BN / 2) + j * 32 + c4;       // first of this lane's 4 channels
+        const int n = n0 + wn * WCOLS + j * 32 + c4;           // first of this lane's 4 channels
         f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
         if (p.bias != nullptr) bias4 = *(const f32x4*)(p.bias + n);
         const bool full = (n + 3) < p.cout;                    // all 4 channels valid
@@ -142,9 +147,9 @@ __device__ __forceinline__ void conv_epilogue(const woft_conv_params& p, f32x16 
 #pragma unroll
             for (int pass = 0; pass < 4; ++pass) {
                 const int row = rr + 8 * pass;
-                const int64_t m = m0 + wm * (BM / 2) + i * 32 + row;
+                const int64_t m = rowmap(wm * WROWS + i * 32 + row);
                 const f32x4 v = *(const f32x4*)(stage + row * STAGE_LD + c4);
-                if (m >= M || n >= p.cout) continue;
+                if (m < 0 || n >= p.cout) continue;
                 f32x4 y;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) y[e] = p.alpha * v[e] + bias4[e];
@@ -229,6 +234,13 @@ __device__ __forceinline__ void conv_epilogue(const woft_conv_params& p, f32x16 
             }
         }
     }
+}
+
+template <int BM, int BN>
+__device__ __forceinline__ void conv_epilogue(const woft_conv_params& p, f32x16 (&acc)[BM / 64][BN / 64],
+                                              float* stage, int64_t m0, int n0, int wm, int wn, int lane, int64_t M,
+                                              int m_tile) {
+    conv_epilogue_t<BM / 64, BN / 64, BM / 2, BN / 2>(p, acc, stage, LinearRows{m0, M}, n0, wm, wn, lane, m_tile);
 }
 
 }  // namespace woft

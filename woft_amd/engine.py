@@ -251,7 +251,7 @@ class _Plan:
                 return out
             raw = self._scratch(f"{tag}_raw_{name}", 1, ho, wo, pc.cout)
             p = self._cp(x, pc, raw, stats=self.stats)
-            rows = 2 * math.ceil(p._m / p.tile_m)
+            rows = 2 * p._m_tiles
             prog.append(("conv", p))
             prog.append(("fin", (rows, pc.cout_pad, pc.cout, raw.cs, p._m)))
             prog.append(("apply", (raw, out, 2 if res is not None else (1 if relu else 0), res)))

@@ -140,6 +140,7 @@ def fold_bn(weight, bias, bn_w, bn_b, mean, var, eps=1e-5):
 
 
 PRECISION = {"fp32": 0, "bf16x3": 1, "bf16": 2}
+USE_HALO = os.environ.get("WOFT_HALO", "1") != "0"
 
 
 TILE_MIN_BLOCKS = int(os.environ.get("WOFT_TILE_MIN_BLOCKS", "400"))
@@ -158,7 +159,7 @@ def pick_tiles(m, cout_pad):
 # kernels
 # ------------------------------------------------------------------------------------------
 def conv_params(x, pc, out, co_off=0, epi=_lib.EPI_LINEAR, x2=None, c_split=0, e0=None, e1=None, out1=None,
-                split=0, alpha=1.0, stats=None, ho=None, wo=None, tiles=None, cout=None, precision=0):
+                split=0, alpha=1.0, stats=None, ho=None, wo=None, tiles=None, cout=None, precision=0, halo=None):
     """Build (and keep alive) a woft_conv_params for `out[:, co_off:co_off+cout] = epi(conv(x))`."""
     if ho is None or wo is None:
         ho, wo = pc.out_hw(x.h, x.w)
@@ -183,8 +184,23 @@ def conv_params(x, pc, out, co_off=0, epi=_lib.EPI_LINEAR, x2=None, c_split=0, e
     m = x.n * ho * wo
     tm, tn = tiles or pick_tiles(m, pc.cout_pad)
     p.tile_m, p.tile_n = tm, tn
+    # LDS-halo kernel for the split-bf16 precisions on stride-1 multi-tap convs (see conv.hip)
+    if halo is None:
+        halo = 0
+        if USE_HALO and p.precision != 0 and not pc.flat and pc.stride == 1 and pc.taps_y * pc.taps_x > 1 \
+                and (ho, wo) == (x.h, x.w) and (pc.taps_y, pc.taps_x) in ((3, 3), (1, 5), (5, 1)):
+            if (x.h, x.w) == (9, 9) and tn == 128:
+                halo = 2
+            elif x.h >= 8 and x.w >= 16:
+                halo = 1
+    p.halo = halo
+    p._m_tiles = math.ceil(m / tm)
+    if halo == 1:
+        p._m_tiles = x.n * math.ceil(ho / 8) * math.ceil(wo / 16)
+    elif halo == 2:
+        p._m_tiles = x.n
     if stats is not None:
-        rows = 2 * math.ceil(m / tm)
+        rows = 2 * p._m_tiles
         assert stats[0].numel() >= rows * pc.cout_pad
         p.stat_sum, p.stat_sq = ptr(stats[0]), ptr(stats[1])
     else:
