@@ -86,7 +86,7 @@ def test_conv_gru_epilogues(ops, kh, kw, precision, tol):
     zb, rh, hn = (ops.new_act(n, h, w, 128, zero=True) for _ in range(3))
     pzr_p = ops.conv_params(ha, pzr, zb, x2=xa, c_split=128, epi=ops._lib.EPI_GRU_ZR, split=128, e0=ha, out1=rh,
                             precision=precision)
-    assert pzr_p.halo == (1 if precision != "fp32" else 0)
+    assert (pzr_p.halo in (1, 4)) == (precision != "fp32")
     ops.run_conv(pzr_p)
     ops.run_conv(ops.conv_params(rh, pq, hn, x2=xa, c_split=128, epi=ops._lib.EPI_GRU_Q, e0=ha, e1=zb,
                                  precision=precision))
@@ -124,7 +124,12 @@ def test_conv_halo_patches_and_fallback(ops, precision, tol):
     big = ops.new_act(1, 19, 37, 256, zero=True)
     p3 = ops.conv_params(ops.act_from_nchw(x), ops.pack_conv(wt, b), big, co_off=128, epi=ops._lib.EPI_RELU,
                          precision=precision)
-    assert p3.halo == 1
+    assert p3.halo in (1, 4)
+    p4 = ops.conv_params(ops.act_from_nchw(x), ops.pack_conv(wt, b), ops.new_act(1, 19, 37, 126, cs=128, zero=True),
+                         epi=ops._lib.EPI_RELU, precision=precision, halo=1 if p3.halo == 4 else 4)
+    ops.run_conv(p4)
+    torch.cuda.synchronize()
+    _close(p4._keep[3].nchw(), ref, tol, what="other halo tile")
     ops.run_conv(p3)
     torch.cuda.synchronize()
     _close(big.nchw()[:, 128:254], ref, tol, what="halo 8x16 ragged")

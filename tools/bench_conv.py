@@ -29,6 +29,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--precision", default="bf16x3")
     ap.add_argument("--tiles", default=None, help="e.g. 128,128")
+    ap.add_argument("--halo", type=int, default=None)
     a = ap.parse_args()
     tiles = tuple(int(t) for t in a.tiles.split(",")) if a.tiles else None
     hf, wf = 135, 240
@@ -46,9 +47,9 @@ def main():
             x2.t.normal_()
         out = ops.new_act(n, h, w, cout, cs=ops._round_up(cout, 4), zero=True)
         p = ops.conv_params(x, pc, out, x2=x2, c_split=cin if x2c else 0, epi=ops._lib.EPI_RELU,
-                            precision=a.precision, tiles=tiles)
+                            precision=a.precision, tiles=tiles, halo=a.halo)
         flops = 2.0 * n * h * w * (cin + x2c) * kh * kw * cout
-        cases.append((name, lambda: ops.run_conv(p), flops, (p.tile_m, p.tile_n)))
+        cases.append((name + f" [halo {p.halo}]", lambda: ops.run_conv(p), flops, (p.tile_m, p.tile_n)))
 
     if os.environ.get("ONLYVOL"):
         conv_case = lambda *a, **k: None
@@ -83,7 +84,7 @@ def main():
     for name, fn, flops, t in cases:
         ms = bench(fn)
         tot += ms
-        print(f"{name:34s} tiles {t}  {ms*1e3:9.1f} us   {flops/ms/1e9:8.1f} TFLOP/s (useful)")
+        print(f"{name:44s} tiles {t}  {ms*1e3:9.1f} us   {flops/ms/1e9:8.1f} TFLOP/s (useful)")
     print(f"sum {tot:.3f} ms  [{a.precision}]")
 
 

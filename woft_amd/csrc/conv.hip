@@ -277,36 +277,42 @@ __global__ __launch_bounds__(256) void conv_mfma_bf16_kernel(const woft_conv_par
 // A-side L2->LDS traffic, the fp32->bf16 splitting and the LDS writes drop by the number of taps;
 // only the weight tile is re-staged per tap.  TY x TX = 8 x 16 for images, 9 x 9 (= the whole image)
 // for the weight head's patches (weighted_raft.py:363-376).
-struct HaloRows {
-    int img, y0, x0, ho, wo;
-    template <int TX_>
-    __device__ __forceinline__ int64_t at(int row, int npix) const {
-        if (row >= npix) return -1;
-        const int y = y0 + row / TX_, x = x0 + row % TX_;
-        return (y < ho && x < wo) ? ((int64_t)img * ho + y) * wo + x : -1;
+// One workgroup = G tiles ("groups") of TY x TX output pixels (G > 1: consecutive images, i.e. weight-head
+// patches) x BN output channels, NWAVES waves laid out WM (rows) x NWAVES/WM (columns).  The weight
+// tile staged per tap is shared by all G*TY*TX rows: the more rows, the less weight traffic per MAC.
+template <int TY, int TX, int G>
+struct HaloRowMap {
+    int img0, n_img, y0, x0, ho, wo;
+    __device__ __forceinline__ int64_t operator()(int row) const {
+        constexpr int NPIX = TY * TX, BMG = (NPIX + 31) / 32 * 32;
+        const int g = row / BMG, pl = row - g * BMG;
+        if (pl >= NPIX || img0 + g >= n_img) return -1;
+        const int y = y0 + pl / TX, x = x0 + pl % TX;
+        return (y < ho && x < wo) ? ((int64_t)(img0 + g) * ho + y) * wo + x : -1;
     }
 };
-template <int TX_, int NPIX_>
-struct HaloRowMap {
-    HaloRows h;
-    __device__ __forceinline__ int64_t operator()(int row) const { return h.at<TX_>(row, NPIX_); }
-};
 
-template <int TY, int TX, int BN, int TERMS>
-__global__ __launch_bounds__(256) void conv_halo_bf16_kernel(const woft_conv_params p) {
+template <int TY, int TX, int G, int BN, int TERMS, int NWAVES, int WM>
+__global__ __launch_bounds__(NWAVES * 64) void conv_halo_bf16_kernel(const woft_conv_params p) {
+    constexpr int NT = NWAVES * 64;
     constexpr int NPIX = TY * TX;
-    constexpr int BM = (NPIX + 31) / 32 * 32;
-    constexpr int WM = (BM % 64 == 0) ? 2 : 1, WN = 4 / WM;
+    constexpr int BMG = (NPIX + 31) / 32 * 32;          // rows per group (padded to MFMA tiles)
+    constexpr int BM = G * BMG;
+    constexpr int WN = NWAVES / WM;
     constexpr int WROWS = BM / WM, WCOLS = BN / WN;
     constexpr int TM = WROWS / 32, TN = WCOLS / 32;
-    static_assert(WCOLS % 32 == 0 && TN >= 1, "N tile too narrow for this wave layout");
+    static_assert(BM % (32 * WM) == 0 && WCOLS % 32 == 0 && TM >= 1 && TN >= 1, "bad wave layout");
     constexpr int NP = (TERMS == 3) ? 2 : 1;
     constexpr int H33 = (TY + 2) * (TX + 2), H15 = TY * (TX + 4), H51 = (TY + 4) * TX;
-    constexpr int HROWS = (H33 > H15 ? (H33 > H51 ? H33 : H51) : (H15 > H51 ? H15 : H51));
-    constexpr int RH = (HROWS + 31) / 32;  // halo rows per thread
-    constexpr int RB = BN / 64;
-    constexpr int A_ELEMS = NP * HROWS * LDB, B_ELEMS = NP * BN * LDB;
-    constexpr int SMEM_ELEMS = (A_ELEMS + B_ELEMS > 8 * woft::STAGE_FLOATS) ? A_ELEMS + B_ELEMS : 8 * woft::STAGE_FLOATS;
+    constexpr int HROWS = (H33 > H15 ? (H33 > H51 ? H33 : H51) : (H15 > H51 ? H15 : H51));   // per group
+    constexpr int HTOT = G * HROWS;
+    constexpr int LROWS = NT / 8;                        // halo rows covered per loader pass
+    constexpr int RH = (HTOT + LROWS - 1) / LROWS;       // halo float4 rows per thread
+    constexpr int BROWS = NT / 4;                        // weight rows covered per loader pass
+    constexpr int RB = (BN + BROWS - 1) / BROWS;
+    constexpr int A_ELEMS = NP * HTOT * LDB, B_ELEMS = NP * BN * LDB;
+    constexpr int STAGE_ELEMS = 2 * NWAVES * woft::STAGE_FLOATS;
+    constexpr int SMEM_ELEMS = (A_ELEMS + B_ELEMS > STAGE_ELEMS) ? A_ELEMS + B_ELEMS : STAGE_ELEMS;
     __shared__ __attribute__((aligned(16))) __bf16 smem[SMEM_ELEMS];
     __bf16* As = smem;
     __bf16* Bs = smem + A_ELEMS;
@@ -319,10 +325,12 @@ __global__ __launch_bounds__(256) void conv_halo_bf16_kernel(const woft_conv_par
     const int vb = tid & 3, rb0 = tid >> 2;
 
     const int tyn = (p.ho + TY - 1) / TY, txn = (p.wo + TX - 1) / TX;
+    const int img_groups = (p.n_img + G - 1) / G;
     int m_tile, n_tile;
-    woft::tile_of_block(blockIdx.x, p.n_img * tyn * txn, p.cout_pad / BN, m_tile, n_tile);
-    const int img = m_tile / (tyn * txn);
-    const int trem = m_tile - img * (tyn * txn);
+    woft::tile_of_block(blockIdx.x, img_groups * tyn * txn, p.cout_pad / BN, m_tile, n_tile);
+    const int ig = m_tile / (tyn * txn);
+    const int trem = m_tile - ig * (tyn * txn);
+    const int img0 = ig * G;
     const int y0 = (trem / txn) * TY, x0 = (trem % txn) * TX;
     const int n0 = n_tile * BN;
     const int taps = p.taps_y * p.taps_x;
@@ -330,17 +338,18 @@ __global__ __launch_bounds__(256) void conv_halo_bf16_kernel(const woft_conv_par
     const int nk = taps * nchunk;
     const int64_t ktot = (int64_t)nk * BK;
     const int HX = TX + p.taps_x - 1;
-    const int hrows = (TY + p.taps_y - 1) * HX;
+    const int hrows = (TY + p.taps_y - 1) * HX;          // used halo rows per group (<= HROWS)
 
-    // halo pixels owned by this thread (rows r0 + 32 j): global pixel index or -1 (zero fill)
-    int64_t hpix[RH];
+    // halo pixels owned by this thread (rows r0 + LROWS j): global pixel index or -1 (zero fill)
+    int hpix[RH];                // (n_img * h * w < 2^31: validated by the launcher)
 #pragma unroll
     for (int j = 0; j < RH; ++j) {
-        const int h = r0 + 32 * j;
+        const int ht = r0 + LROWS * j;
+        const int g = ht / HROWS, h = ht - g * HROWS;
         const int hy = h / HX, hx = h - hy * HX;
         const int iy = y0 + hy - p.pad_y, ix = x0 + hx - p.pad_x;
-        const bool ok = h < hrows && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w;
-        hpix[j] = ok ? ((int64_t)img * p.h + iy) * p.w + ix : -1;
+        const bool ok = ht < HTOT && h < hrows && img0 + g < p.n_img && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w;
+        hpix[j] = ok ? ((img0 + g) * p.h + iy) * p.w + ix : -1;
     }
     const __bf16* bsrc[NP];
     bsrc[0] = (const __bf16*)p.wgt_hi;
@@ -357,20 +366,20 @@ __global__ __launch_bounds__(256) void conv_halo_bf16_kernel(const woft_conv_par
 #pragma unroll
         for (int j = 0; j < RH; ++j) {
             f32x4 val = {0.f, 0.f, 0.f, 0.f};
-            if (hpix[j] >= 0) val = *(const f32x4*)(src + hpix[j] * cs + cc);
+            if (hpix[j] >= 0) val = *(const f32x4*)(src + (int64_t)hpix[j] * cs + cc);
             rh[j] = val;
         }
     };
     auto store_halo = [&]() {
 #pragma unroll
         for (int j = 0; j < RH; ++j) {
-            const int h = r0 + 32 * j;
-            if (h >= HROWS) continue;
+            const int ht = r0 + LROWS * j;
+            if (ht >= HTOT) continue;
             const bf16x4 hi = __builtin_convertvector(rh[j], bf16x4);
-            *(bf16x4*)(As + h * LDB + 4 * v) = hi;
+            *(bf16x4*)(As + ht * LDB + 4 * v) = hi;
             if (NP == 2) {
                 const f32x4 rem = rh[j] - __builtin_convertvector(hi, f32x4);
-                *(bf16x4*)(As + HROWS * LDB + h * LDB + 4 * v) = __builtin_convertvector(rem, bf16x4);
+                *(bf16x4*)(As + HTOT * LDB + ht * LDB + 4 * v) = __builtin_convertvector(rem, bf16x4);
             }
         }
     };
@@ -380,13 +389,16 @@ __global__ __launch_bounds__(256) void conv_halo_bf16_kernel(const woft_conv_par
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
-            for (int j = 0; j < RB; ++j) rb[pl][j] = *(const bf16x8*)(bsrc[pl] + (int64_t)(n0 + rb0 + 64 * j) * ktot + koff);
+            for (int j = 0; j < RB; ++j)
+                if (rb0 + BROWS * j < BN)
+                    rb[pl][j] = *(const bf16x8*)(bsrc[pl] + (int64_t)(n0 + rb0 + BROWS * j) * ktot + koff);
     };
     auto store_b = [&]() {
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
-            for (int j = 0; j < RB; ++j) *(bf16x8*)(Bs + pl * BN * LDB + (rb0 + 64 * j) * LDB + 8 * vb) = rb[pl][j];
+            for (int j = 0; j < RB; ++j)
+                if (rb0 + BROWS * j < BN) *(bf16x8*)(Bs + pl * BN * LDB + (rb0 + BROWS * j) * LDB + 8 * vb) = rb[pl][j];
     };
 
     f32x16 acc[TM][TN];
@@ -397,12 +409,13 @@ __global__ __launch_bounds__(256) void conv_halo_bf16_kernel(const woft_conv_par
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // A fragment rows: output pixel (ty, tx) of the tile reads halo row (ty + ky) * HX + (tx + kx)
+    // A fragment rows: output pixel (ty, tx) of group g reads halo row g*HROWS + (ty + ky) * HX + (tx + kx)
     int abase[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int ml = wm * WROWS + i * 32 + r32;
-        abase[i] = (ml < NPIX) ? (ml / TX) * HX + (ml % TX) : 0;
+        const int g = ml / BMG, pl = ml - g * BMG;
+        abase[i] = g * HROWS + ((pl < NPIX) ? (pl / TX) * HX + (pl % TX) : 0);
     }
     const __bf16* b_frag = Bs + (wn * WCOLS + r32) * LDB + hh * 8;
 
@@ -421,24 +434,25 @@ __global__ __launch_bounds__(256) void conv_halo_bf16_kernel(const woft_conv_par
         const int toff = (ky * HX + kx) * LDB + hh * 8;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            bf16x8 a[NP][TM], b[NP][TN];
+            bf16x8 b[NP][TN];
 #pragma unroll
-            for (int pl = 0; pl < NP; ++pl) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) a[pl][i] = *(const bf16x8*)(As + pl * HROWS * LDB + abase[i] * LDB + toff + s * 16);
+            for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) b[pl][j] = *(const bf16x8*)(b_frag + pl * BN * LDB + j * 32 * LDB + s * 16);
-            }
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i) {
+                bf16x8 a[NP];            // A fragments are loaded per row tile: keeps tall wave tiles in registers
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl) a[pl] = *(const bf16x8*)(As + pl * HTOT * LDB + abase[i] * LDB + toff + s * 16);
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     if (NP == 2) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[NP - 1][i], b[0][j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[NP - 1][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[NP - 1], b[0][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[NP - 1][j], acc[i][j], 0, 0, 0);
                     }
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0][j], acc[i][j], 0, 0, 0);
                 }
+            }
         }
         __syncthreads();
         if (nxt) {
@@ -447,19 +461,20 @@ __global__ __launch_bounds__(256) void conv_halo_bf16_kernel(const woft_conv_par
             __syncthreads();
         }
     }
-    const HaloRowMap<TX, NPIX> rowmap{HaloRows{img, y0, x0, p.ho, p.wo}};
+    const HaloRowMap<TY, TX, G> rowmap{img0, p.n_img, y0, x0, p.ho, p.wo};
     woft::conv_epilogue_t<TM, TN, WROWS, WCOLS>(p, acc, (float*)smem + wave * woft::STAGE_FLOATS, rowmap, n0, wm, wn,
                                                 lane, m_tile);
 }
 
-template <int TY, int TX, int BN>
+template <int TY, int TX, int G, int BN, int NWAVES, int WM>
 int launch_halo(const woft_conv_params& p, hipStream_t s) {
     const int tyn = (p.ho + TY - 1) / TY, txn = (p.wo + TX - 1) / TX;
-    dim3 grid((unsigned)((int64_t)p.n_img * tyn * txn * (p.cout_pad / BN)));
+    const int64_t mt = (int64_t)((p.n_img + G - 1) / G) * tyn * txn;
+    dim3 grid((unsigned)(mt * (p.cout_pad / BN)));
     if (p.precision == 1)
-        hipLaunchKernelGGL((conv_halo_bf16_kernel<TY, TX, BN, 3>), grid, dim3(256), 0, s, p);
+        hipLaunchKernelGGL((conv_halo_bf16_kernel<TY, TX, G, BN, 3, NWAVES, WM>), grid, dim3(NWAVES * 64), 0, s, p);
     else
-        hipLaunchKernelGGL((conv_halo_bf16_kernel<TY, TX, BN, 1>), grid, dim3(256), 0, s, p);
+        hipLaunchKernelGGL((conv_halo_bf16_kernel<TY, TX, G, BN, 1, NWAVES, WM>), grid, dim3(NWAVES * 64), 0, s, p);
     return woft_launch_status();
 }
 
@@ -531,9 +546,14 @@ extern "C" int woft_conv2d(const woft_conv_params* pp, void* stream) {
         if (p.precision == 0 || p.flat || p.stride != 1 || p.taps_y * p.taps_x < 2) return WOFT_EINVAL;
         if (p.taps_y + p.taps_x > 6 || p.taps_y > 5 || p.taps_x > 5) return WOFT_EINVAL;      // 3x3, 1x5, 5x1 (and smaller)
         if (p.ho != p.h + 2 * p.pad_y - p.taps_y + 1 || p.wo != p.w + 2 * p.pad_x - p.taps_x + 1) return WOFT_EINVAL;
-        if (p.halo == 1 && p.tile_n == 128) return launch_halo<8, 16, 128>(p, s);
-        if (p.halo == 1 && p.tile_n == 64) return launch_halo<8, 16, 64>(p, s);
-        if (p.halo == 2 && p.tile_n == 128 && p.ho == 9 && p.wo == 9) return launch_halo<9, 9, 128>(p, s);
+        if ((int64_t)p.n_img * p.h * p.w >= (1ll << 31)) return WOFT_EINVAL;
+        if (p.halo == 1 && p.tile_n == 128) return launch_halo<8, 16, 1, 128, 4, 2>(p, s);
+        if (p.halo == 1 && p.tile_n == 64) return launch_halo<8, 16, 1, 64, 4, 2>(p, s);
+        if (p.halo == 2 && p.tile_n == 128 && p.ho == 9 && p.wo == 9) return launch_halo<9, 9, 1, 128, 4, 1>(p, s);
+        if (p.halo == 3 && p.tile_n == 128) return launch_halo<16, 16, 1, 128, 8, 4>(p, s);
+        if (p.halo == 4 && p.tile_n == 128) return launch_halo<4, 16, 1, 128, 4, 2>(p, s);
+        if (p.halo == 5 && p.tile_n == 128 && p.ho == 9 && p.wo == 9) return launch_halo<9, 9, 4, 128, 8, 2>(p, s);
+        if (p.halo == 6 && p.tile_n == 128 && p.ho == 9 && p.wo == 9) return launch_halo<9, 9, 2, 128, 4, 1>(p, s);
         return WOFT_EINVAL;
     }
     if (p.tile_m == 128 && p.tile_n == 128) return launch_conv<128, 128>(p, s);

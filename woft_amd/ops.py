@@ -141,6 +141,9 @@ def fold_bn(weight, bias, bn_w, bn_b, mean, var, eps=1e-5):
 
 PRECISION = {"fp32": 0, "bf16x3": 1, "bf16": 2}
 USE_HALO = os.environ.get("WOFT_HALO", "1") != "0"
+HALO_TILES = {1: (8, 16, 1), 2: (9, 9, 1), 3: (16, 16, 1), 4: (4, 16, 1), 5: (9, 9, 4), 6: (9, 9, 2)}     # (TY, TX, images per workgroup)
+HALO_MIN_BLOCKS = int(os.environ.get("WOFT_HALO_MIN_BLOCKS", "400"))
+WH_HALO = int(os.environ.get("WOFT_WH_HALO", "2"))
 
 
 TILE_MIN_BLOCKS = int(os.environ.get("WOFT_TILE_MIN_BLOCKS", "400"))
@@ -189,16 +192,21 @@ def conv_params(x, pc, out, co_off=0, epi=_lib.EPI_LINEAR, x2=None, c_split=0, e
         halo = 0
         if USE_HALO and p.precision != 0 and not pc.flat and pc.stride == 1 and pc.taps_y * pc.taps_x > 1 \
                 and (ho, wo) == (x.h, x.w) and (pc.taps_y, pc.taps_x) in ((3, 3), (1, 5), (5, 1)):
+            nt = pc.cout_pad // tn
             if (x.h, x.w) == (9, 9) and tn == 128:
-                halo = 2
+                halo = WH_HALO if x.n >= 4 * 256 else 2
             elif x.h >= 8 and x.w >= 16:
                 halo = 1
+                # measured on MI355X: many independent workgroups beat larger tiles (16x16 / multi-patch
+                # workgroups run at 1 block per CU and lose to 8x16 by 1.5-3x), so take the 8x16 tile
+                # only while it still yields ~2 workgroups per CU, else 4x16
+                if tn == 128 and x.n * math.ceil(ho / 8) * math.ceil(wo / 16) * nt < HALO_MIN_BLOCKS:
+                    halo = 4
     p.halo = halo
     p._m_tiles = math.ceil(m / tm)
-    if halo == 1:
-        p._m_tiles = x.n * math.ceil(ho / 8) * math.ceil(wo / 16)
-    elif halo == 2:
-        p._m_tiles = x.n
+    if halo in HALO_TILES:
+        ty, tx, g = HALO_TILES[halo]
+        p._m_tiles = math.ceil(x.n / g) * math.ceil(ho / ty) * math.ceil(wo / tx)
     if stats is not None:
         rows = 2 * p._m_tiles
         assert stats[0].numel() >= rows * pc.cout_pad
