@@ -141,6 +141,13 @@ def main():
     lk_ms = [s.elapsed_time(e) for s, e in events]
     lk_avg = float(np.mean(lk_ms)) if lk_ms else float("nan")
     algo_bytes = LOOKUP_ALGO_BYTES_PER_PIXEL * plan.P
+    traffic = None            # HBM bytes per launch from the committed PMC passes (separate rocprofv3 runs)
+    try:
+        pmc = json.loads((ROOT / "profiles" / "r01_lookup_pmc.json").read_text())
+        if pmc["resolution"] == [H, W]:
+            traffic = pmc["traffic_bytes_per_launch"]
+    except Exception:
+        pass
     achieved = algo_bytes / (lk_avg * 1e-3) / 1e9 if lk_ms else float("nan")
     out = {
         "metric": "tracked frames/sec at 1080p, 12 RAFT iters; flow EPE vs reference",
@@ -155,7 +162,7 @@ def main():
                    "frames_resident_in_hbm": True},
         "lost_frames": n_lost,
         "roofline": {"bound": "hbm", "kernel": "corr_lookup_kernel<4>", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": lk_avg, "launches_timed": len(lk_ms)},
     }
     tc_gpu = {}
