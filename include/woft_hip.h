@@ -176,6 +176,11 @@ int woft_upflow8(const float* coords1, const float* wlow, int32_t hf, int32_t wf
 int woft_warp_perspective_u8(const uint8_t* img, int32_t h, int32_t w, int32_t c, const double* hinv,
                              uint8_t* out, uint8_t* valid, int32_t nearest, void* stream);
 
+/* cv2.resize(img, None, fx, fy) with INTER_LINEAR geometry (tracker/YAOF_tracker_single_control.py:27-30,60-61,
+ * `downscale_inputs`): src = (dst + 0.5) * scale - 0.5, edge clamped; scale = 1 / fx. */
+int woft_resize_linear_u8(const uint8_t* img, int32_t h, int32_t w, int32_t c, uint8_t* out, int32_t ho, int32_t wo,
+                          float scale_y, float scale_x, void* stream);
+
 /* Weighted / iteratively re-weighted least-squares homography, utils/least_squares_H.py:142-210
  * (n_irls = 0) and :280-346 (n_irls = 5 -> 6 solves); reweight: 0 none, 1 L1 (:268-269),
  * 2 Huber(k) (:272-277).  pa, pb: [n][2] points (A -> B), w: [n] or NULL; n = min(count[0], n_max)

@@ -61,12 +61,42 @@ def warp_nearest(img, Hm):
     return img[np.clip(sy, 0, H - 1), np.clip(sx, 0, W - 1)] * ok
 
 
+def resize_linear_u8(img, factor):
+    """cv2.resize(img, None, fx=1/factor, fy=1/factor), INTER_LINEAR geometry, float arithmetic (TRK:27-30)."""
+    h, w = img.shape[:2]
+    ho, wo = int(round(h / factor)), int(round(w / factor))
+    fy = (np.arange(ho, dtype=np.float32) + np.float32(0.5)) * np.float32(factor) - np.float32(0.5)
+    fx = (np.arange(wo, dtype=np.float32) + np.float32(0.5)) * np.float32(factor) - np.float32(0.5)
+    y0 = np.floor(fy).astype(np.int64)
+    x0 = np.floor(fx).astype(np.int64)
+    wy = (fy - y0).astype(np.float32)
+    wx = (fx - x0).astype(np.float32)
+    wy[y0 < 0] = 0
+    wx[x0 < 0] = 0
+    y0 = np.clip(y0, 0, h - 1)
+    x0 = np.clip(x0, 0, w - 1)
+    wy[y0 >= h - 1] = 0
+    wx[x0 >= w - 1] = 0
+    y1 = np.minimum(y0 + 1, h - 1)
+    x1 = np.minimum(x0 + 1, w - 1)
+    src = img.astype(np.float32)
+    if src.ndim == 2:
+        src = src[..., None]
+    wxx = wx[None, :, None]
+    top = src[y0][:, x0] * (1 - wxx) + src[y0][:, x1] * wxx
+    bot = src[y1][:, x0] * (1 - wxx) + src[y1][:, x1] * wxx
+    wyy = wy[:, None, None]
+    out = np.clip(np.rint(top * (1 - wyy) + bot * wyy), 0, 255).astype(np.uint8)
+    return out[..., 0] if img.ndim == 2 else out
+
+
 class TrackerRef:
     """YAOFTrackerSingleControl restated (default WOFT config: QR estimator, Sobol-500,
     no_prewarp_after_N = 10; configs/YAOFT_single_control_repRAFT_sub500_noreliableinl_wLSq.py:56-71)."""
 
     def __init__(self, sd, iters=12, estimator="qr", subsample=500, no_prewarp_after_N=10,
-                 no_local_H=False, small=False):
+                 no_local_H=False, small=False, downscale=None, padding_mode="nopad"):
+        self.downscale, self.padding_mode = downscale, padding_mode
         self.sd, self.iters, self.small = sd, iters, small
         self.subsample = subsample
         self.no_prewarp_after_N = no_prewarp_after_N
@@ -80,6 +110,8 @@ class TrackerRef:
             raise ValueError(estimator)
 
     def init(self, img, mask):                                   # TRK:26-47
+        if self.downscale:
+            img, mask = resize_linear_u8(img, self.downscale), resize_linear_u8(mask, self.downscale)
         self.template_img = img
         self.template_mask = torch.from_numpy(mask > 0)
         self.np_template_mask = mask
@@ -91,7 +123,7 @@ class TrackerRef:
 
     def _flow(self, a, b):
         return raft_ref.compute_flow(self.sd, a, b, self.iters, mode="TC", small=self.small,
-                                     weighted=True, do_sigmoid=True)
+                                     weighted=True, do_sigmoid=True, padding_mode=self.padding_mode)
 
     def _subsample(self, a, b, w):                               # configs/..wLSq.py:31-53
         if not self.subsample:
@@ -101,6 +133,8 @@ class TrackerRef:
 
     def track(self, img):                                        # TRK:57-285
         meta = SimpleNamespace()
+        if self.downscale:
+            img = resize_linear_u8(img, self.downscale)
         if self.no_prewarp_after_N and self.N_lost > self.no_prewarp_after_N:
             self.last_good_H2init = np.eye(3)
         meta.last_good_H2init = self.last_good_H2init.copy()
@@ -142,6 +176,9 @@ class TrackerRef:
         if not self.lost:
             self.last_good_H2init = H_cur.copy()
         meta.lost, meta.N_lost, meta.global_H_success = self.lost, self.N_lost, ok
+        if self.downscale:                                       # TRK:280-283
+            k = self.downscale
+            H_cur = hfit_ref.compose_H(np.diag([1.0 / k, 1.0 / k, 1.0]), H_cur, np.diag([float(k), float(k), 1.0]))
         return H_cur, meta
 
     def _mask_coords(self, tc, cur, w, pw_mask):                 # TRK:287-312

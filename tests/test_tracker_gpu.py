@@ -90,3 +90,27 @@ def test_tracker_lost_branch_and_interfaces():
     two[:8, :8] = 255
     with pytest.raises(AssertionError):
         tracker.init(template, two)
+
+
+def test_tracker_downscaled_inputs():
+    """downscale_inputs = 2 with RAFT replicate padding (configs/WOFT_downscale_2x.py, TRK:27-30,60-61,280-283)."""
+    from pytracking.utils.config import load_config
+    H, W, iters = 268, 332, 3                  # -> 134 x 166 after the resize: not a multiple of 8
+    sd = synth.make_state_dict(seed=7)
+    template = synth.make_template(H, W, seq_id=6)
+    frames = [synth.make_frame(template, t) for t in (1, 2)]
+    mask = synth.make_init_mask(H, W)
+    conf = load_config(ROOT / "pytracking" / "configs" / "WOFT_downscale_2x.py")
+    conf.flow_config.model = sd
+    conf.flow_config.iters = iters
+    tracker = conf.tracker_class(conf)
+    tracker.init(template, mask)
+    ref = tracker_ref.TrackerRef(sd, iters=iters, downscale=2, padding_mode="RAFT")
+    ref.init(template, mask)
+    d = np.abs(tracker.template_img.cpu().numpy().astype(np.int32) - ref.template_img.astype(np.int32))
+    assert d.max() <= 1
+    for f in frames:
+        Hg, mg = tracker.track(f)
+        Hr, mr = ref.track(f)
+        assert mg.lost == mr.lost
+        assert _corners_err(Hg, Hr, H, W) < 1.0

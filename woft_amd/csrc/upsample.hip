@@ -146,7 +146,40 @@ __global__ void warp_kernel(const uint8_t* __restrict__ img, int h, int w, int c
     }
 }
 
+// cv2.resize(..., fx, fy, INTER_LINEAR) geometry: src = (dst + 0.5) * scale - 0.5, edge clamped;
+// float interpolation (OpenCV's is fixed point: expect +-1 grey level).
+__global__ void resize_linear_kernel(const uint8_t* __restrict__ img, int h, int w, int c, uint8_t* __restrict__ out,
+                                     int ho, int wo, float sy, float sx) {
+    const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= (int64_t)ho * wo) return;
+    const int y = (int)(o / wo), x = (int)(o - (int64_t)y * wo);
+    float fy = ((float)y + 0.5f) * sy - 0.5f, fx = ((float)x + 0.5f) * sx - 0.5f;
+    int y0 = (int)floorf(fy), x0 = (int)floorf(fx);
+    fy -= (float)y0;
+    fx -= (float)x0;
+    if (y0 < 0) { y0 = 0; fy = 0.f; }
+    if (x0 < 0) { x0 = 0; fx = 0.f; }
+    if (y0 >= h - 1) { y0 = h - 1; fy = 0.f; }
+    if (x0 >= w - 1) { x0 = w - 1; fx = 0.f; }
+    const int y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
+    for (int k = 0; k < c; ++k) {
+        const float t00 = img[((int64_t)y0 * w + x0) * c + k], t01 = img[((int64_t)y0 * w + x1) * c + k];
+        const float t10 = img[((int64_t)y1 * w + x0) * c + k], t11 = img[((int64_t)y1 * w + x1) * c + k];
+        const float top = t00 * (1.f - fx) + t01 * fx, bot = t10 * (1.f - fx) + t11 * fx;
+        out[o * c + k] = (uint8_t)fminf(fmaxf(rintf(top * (1.f - fy) + bot * fy), 0.f), 255.f);
+    }
+}
+
 }  // namespace
+
+extern "C" int woft_resize_linear_u8(const uint8_t* img, int32_t h, int32_t w, int32_t c, uint8_t* out, int32_t ho,
+                                     int32_t wo, float scale_y, float scale_x, void* stream) {
+    if (!img || !out || h <= 0 || w <= 0 || c <= 0 || c > 4 || ho <= 0 || wo <= 0) return WOFT_EINVAL;
+    const int64_t n = (int64_t)ho * wo;
+    hipLaunchKernelGGL(resize_linear_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, (hipStream_t)stream, img,
+                       h, w, c, out, ho, wo, scale_y, scale_x);
+    return woft_launch_status();
+}
 
 extern "C" int woft_convex_upsample(const float* coords1, const float* wlow, const float* mask, int32_t ld_mask,
                                     int32_t hf, int32_t wf, int32_t crop_top, int32_t crop_left, int32_t h, int32_t w,

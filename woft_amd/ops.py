@@ -353,6 +353,17 @@ def warp_perspective_u8(img, Hmat, out=None, valid=None, nearest=False):
                                                stream_ptr()), "woft_warp_perspective_u8")
 
 
+def resize_by_factor_u8(img, factor):
+    """cv2.resize(img, None, fx=1/factor, fy=1/factor) (INTER_LINEAR geometry) on the device."""
+    h, w = img.shape[:2]
+    c = 1 if img.dim() == 2 else img.shape[2]
+    ho, wo = int(round(h / factor)), int(round(w / factor))
+    out = torch.empty((ho, wo) if img.dim() == 2 else (ho, wo, c), dtype=torch.uint8, device=img.device)
+    check(_lib.load().woft_resize_linear_u8(ptr(img), h, w, c, ptr(out), ho, wo, float(factor), float(factor),
+                                            stream_ptr()), "woft_resize_linear_u8")
+    return out
+
+
 def hfit(pa, pb, w, Hout, status, count=None, reweight=0, huber_k=1.0, n_irls=0):
     n = pa.shape[0]
     check(_lib.load().woft_hfit(ptr(pa), ptr(pb), ptr(w), n, ptr(count), reweight, float(huber_k), n_irls,

@@ -53,8 +53,12 @@ class YAOFTrackerSingleControl:
         self.device = "cuda"
 
     def init(self, img, mask, img_identifier=None):
-        if self.C.downscale_inputs:
-            raise NotImplementedError("downscale_inputs (cv2.resize, TRK:27-30) is not on the HIP path yet")
+        if self.C.downscale_inputs:                                  # TRK:27-30
+            k = self.C.downscale_inputs
+            img = ops.resize_by_factor_u8(_to_gpu_u8(img), k)
+            mask = ops.resize_by_factor_u8(_to_gpu_u8(np.ascontiguousarray(mask) if not isinstance(mask, torch.Tensor)
+                                                      else mask), k)
+            img_identifier = None
         mask_np = mask.cpu().numpy() if isinstance(mask, torch.Tensor) else np.asarray(mask)
         self.template_img = img
         self.template_mask = torch.from_numpy(mask_np > 0).to(self.device)
@@ -80,6 +84,8 @@ class YAOFTrackerSingleControl:
 
     def track(self, input_img, debug=False, img_identifier=None):
         meta = SimpleNamespace()
+        if self.C.downscale_inputs:                                  # TRK:60-61
+            input_img = ops.resize_by_factor_u8(_to_gpu_u8(input_img), self.C.downscale_inputs)
         if self.fast_forward:                                        # TRK:63-76
             H_cur2init = self.fast_forward_H2init
             meta = self.fast_forward_meta
@@ -173,6 +179,9 @@ class YAOFTrackerSingleControl:
         meta.lost = self.lost
         meta.N_lost = self.N_lost
         meta.global_H_success = global_H_success
+        if self.C.downscale_inputs:                                  # TRK:280-283
+            k = self.C.downscale_inputs
+            H_cur2init = compose_H(np.diag([1.0 / k, 1.0 / k, 1.0]), H_cur2init, np.diag([float(k), float(k), 1.0]))
         return H_cur2init, meta
 
     def _mask_coords(self, template_coords, cur_coords, weights, post_weights, pw_mask=None, do_pw_mask=True):
