@@ -85,9 +85,9 @@ typedef struct woft_conv_params {
     int32_t tile_m, tile_n;/* block tile: 128 or 64 each                                       */
     int32_t halo;          /* 0: gather A per tap.  Split-bf16 precisions, stride 1, 3x3/1x5/5x1 only:
                               input halo of the output tile resident in LDS for all taps; tile_m ignored:
-                              1 = 8x16 px (4 waves), 3 = 16x16 px (8 waves), 4 = 4x16 px (4 waves),
-                              2 = one 9x9 image per workgroup, 5 = four 9x9 images per workgroup (8 waves)
-                              (weight-head patches; ho = wo = 9). */
+                              1 = 8x16 px, 4 = 4x16 px, 2 = one 9x9 image per workgroup (weight-head patches;
+                              ho = wo = 9).  (Larger tiles / several patches per workgroup were measured
+                              1.5-3x slower: one workgroup per CU cannot hide its own latencies.) */
 } woft_conv_params;
 
 int woft_conv2d(const woft_conv_params* p, void* stream);

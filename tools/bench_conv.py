@@ -48,6 +48,7 @@ def main():
         out = ops.new_act(n, h, w, cout, cs=ops._round_up(cout, 4), zero=True)
         p = ops.conv_params(x, pc, out, x2=x2, c_split=cin if x2c else 0, epi=ops._lib.EPI_RELU,
                             precision=a.precision, tiles=tiles, halo=a.halo)
+        p.out_w = int(os.environ.get("ABL", "0"))
         flops = 2.0 * n * h * w * (cin + x2c) * kh * kw * cout
         cases.append((name + f" [halo {p.halo}]", lambda: ops.run_conv(p), flops, (p.tile_m, p.tile_n)))
 
@@ -81,6 +82,9 @@ def main():
     cases.append(("torch fill 4.2 GB", lambda: big.fill_(1.0), 0.0, (0, 0)))
     cases.append(("torch copy 4.2 GB", lambda: big.copy_(vol), 0.0, (0, 0)))
     tot = 0.0
+    only = os.environ.get("ONLY")
+    if only:
+        cases = [c for c in cases if only in c[0]]
     for name, fn, flops, t in cases:
         ms = bench(fn)
         tot += ms

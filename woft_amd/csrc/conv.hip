@@ -550,10 +550,7 @@ extern "C" int woft_conv2d(const woft_conv_params* pp, void* stream) {
         if (p.halo == 1 && p.tile_n == 128) return launch_halo<8, 16, 1, 128, 4, 2>(p, s);
         if (p.halo == 1 && p.tile_n == 64) return launch_halo<8, 16, 1, 64, 4, 2>(p, s);
         if (p.halo == 2 && p.tile_n == 128 && p.ho == 9 && p.wo == 9) return launch_halo<9, 9, 1, 128, 4, 1>(p, s);
-        if (p.halo == 3 && p.tile_n == 128) return launch_halo<16, 16, 1, 128, 8, 4>(p, s);
         if (p.halo == 4 && p.tile_n == 128) return launch_halo<4, 16, 1, 128, 4, 2>(p, s);
-        if (p.halo == 5 && p.tile_n == 128 && p.ho == 9 && p.wo == 9) return launch_halo<9, 9, 4, 128, 8, 2>(p, s);
-        if (p.halo == 6 && p.tile_n == 128 && p.ho == 9 && p.wo == 9) return launch_halo<9, 9, 2, 128, 4, 1>(p, s);
         return WOFT_EINVAL;
     }
     if (p.tile_m == 128 && p.tile_n == 128) return launch_conv<128, 128>(p, s);

@@ -141,7 +141,7 @@ def fold_bn(weight, bias, bn_w, bn_b, mean, var, eps=1e-5):
 
 PRECISION = {"fp32": 0, "bf16x3": 1, "bf16": 2}
 USE_HALO = os.environ.get("WOFT_HALO", "1") != "0"
-HALO_TILES = {1: (8, 16, 1), 2: (9, 9, 1), 3: (16, 16, 1), 4: (4, 16, 1), 5: (9, 9, 4), 6: (9, 9, 2)}     # (TY, TX, images per workgroup)
+HALO_TILES = {1: (8, 16, 1), 2: (9, 9, 1), 4: (4, 16, 1)}     # (TY, TX, images per workgroup)
 HALO_MIN_BLOCKS = int(os.environ.get("WOFT_HALO_MIN_BLOCKS", "400"))
 WH_HALO = int(os.environ.get("WOFT_WH_HALO", "2"))
 
