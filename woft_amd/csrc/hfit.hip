@@ -6,8 +6,11 @@
 // row weighting, per-row IRLS re-weighting) and the 9x9 Gram matrix [A b]^T [A b] is accumulated in
 // fp64 (streaming, 20 B per correspondence per pass) and solved by an fp64 Cholesky factorisation:
 // the least-squares solution is the same, the conditioning loss of the normal equations is absorbed
-// by the wider type.  One workgroup does the whole fit in a single launch (N <= 500 after the Sobol
-// subsampler of the default configs; larger N loops).
+// by the wider type.  The Gram matrix is a (16 x 2N) x (2N x 16) GEMM (9 live columns): it runs on the
+// fp64 matrix cores, v_mfma_f64_16x16x4_f64 -- one MFMA consumes the 4 system rows of 2
+// correspondences, lane (c = lane & 15, k = lane >> 4) supplying element c of row k as BOTH operands
+// (A[i][k] = B[k][i] = R_k[i]).  One workgroup does the whole fit in a single launch (N <= 500 after
+// the Sobol subsampler of the default configs; larger N loops).
 #include "common.h"
 
 namespace {
@@ -63,8 +66,9 @@ __global__ __launch_bounds__(HT) void hfit_kernel(const float* __restrict__ pa, 
                                                   const float* __restrict__ w, int n_max,
                                                   const int* __restrict__ count, int reweight, float huber_k,
                                                   int n_solves, float* __restrict__ Hout, int* __restrict__ status) {
-    __shared__ double red[(HT / 64) * NG];
+    __shared__ double red[(HT / 64) * 81];
     __shared__ double tot[NG];
+    __shared__ double gram[81];
     __shared__ float sol_s[8];
     __shared__ int fail_s;
     int n = n_max;
@@ -104,55 +108,60 @@ __global__ __launch_bounds__(HT) void hfit_kernel(const float* __restrict__ pa, 
     __syncthreads();
 
     // ---- (re-)weighted normal equations, n_solves solves -----------------------------------------
+    typedef double f64x4 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ec = lane & 15, ek = lane >> 4;            // element column, row-in-quad (point = ek >> 1, x/y row = ek & 1)
     for (int it = 0; it < n_solves; ++it) {
-        double g[NG];
-#pragma unroll
-        for (int k = 0; k < NG; ++k) g[k] = 0.0;
         float sol[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) sol[k] = (it > 0) ? sol_s[k] : 0.f;
-        for (int i = threadIdx.x; i < n; i += HT) {
-            const float x1 = s1 * pa[2 * i] + t1x, y1 = s1 * pa[2 * i + 1] + t1y;
-            const float x2 = s2 * pb[2 * i] + t2x, y2 = s2 * pb[2 * i + 1] + t2y;
-            const float wv = (w != nullptr) ? w[i] : 1.f;
-            float rx[9], ry[9];
-            build_rows(x1, y1, x2, y2, wv, rx, ry);
-            if (it > 0 && reweight != 0) {
-                float resx = -rx[8], resy = -ry[8];
+        f64x4 g4 = {0.0, 0.0, 0.0, 0.0};
+        for (int base = wave * 2; base < n; base += (HT / 64) * 2) {
+            const int i = base + (ek >> 1);
+            double val = 0.0;
+            if (i < n && ec < 9) {
+                const float x1 = s1 * pa[2 * i] + t1x, y1 = s1 * pa[2 * i + 1] + t1y;
+                const float x2 = s2 * pb[2 * i] + t2x, y2 = s2 * pb[2 * i + 1] + t2y;
+                const float wv = (w != nullptr) ? w[i] : 1.f;
+                float rx[9], ry[9];
+                build_rows(x1, y1, x2, y2, wv, rx, ry);
+                float q = 1.f;
+                if (it > 0 && reweight != 0) {
+                    float resx = -rx[8], resy = -ry[8];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    resx += rx[k] * sol[k];
-                    resy += ry[k] * sol[k];
+                    for (int k = 0; k < 8; ++k) {
+                        resx += rx[k] * sol[k];
+                        resy += ry[k] * sol[k];
+                    }
+                    q = sqrtf(reweight_fn((ek & 1) ? resy : resx, reweight, huber_k));
                 }
-                const float qx = sqrtf(reweight_fn(resx, reweight, huber_k));
-                const float qy = sqrtf(reweight_fn(resy, reweight, huber_k));
+                float e = 0.f;
 #pragma unroll
-                for (int k = 0; k < 9; ++k) {
-                    rx[k] *= qx;
-                    ry[k] *= qy;
-                }
+                for (int k = 0; k < 9; ++k)
+                    if (k == ec) e = (ek & 1) ? ry[k] : rx[k];
+                val = (double)(e * q);
             }
-            int idx = 0;
-#pragma unroll
-            for (int a = 0; a < 9; ++a)
-#pragma unroll
-                for (int b = a; b < 9; ++b) {
-                    g[idx] += (double)rx[a] * (double)rx[b] + (double)ry[a] * (double)ry[b];
-                    ++idx;
-                }
+            g4 = __builtin_amdgcn_mfma_f64_16x16x4f64(val, val, g4, 0, 0, 0);
         }
-        block_sum<NG>(g, red, tot);
+        // D layout of the f64 MFMA: column = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = ek + 4 * r;
+            if (row < 9 && ec < 9) red[wave * 81 + row * 9 + ec] = g4[r];
+        }
+        __syncthreads();
+        if (threadIdx.x < 81) {
+            double sacc = 0.0;
+            for (int wv = 0; wv < HT / 64; ++wv) sacc += red[wv * 81 + threadIdx.x];
+            gram[threadIdx.x] = sacc;
+        }
+        __syncthreads();
         if (threadIdx.x == 0) {
             // Cholesky of G[0:8,0:8] = L L^T, solve L L^T x = G[0:8,8]
             double L[8][8], rhs[8];
-            int idx = 0;
             double G[9][9];
             for (int a = 0; a < 9; ++a)
-                for (int b = a; b < 9; ++b) {
-                    G[a][b] = tot[idx];
-                    G[b][a] = tot[idx];
-                    ++idx;
-                }
+                for (int b = 0; b < 9; ++b) G[a][b] = gram[a * 9 + b];
             bool ok = true;
             for (int i = 0; i < 8 && ok; ++i) {
                 for (int j = 0; j <= i; ++j) {
