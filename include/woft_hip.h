@@ -181,6 +181,17 @@ int woft_warp_perspective_u8(const uint8_t* img, int32_t h, int32_t w, int32_t c
 int woft_resize_linear_u8(const uint8_t* img, int32_t h, int32_t w, int32_t c, uint8_t* out, int32_t ho, int32_t wo,
                           float scale_y, float scale_x, void* stream);
 
+/* Correspondence masking + order-preserving compaction + Sobol subsampling on the device
+ * (tracker/YAOF_tracker_single_control.py:287-327; configs/..._wLSq.py:31-53), outputs in woft_hfit's format.
+ * dst: [2][h*w] (x plane, y plane) target coords of source pixel i = y*w + x; w: [h*w] or NULL; tmask: uint8 [h][w];
+ * check_dst != 0 adds the bounds test on dst and, if pwmask != NULL, pwmask[rint(dy)][rint(dx)].
+ * sobol_u: [n_draw] float32 1-D Sobol points (n_draw <= 1024; 0 = keep all).  ws: woft_tc_select_ws_bytes(h*w) bytes.
+ * pa[k] = (dst_x, dst_y), pb[k] = (src_x, src_y), wout[k]; count[0] = selected (<= cap), count[1] = kept by the masks. */
+int64_t woft_tc_select_ws_bytes(int64_t n);
+int woft_tc_select(const float* dst, const float* w, const uint8_t* tmask, const uint8_t* pwmask, int32_t h,
+                   int32_t wimg, int32_t check_dst, const float* sobol_u, int32_t n_draw, void* ws,
+                   float* pa, float* pb, float* wout, int32_t cap, int32_t* count, void* stream);
+
 /* Weighted / iteratively re-weighted least-squares homography, utils/least_squares_H.py:142-210
  * (n_irls = 0) and :280-346 (n_irls = 5 -> 6 solves); reweight: 0 none, 1 L1 (:268-269),
  * 2 Huber(k) (:272-277).  pa, pb: [n][2] points (A -> B), w: [n] or NULL; n = min(count[0], n_max)

@@ -18,7 +18,7 @@ def lib():
 
 def test_header_symbols_exported(lib):
     header = (ROOT / "include" / "woft_hip.h").read_text()
-    declared = set(re.findall(r"^\s*int\s+(woft_\w+)\s*\(", header, flags=re.M))
+    declared = set(re.findall(r"^\s*(?:int|int64_t)\s+(woft_\w+)\s*\(", header, flags=re.M))
     assert len(declared) >= 18
     raw = ctypes.CDLL(str(ROOT / "woft_amd" / "lib" / "libwoft_hip.so"))
     for name in declared:

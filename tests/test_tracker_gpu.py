@@ -114,3 +114,69 @@ def test_tracker_downscaled_inputs():
         Hr, mr = ref.track(f)
         assert mg.lost == mr.lost
         assert _corners_err(Hg, Hr, H, W) < 1.0
+
+
+def test_fused_path_equals_generic_path(monkeypatch):
+    """The device-side selection / fit / inlier kernels (one host read per flow) must give exactly the
+    result of calling the config's callables as the reference tracker does."""
+    from pytracking.utils.config import load_config
+    from woft_amd import presets
+    H, W, iters, nframes = 136, 200, 3, 4
+    sd = synth.make_state_dict(seed=7)
+    template = synth.make_template(H, W, seq_id=8)
+    frames = [synth.make_frame(template, t) for t in range(1, nframes + 1)]
+    mask = synth.make_init_mask(H, W)
+
+    def run(fused, always_lost=False, cfg="WOFT.py"):
+        monkeypatch.setenv("WOFT_FUSED", "1" if fused else "0")
+        conf = load_config(ROOT / "pytracking" / "configs" / cfg)
+        conf.flow_config.model = sd
+        conf.flow_config.iters = iters
+        if always_lost:
+            conf.redet_success_fn = presets.redetection_by_inliers(1e-6, 0.999)
+        trk = conf.tracker_class(conf)
+        assert (trk._fused is not None) == fused
+        trk.init(template, mask)
+        return [trk.track(f) for f in frames]
+
+    for kw in (dict(), dict(always_lost=True), dict(cfg="WOFT_IRLS.py")):
+        a, b = run(True, **kw), run(False, **kw)
+        for (Ha, ma), (Hb, mb) in zip(a, b):
+            assert ma.lost == mb.lost and ma.N_lost == mb.N_lost and bool(ma.global_H_success) == bool(mb.global_H_success)
+            assert np.array_equal(Ha, Hb), np.abs(Ha - Hb).max()
+            assert np.array_equal(ma.H_global_cur2init, mb.H_global_cur2init)
+
+
+def test_tc_select_kernel_semantics(golden_dir):
+    """Sobol ranks / order / duplicates of the device-side selection against the reference's subsampler output."""
+    from woft_amd import ops, presets
+    g = np.load(golden_dir / "sobol.npz")
+    for (h, w) in ((20, 30), (25, 24), (50, 40), (720, 720)):
+        n = h * w
+        rs = np.random.RandomState(n)
+        tmask = (rs.uniform(size=(h, w)) < 0.97).astype(np.uint8) * 255
+        dst = torch.from_numpy(np.stack([rs.uniform(-3, w + 3, n), rs.uniform(-3, h + 3, n)]).astype(np.float32)).cuda()
+        wts = torch.from_numpy(rs.uniform(size=n).astype(np.float32)).cuda()
+        pw = (rs.uniform(size=(h, w)) < 0.9).astype(np.uint8)
+        u = torch.from_numpy(presets.sobol_points(500).astype(np.float32)).cuda()
+        pa, pb, wo = torch.zeros(1024, 2, device="cuda"), torch.zeros(1024, 2, device="cuda"), torch.zeros(1024, device="cuda")
+        cnt = torch.zeros(2, dtype=torch.int32, device="cuda")
+        ops.tc_select(dst, wts, torch.from_numpy(tmask).cuda(), torch.from_numpy(pw).cuda(), h, w, 1, u,
+                      ops.tc_select_ws(n), pa, pb, wo, cnt)
+        torch.cuda.synchronize()
+        d = dst.cpu().numpy()
+        idx = np.arange(n)
+        keep = (tmask.reshape(-1) > 0) & ~((d[0] < 0) | (d[1] < 0) | (np.rint(d[0]) >= w) | (np.rint(d[1]) >= h))
+        ri = np.clip(np.rint(d[1]).astype(np.int64), 0, h - 1) * w + np.clip(np.rint(d[0]).astype(np.int64), 0, w - 1)
+        keep &= pw.reshape(-1)[ri] > 0
+        kept = idx[keep]
+        N = len(kept)
+        sel = np.arange(N) if N <= 500 else np.unique(np.round(N * presets.sobol_points(500)).astype(np.int32))
+        if N == 518400:
+            assert np.array_equal(sel, g["n518400"])
+        chosen = kept[sel]
+        m, nk = int(cnt[0]), int(cnt[1])
+        assert nk == N and m == len(chosen)
+        assert np.array_equal(pb[:m].cpu().numpy(), np.stack([chosen % w, chosen // w], 1).astype(np.float32))
+        assert np.array_equal(pa[:m].cpu().numpy(), d[:, chosen].T)
+        assert np.array_equal(wo[:m].cpu().numpy(), wts.cpu().numpy()[chosen])

@@ -364,6 +364,18 @@ def resize_by_factor_u8(img, factor):
     return out
 
 
+def tc_select_ws(n):
+    return torch.empty(int(_lib.load().woft_tc_select_ws_bytes(n)), dtype=torch.uint8, device=DEV)
+
+
+def tc_select(dst, w, tmask_u8, pwmask_u8, h, wimg, check_dst, sobol_u, ws, pa, pb, wout, count):
+    """Mask + compact + Sobol-subsample correspondences on the device (see csrc/select.hip)."""
+    n_draw = 0 if sobol_u is None else sobol_u.numel()
+    check(_lib.load().woft_tc_select(ptr(dst), ptr(w), ptr(tmask_u8), ptr(pwmask_u8), h, wimg, int(check_dst),
+                                     ptr(sobol_u), n_draw, ptr(ws), ptr(pa), ptr(pb), ptr(wout), pa.shape[0],
+                                     ptr(count), stream_ptr()), "woft_tc_select")
+
+
 def hfit(pa, pb, w, Hout, status, count=None, reweight=0, huber_k=1.0, n_irls=0):
     n = pa.shape[0]
     check(_lib.load().woft_hfit(ptr(pa), ptr(pb), ptr(w), n, ptr(count), reweight, float(huber_k), n_irls,

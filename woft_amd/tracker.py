@@ -9,6 +9,7 @@ tensors are computed once (the flow provider pins the template image), and there
 device->host read per frame for the homography and one for the re-detection test.
 """
 import logging
+import os
 from inspect import signature
 from types import SimpleNamespace
 
@@ -34,6 +35,8 @@ def make_forward_compatible(subsampler_fn):
             if post_weights is not None:
                 raise NotImplementedError("Using post-hoc weights post-processing with a subsampler that takes only 3 arguments")
             return subsampler_fn(coords_a, coords_b, weights) + (None,)
+        if hasattr(subsampler_fn, "woft_spec"):
+            new_fn.woft_spec = subsampler_fn.woft_spec
         return new_fn
     return subsampler_fn
 
@@ -51,6 +54,61 @@ class YAOFTrackerSingleControl:
             self.C.subsampler_fn = make_forward_compatible(self.C.subsampler_fn)
         self.flower = config.flow_config.of_class(config.flow_config)
         self.device = "cuda"
+        self._fused = self._fused_specs()
+
+    # ---- fused device-side path --------------------------------------------------------------
+    def _fused_specs(self):
+        """When the config's estimator / subsampler / re-detection callables are the tagged ones of
+        woft_amd.presets, masking + Sobol selection + H fit + inlier test run as HIP kernels with ONE
+        device->host read per flow (results identical to calling the callables).  Any other config takes
+        the generic path that calls them as the reference tracker does."""
+        C = self.C
+        if os.environ.get("WOFT_FUSED", "1") == "0":
+            return None
+        est = getattr(C.H_estimator, "woft_spec", None)
+        red = getattr(C.redet_success_fn, "woft_spec", None)
+        sub = getattr(C.subsampler_fn, "woft_spec", None) if C.subsampler_fn else ("none", 0)
+        if est is None or red is None or sub is None or red[0] != "inliers":
+            return None
+        if C.post_hoc_weights_postprocessing_fn or C.flow_numpy_out:
+            return None
+        if not hasattr(self.flower, "pin_source") or self.flower.C.raft_type != "weighted":
+            return None
+        n_draw = int(sub[1]) if sub[0] == "sobol" else 0
+        if n_draw > 1024:
+            return None
+        from .presets import sobol_points
+        return dict(reweight=int(est[1]), huber_k=float(est[2]), n_irls=int(est[3]), thr=float(red[1]),
+                    min_frac=float(red[2]), n_draw=n_draw,
+                    sobol_u=torch.from_numpy(sobol_points(n_draw).astype(np.float32)).cuda() if n_draw else None)
+
+    def _fused_buffers(self, h, w):
+        key = (h, w)
+        if getattr(self, "_fb_key", None) != key:
+            cap = 1024 if self._fused["n_draw"] else h * w
+            self._fb = dict(ws=ops.tc_select_ws(h * w), pa=torch.empty(cap, 2, device=self.device),
+                            pb=torch.empty(cap, 2, device=self.device), w=torch.empty(cap, device=self.device),
+                            res=torch.zeros(16, dtype=torch.float32, device=self.device))
+            self._fb_key = key
+        return self._fb
+
+    def _fused_fit(self, dst, weights, tmask_u8, pwmask_u8, h, w, check_dst):
+        """-> (H 3x3 float64 mapping dst -> src, success flag, #kept, #selected)."""
+        F, b = self._fused, self._fused_buffers(h, w)
+        res = b["res"]
+        ires = res.view(torch.int32)
+        ops.tc_select(dst, weights, tmask_u8, pwmask_u8, h, w, check_dst, F["sobol_u"], b["ws"], b["pa"], b["pb"],
+                      b["w"], ires[12:14])
+        ops.hfit(b["pa"], b["pb"], b["w"], res[0:9], ires[10:11], count=ires[12:13], reweight=F["reweight"],
+                 huber_k=F["huber_k"], n_irls=F["n_irls"])
+        ops.inlier_frac(b["pa"], b["pb"], res[0:9], res[9:10], thr=F["thr"], count=ires[12:13])
+        host = res.cpu()                                             # the frame's single device->host read
+        ih = host.view(torch.int32)
+        status, n_sel, n_kept = int(ih[10]), int(ih[12]), int(ih[13])
+        if status == 1:
+            raise AssertionError(torch.Size([1, n_sel, 2]))          # least_squares_H.py:162 (fewer than 4 points)
+        Hm = host[0:9].numpy().astype(np.float64).reshape(3, 3)
+        return Hm, bool(float(host[9]) > F["min_frac"]), n_kept, n_sel
 
     def init(self, img, mask, img_identifier=None):
         if self.C.downscale_inputs:                                  # TRK:27-30
@@ -105,6 +163,7 @@ class YAOFTrackerSingleControl:
         prewarp_H = self.last_good_H2init
         frame = _to_gpu_u8(input_img)
         Hh, Ww = frame.shape[:2]
+        valid = None
         if np.array_equal(prewarp_H, np.eye(3)):
             prewarped, pw_mask = frame, None                         # identity warp: same image, mask all-true
         else:
@@ -114,6 +173,10 @@ class YAOFTrackerSingleControl:
             pw_mask = valid > 0
         template_coords, cur_pw_coords, weights = self.flower.compute_flow(
             self.template_img, prewarped, mode="TC", vis=False, do_sigmoid=True)
+        if self._fused is not None:
+            return self._track_fused(meta, frame, prewarp_H, cur_pw_coords, weights,
+                                     None if pw_mask is None or self.C.do_not_mask_TCs_by_prewarped else valid,
+                                     img_identifier)
         post_hoc_weights = None
         if self.C.post_hoc_weights_postprocessing_fn:
             post_hoc_weights = self.flower.postprocess_weights(weights.clone(), self.C.post_hoc_weights_postprocessing_fn)
@@ -180,6 +243,52 @@ class YAOFTrackerSingleControl:
         meta.N_lost = self.N_lost
         meta.global_H_success = global_H_success
         if self.C.downscale_inputs:                                  # TRK:280-283
+            k = self.C.downscale_inputs
+            H_cur2init = compose_H(np.diag([1.0 / k, 1.0 / k, 1.0]), H_cur2init, np.diag([float(k), float(k), 1.0]))
+        return H_cur2init, meta
+
+    def _track_fused(self, meta, frame, prewarp_H, cur_pw_coords, weights, pw_valid_u8, img_identifier):
+        """TRK:134-278 with masking / selection / fit / inlier test on the device."""
+        Hh, Ww = frame.shape[:2]
+        Hpw, success, _, _ = self._fused_fit(cur_pw_coords, weights, self._template_mask_u8, pw_valid_u8, Hh, Ww, 1)
+        H_global_cur2init = compose_H(prewarp_H, Hpw)
+        meta.H_global_cur2init = H_global_cur2init.copy()
+        if success:
+            H_cur2init = H_global_cur2init
+            self.lost, self.N_lost = False, 0
+        else:
+            self.lost = True
+            self.N_lost += 1
+            if self.C.no_local_H:
+                H_cur2init = H_global_cur2init
+            else:
+                _, cur_coords, weights = self.flower.compute_flow(self.prev_img, frame, mode="TC",
+                                                                  src_img_identifier=None, do_sigmoid=True)
+                if np.array_equal(self.prev_H2init, np.eye(3)):
+                    prev_mask_u8 = self._template_mask_u8
+                else:
+                    prev_mask_u8 = torch.empty_like(self._template_mask_u8)
+                    ops.warp_perspective_u8(self._template_mask_u8, np.linalg.inv(self.prev_H2init), prev_mask_u8,
+                                            None, nearest=True)
+                try:
+                    H_flow, _, _, _ = self._fused_fit(cur_coords, weights, prev_mask_u8, None, Hh, Ww, 0)
+                    if not np.all(np.isfinite(H_flow)):
+                        raise FloatingPointError("singular homography system")
+                    H_local_cur2init = compose_H(H_flow, self.prev_H2init)
+                except Exception:
+                    logger.warning("local flow RANSAC failed")
+                    H_local_cur2init = self.prev_H2init
+                meta.H_local_cur2init = H_local_cur2init.copy()
+                H_cur2init = H_local_cur2init
+        self.prev_img_identifier = img_identifier
+        self.prev_img = frame
+        self.prev_H2init = H_cur2init.copy()
+        if not self.lost:
+            self.last_good_H2init = H_cur2init.copy()
+        meta.lost = self.lost
+        meta.N_lost = self.N_lost
+        meta.global_H_success = success
+        if self.C.downscale_inputs:
             k = self.C.downscale_inputs
             H_cur2init = compose_H(np.diag([1.0 / k, 1.0 / k, 1.0]), H_cur2init, np.diag([float(k), float(k), 1.0]))
         return H_cur2init, meta
