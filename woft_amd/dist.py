@@ -16,15 +16,19 @@ def init_distributed(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # WOFT_SINGLE_DEVICE=1 (testing the N>1 code path on a 1-GPU box): every rank uses device 0, gloo collectives
+    single = os.environ.get("WOFT_SINGLE_DEVICE") == "1"
+    dev = 0 if single else local
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
-        if backend == "nccl":
-            torch.cuda.set_device(local)
+        backend = backend or os.environ.get("WOFT_DIST_BACKEND") or \
+            ("gloo" if single or not torch.cuda.is_available() else "nccl")
+        if torch.cuda.is_available():
+            torch.cuda.set_device(dev)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     elif torch.cuda.is_available():
-        torch.cuda.set_device(local)
+        torch.cuda.set_device(dev)
     return rank, world, local
 
 
