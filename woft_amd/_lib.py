@@ -89,6 +89,8 @@ def load():
         raise WoftHipError("ctypes mirror of woft_conv_params / woft_lookup_params is out of sync with the library")
     if os.environ.get("WOFT_CONV_DEEP"):
         lib.woft_set_tuning(0, int(os.environ["WOFT_CONV_DEEP"]))
+    if os.environ.get("WOFT_CONV_DMA"):
+        lib.woft_set_tuning(1, int(os.environ["WOFT_CONV_DMA"]))
     _lib = lib
     return lib
 

@@ -32,6 +32,11 @@ namespace {
 using woft::ARows;
 using woft::BK;
 
+// developer tuning knobs (A/B experiments only; set once at start-up, never from the hot path):
+//   [0] gather kernel: 0 = single-stage mainloop (default), 1 = two-stage / two-step-ahead mainloop
+//   [1] halo kernel:   0 = weight tile through registers, 1 = weight tile by LDS-DMA (global_load_lds; default)
+int g_tuning[4] = {0, 1, 0, 0};
+
 constexpr int LDS_LD = 36;   // fp32 tiles: floats per row (144 B: 16-B aligned, conflict-free b128 reads)
 
 template <int BM, int BN>
@@ -292,7 +297,7 @@ struct HaloRowMap {
     }
 };
 
-template <int TY, int TX, int G, int BN, int TERMS, int NWAVES, int WM>
+template <int TY, int TX, int G, int BN, int TERMS, int NWAVES, int WM, bool DMA>
 __global__ __launch_bounds__(NWAVES * 64) void conv_halo_bf16_kernel(const woft_conv_params p) {
     constexpr int NT = NWAVES * 64;
     constexpr int NPIX = TY * TX;
@@ -310,9 +315,15 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_halo_bf16_kernel(const woft_
     constexpr int RH = (HTOT + LROWS - 1) / LROWS;       // halo float4 rows per thread
     constexpr int BROWS = NT / 4;                        // weight rows covered per loader pass
     constexpr int RB = (BN + BROWS - 1) / BROWS;
-    constexpr int A_ELEMS = NP * HTOT * LDB, B_ELEMS = NP * BN * LDB;
+    // DMA variant: the weight tile is copied global -> LDS by global_load_lds (no staging registers, no
+    // ds_write pass) into one of TWO stages of unpadded 64-byte rows whose four 16-byte chunks are XOR
+    // swizzled with (row >> 2) & 3 on the SOURCE side (the DMA image is lane-linear), which keeps the
+    // ds_read_b128 fragment reads conflict free; a K step then needs a single block barrier.
+    constexpr int LDBB = DMA ? 32 : LDB;                 // B row pitch in elements
+    constexpr int A_ELEMS = NP * HTOT * LDB, B_ELEMS = NP * BN * LDBB;
+    constexpr int NBST = DMA ? 2 : 1;
     constexpr int STAGE_ELEMS = 2 * NWAVES * woft::STAGE_FLOATS;
-    constexpr int SMEM_ELEMS = (A_ELEMS + B_ELEMS > STAGE_ELEMS) ? A_ELEMS + B_ELEMS : STAGE_ELEMS;
+    constexpr int SMEM_ELEMS = (A_ELEMS + NBST * B_ELEMS > STAGE_ELEMS) ? A_ELEMS + NBST * B_ELEMS : STAGE_ELEMS;
     __shared__ __attribute__((aligned(16))) __bf16 smem[SMEM_ELEMS];
     __bf16* As = smem;
     __bf16* Bs = smem + A_ELEMS;
@@ -401,6 +412,26 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_halo_bf16_kernel(const woft_
                 if (rb0 + BROWS * j < BN) *(bf16x8*)(Bs + pl * BN * LDB + (rb0 + BROWS * j) * LDB + 8 * vb) = rb[pl][j];
     };
 
+    // DMA: one wave instruction moves 16 rows x 64 B (1 KiB); lane L -> (row L/4, physical chunk L%4)
+    constexpr int DMA_PER_PLANE = BN / 16, DMA_TOTAL = NP * DMA_PER_PLANE;
+    auto dma_b = [&](int ks, int stage) {
+        const int chunk = ks / taps, tap = ks - chunk * taps;
+        const int64_t koff = (int64_t)tap * p.cin_pad + chunk * BK;
+#pragma unroll
+        for (int t = 0; t < (DMA_TOTAL + NWAVES - 1) / NWAVES; ++t) {
+            const int q = wave + t * NWAVES;               // wave-uniform instruction index
+            if (q < DMA_TOTAL) {
+                const int pl = q / DMA_PER_PLANE, cb = q - pl * DMA_PER_PLANE;
+                const int row = cb * 16 + (lane >> 2);
+                const int c = (lane & 3) ^ ((row >> 2) & 3);
+                const __bf16* src = bsrc[pl] + (int64_t)(n0 + row) * ktot + koff + c * 8;
+                __bf16* dstl = Bs + stage * B_ELEMS + pl * BN * LDBB + cb * 16 * LDBB;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)dstl, 16, 0, 0);
+            }
+        }
+    };
+
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -418,6 +449,58 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_halo_bf16_kernel(const woft_
         abase[i] = g * HROWS + ((pl < NPIX) ? (pl / TX) * HX + (pl % TX) : 0);
     }
     const __bf16* b_frag = Bs + (wn * WCOLS + r32) * LDB + hh * 8;
+
+    if (DMA) {
+        // physical 16-byte chunk of logical chunk (s*2 + hh) in this lane's B rows (rows = 32*j + r32 + const)
+        const int sw = (r32 >> 2) & 3;
+        const __bf16* bfr = Bs + (wn * WCOLS + r32) * LDBB;
+        load_halo(0);
+        dma_b(0, 0);
+        store_halo();
+        __syncthreads();
+        for (int ks = 0; ks < nk; ++ks) {
+            const int chunk = ks / taps, tap = ks - chunk * taps;
+            const bool nxt = ks + 1 < nk;
+            const bool new_chunk = nxt && (tap + 1 == taps);
+            if (nxt) dma_b(ks + 1, (ks + 1) & 1);          // lands while this step computes
+            if (new_chunk) load_halo(chunk + 1);
+            const int ky = tap / p.taps_x, kx = tap - ky * p.taps_x;
+            const int toff = (ky * HX + kx) * LDB + hh * 8;
+            const __bf16* bst = bfr + (ks & 1) * B_ELEMS;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int pc = ((s * 2 + hh) ^ sw) * 8;
+                bf16x8 b[NP][TN];
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) b[pl][j] = *(const bf16x8*)(bst + pl * BN * LDBB + j * 32 * LDBB + pc);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    bf16x8 a[NP];
+#pragma unroll
+                    for (int pl = 0; pl < NP; ++pl) a[pl] = *(const bf16x8*)(As + pl * HTOT * LDB + abase[i] * LDB + toff + s * 16);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        if (NP == 2) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[NP - 1], b[0][j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[NP - 1][j], acc[i][j], 0, 0, 0);
+                        }
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0][j], acc[i][j], 0, 0, 0);
+                    }
+                }
+            }
+            __syncthreads();                             // (drains the DMA: the next stage is complete)
+            if (new_chunk) {
+                store_halo();
+                __syncthreads();
+            }
+        }
+        const HaloRowMap<TY, TX, G> rowmap_d{img0, p.n_img, y0, x0, p.ho, p.wo};
+        woft::conv_epilogue_t<TM, TN, WROWS, WCOLS>(p, acc, (float*)smem + wave * woft::STAGE_FLOATS, rowmap_d, n0, wm,
+                                                    wn, lane, m_tile);
+        return;
+    }
 
     load_halo(0);
     load_b(0);
@@ -471,10 +554,15 @@ int launch_halo(const woft_conv_params& p, hipStream_t s) {
     const int tyn = (p.ho + TY - 1) / TY, txn = (p.wo + TX - 1) / TX;
     const int64_t mt = (int64_t)((p.n_img + G - 1) / G) * tyn * txn;
     dim3 grid((unsigned)(mt * (p.cout_pad / BN)));
-    if (p.precision == 1)
-        hipLaunchKernelGGL((conv_halo_bf16_kernel<TY, TX, G, BN, 3, NWAVES, WM>), grid, dim3(NWAVES * 64), 0, s, p);
+    const bool dma = g_tuning[1] != 0;
+    if (p.precision == 1 && dma)
+        hipLaunchKernelGGL((conv_halo_bf16_kernel<TY, TX, G, BN, 3, NWAVES, WM, true>), grid, dim3(NWAVES * 64), 0, s, p);
+    else if (p.precision == 1)
+        hipLaunchKernelGGL((conv_halo_bf16_kernel<TY, TX, G, BN, 3, NWAVES, WM, false>), grid, dim3(NWAVES * 64), 0, s, p);
+    else if (dma)
+        hipLaunchKernelGGL((conv_halo_bf16_kernel<TY, TX, G, BN, 1, NWAVES, WM, true>), grid, dim3(NWAVES * 64), 0, s, p);
     else
-        hipLaunchKernelGGL((conv_halo_bf16_kernel<TY, TX, G, BN, 1, NWAVES, WM>), grid, dim3(NWAVES * 64), 0, s, p);
+        hipLaunchKernelGGL((conv_halo_bf16_kernel<TY, TX, G, BN, 1, NWAVES, WM, false>), grid, dim3(NWAVES * 64), 0, s, p);
     return woft_launch_status();
 }
 
@@ -488,10 +576,6 @@ __global__ void split_bf16_kernel(const float* __restrict__ x, int64_t n4, __bf1
     *(bf16x4*)(hi + i * 4) = h;
     if (lo != nullptr) *(bf16x4*)(lo + i * 4) = __builtin_convertvector(vv - __builtin_convertvector(h, f32x4), bf16x4);
 }
-
-// developer tuning knobs (A/B experiments only; set once at start-up, never from the hot path):
-//   [0] 0 = single-stage mainloop (default), 1 = two-stage / two-step-ahead mainloop
-int g_tuning[4] = {0, 0, 0, 0};
 
 template <int BM, int BN>
 int launch_conv(const woft_conv_params& p, hipStream_t s) {
