@@ -33,7 +33,7 @@ using woft::ARows;
 using woft::BK;
 
 // developer tuning knobs (A/B experiments only; set once at start-up, never from the hot path):
-//   [0] gather kernel: 0 = single-stage mainloop (default), 1 = two-stage / two-step-ahead mainloop
+//   [0] gather kernel: 0 = register-staged operands, one LDS stage; 1 = B by LDS-DMA, two stages, one barrier per step
 //   [1] halo kernel:   0 = weight tile through registers, 1 = weight tile by LDS-DMA (global_load_lds; default)
 int g_tuning[4] = {0, 1, 0, 0};
 
@@ -137,14 +137,22 @@ constexpr int LDB = 40;      // bf16 tiles: elements per row (80 B: 16-B aligned
 
 template <int BM, int BN, int TERMS, bool DEEP>
 __global__ __launch_bounds__(256) void conv_mfma_bf16_kernel(const woft_conv_params p) {
+    // DEEP = false: register-staged operands, one LDS stage, two barriers per K step.
+    // DEEP = true : B (pre-split bf16) is copied global -> LDS by global_load_lds into two stages of unpadded,
+    //               source-swizzled 64-byte rows; A (fp32 -> hi/lo) goes through registers into two stages;
+    //               one barrier per K step, no staging registers for B.
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int RA = BM / 32;            // float4 rows per thread (A, fp32 source)
-    constexpr int RB = BN / 64;            // 16-B rows per thread and plane (B, pre-split bf16)
+    constexpr int RB = BN / 64;            // 16-B rows per thread and plane (B, pre-split bf16; register path)
     constexpr int NP = (TERMS == 3) ? 2 : 1;
-    constexpr int BUF = (BM + BN) * LDB * NP;          // one LDS stage: A planes then B planes
-    constexpr int NBUF = DEEP ? 2 : 1;
-    constexpr int SMEM_ELEMS = (NBUF * BUF > 8 * woft::STAGE_FLOATS) ? NBUF * BUF : 8 * woft::STAGE_FLOATS;
+    constexpr int LDBB = DEEP ? 32 : LDB;
+    constexpr int A_ELEMS = NP * BM * LDB, B_ELEMS = NP * BN * LDBB;
+    constexpr int NST = DEEP ? 2 : 1;
+    constexpr int SMEM_ELEMS = (NST * (A_ELEMS + B_ELEMS) > 8 * woft::STAGE_FLOATS) ? NST * (A_ELEMS + B_ELEMS)
+                                                                                     : 8 * woft::STAGE_FLOATS;
     __shared__ __attribute__((aligned(16))) __bf16 smem[SMEM_ELEMS];
+    __bf16* Asm = smem;                                // [NST][NP][BM][LDB]
+    __bf16* Bsm = smem + NST * A_ELEMS;                // [NST][NP][BN][LDBB]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -168,21 +176,11 @@ __global__ __launch_bounds__(256) void conv_mfma_bf16_kernel(const woft_conv_par
     bsrc[0] = (const __bf16*)p.wgt_hi;
     if (NP == 2) bsrc[NP - 1] = (const __bf16*)p.wgt_lo;
 
-    // Two register sets: tiles are fetched TWO K steps ahead (the operands mostly come from beyond
-    // the XCD's L2), two LDS stages: one block barrier per K step.
-    f32x4 raA[RA], raB[RA];
-    bf16x8 rbA[NP][RB], rbB[NP][RB];
-    auto load_tiles = [&](int ks, f32x4 (&ra)[RA], bf16x8 (&rb)[NP][RB]) {
-        woft::a_load<RA>(p, arows, ks, nchunk, v, ra);
-#pragma unroll
-        for (int pl = 0; pl < NP; ++pl)
-#pragma unroll
-            for (int j = 0; j < RB; ++j)
-                rb[pl][j] = *(const bf16x8*)(bsrc[pl] + (int64_t)(n0 + rb0 + 64 * j) * ktot + (int64_t)ks * BK + 8 * vb);
-    };
-    auto store_tiles = [&](int buf, const f32x4 (&ra)[RA], const bf16x8 (&rb)[NP][RB]) {
-        __bf16* As = smem + buf * BUF;
-        __bf16* Bs = As + NP * BM * LDB;
+    f32x4 ra[RA];
+    bf16x8 rb[NP][RB];
+    auto load_a = [&](int ks) { woft::a_load<RA>(p, arows, ks, nchunk, v, ra); };
+    auto store_a = [&](int stage) {
+        __bf16* As = Asm + stage * A_ELEMS;
 #pragma unroll
         for (int j = 0; j < RA; ++j) {
             const bf16x4 hi = __builtin_convertvector(ra[j], bf16x4);
@@ -192,10 +190,37 @@ __global__ __launch_bounds__(256) void conv_mfma_bf16_kernel(const woft_conv_par
                 *(bf16x4*)(As + BM * LDB + (r0 + 32 * j) * LDB + 4 * v) = __builtin_convertvector(rem, bf16x4);
             }
         }
+    };
+    auto load_b = [&](int ks) {
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
-            for (int j = 0; j < RB; ++j) *(bf16x8*)(Bs + pl * BN * LDB + (rb0 + 64 * j) * LDB + 8 * vb) = rb[pl][j];
+            for (int j = 0; j < RB; ++j)
+                rb[pl][j] = *(const bf16x8*)(bsrc[pl] + (int64_t)(n0 + rb0 + 64 * j) * ktot + (int64_t)ks * BK + 8 * vb);
+    };
+    auto store_b = [&]() {
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+            for (int j = 0; j < RB; ++j) *(bf16x8*)(Bsm + pl * BN * LDB + (rb0 + 64 * j) * LDB + 8 * vb) = rb[pl][j];
+    };
+    // LDS-DMA of the B tile: one wave instruction = 16 rows x 64 B; lane L -> (row L/4, physical chunk L%4),
+    // logical chunk = physical ^ ((row >> 2) & 3)  (swizzle applied on the source side)
+    constexpr int DMA_PER_PLANE = BN / 16, DMA_TOTAL = NP * DMA_PER_PLANE;
+    auto dma_b = [&](int ks, int stage) {
+#pragma unroll
+        for (int t = 0; t < (DMA_TOTAL + 3) / 4; ++t) {
+            const int q = wave + t * 4;
+            if (q < DMA_TOTAL) {
+                const int pl = q / DMA_PER_PLANE, cb = q - pl * DMA_PER_PLANE;
+                const int row = cb * 16 + (lane >> 2);
+                const int c = (lane & 3) ^ ((row >> 2) & 3);
+                const __bf16* src = bsrc[pl] + (int64_t)(n0 + row) * ktot + (int64_t)ks * BK + c * 8;
+                __bf16* dstl = Bsm + stage * B_ELEMS + pl * BN * LDBB + cb * 16 * LDBB;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)dstl, 16, 0, 0);
+            }
+        }
     };
 
     f32x16 acc[TM][TN];
@@ -208,19 +233,20 @@ __global__ __launch_bounds__(256) void conv_mfma_bf16_kernel(const woft_conv_par
 
     // lane (r32, hh) feeds k = s*16 + hh*8 + [0,8) of the step for both operands
     const int a_off = (wm * (BM / 2) + r32) * LDB + hh * 8;
-    const int b_off = NP * BM * LDB + (wn * (BN / 2) + r32) * LDB + hh * 8;
-    auto compute = [&](int buf) {
-        const __bf16* a_frag = smem + buf * BUF + a_off;
-        const __bf16* b_frag = smem + buf * BUF + b_off;
+    const int sw = (r32 >> 2) & 3;
+    auto compute = [&](int stage) {
+        const __bf16* a_frag = Asm + stage * A_ELEMS + a_off;
+        const __bf16* b_rows = Bsm + stage * B_ELEMS + (wn * (BN / 2) + r32) * LDBB;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
+            const int bcol = DEEP ? (((s * 2 + hh) ^ sw) * 8) : (hh * 8 + s * 16);
             bf16x8 a[NP][TM], b[NP][TN];
 #pragma unroll
             for (int pl = 0; pl < NP; ++pl) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i) a[pl][i] = *(const bf16x8*)(a_frag + pl * BM * LDB + i * 32 * LDB + s * 16);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) b[pl][j] = *(const bf16x8*)(b_frag + pl * BN * LDB + j * 32 * LDB + s * 16);
+                for (int j = 0; j < TN; ++j) b[pl][j] = *(const bf16x8*)(b_rows + pl * BN * LDBB + j * 32 * LDBB + bcol);
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -236,40 +262,36 @@ __global__ __launch_bounds__(256) void conv_mfma_bf16_kernel(const woft_conv_par
     };
 
     if (!DEEP) {
-        // one LDS stage, tiles fetched one K step ahead, two barriers per step; lowest register and LDS
-        // footprint -> most resident waves
-        load_tiles(0, raA, rbA);
-        store_tiles(0, raA, rbA);
+        load_a(0);
+        load_b(0);
+        store_a(0);
+        store_b();
         __syncthreads();
         for (int ks = 0; ks < nk; ++ks) {
-            if (ks + 1 < nk) load_tiles(ks + 1, raA, rbA);
+            if (ks + 1 < nk) { load_a(ks + 1); load_b(ks + 1); }
             compute(0);
             __syncthreads();
             if (ks + 1 < nk) {
-                store_tiles(0, raA, rbA);
+                store_a(0);
+                store_b();
                 __syncthreads();
             }
         }
-        woft::conv_epilogue<BM, BN>(p, acc, (float*)smem + wave * woft::STAGE_FLOATS, m0, n0, wm, wn, lane, M, m_tile);
-        return;
-    }
-    load_tiles(0, raA, rbA);
-    if (nk > 1) load_tiles(1, raB, rbB);
-    store_tiles(0, raA, rbA);
-    if (nk > 2) load_tiles(2, raA, rbA);
-    __syncthreads();
-    for (int ks = 0; ks < nk; ks += 2) {
-        // even step: stage 0 holds tile ks; set B holds tile ks+1, set A tile ks+2
-        if (ks + 1 < nk) store_tiles(1, raB, rbB);
-        if (ks + 3 < nk) load_tiles(ks + 3, raB, rbB);
-        compute(0);
+    } else {
+        load_a(0);
+        dma_b(0, 0);
+        store_a(0);
         __syncthreads();
-        if (ks + 1 >= nk) break;
-        // odd step: stage 1 holds tile ks+1; set A holds tile ks+2, set B tile ks+3
-        if (ks + 2 < nk) store_tiles(0, raA, rbA);
-        if (ks + 4 < nk) load_tiles(ks + 4, raA, rbA);
-        compute(1);
-        __syncthreads();
+        for (int ks = 0; ks < nk; ++ks) {
+            const bool nxt = ks + 1 < nk;
+            if (nxt) {
+                dma_b(ks + 1, (ks + 1) & 1);         // lands in the idle stage while this step computes
+                load_a(ks + 1);
+            }
+            compute(ks & 1);
+            if (nxt) store_a((ks + 1) & 1);          // idle A stage: last read in step ks-1, a barrier ago
+            __syncthreads();                         // (drains the DMA)
+        }
     }
     // every path leaves the loop through a block barrier: the operand stages are dead, reuse them
     woft::conv_epilogue<BM, BN>(p, acc, (float*)smem + wave * woft::STAGE_FLOATS, m0, n0, wm, wn, lane, M, m_tile);
