@@ -192,9 +192,15 @@ def gen_wrapper():
         fc.padding_mode = "RAFT"
         a2, b2 = a[:125, :157].copy(), b[:125, :157].copy()
         src2, dst2, w2 = flower.compute_flow(a2, b2, mode="TC", do_sigmoid=True)
+        # ('Michal' mode cannot be pinned: the reference's MichalPadder.unpad(None) raises AttributeError for
+        #  raft_type 'orig' / 'weighted' (raft.py:148-150,264-265) -- it is unreachable in every shipped config)
+        fc.padding_mode = "crop"            # crop to a multiple of 8 from the right/bottom (raft.py:235-247)
+        a4, b4 = a[:, :157].copy(), b[:, :157].copy()
+        src4, dst4, w4 = flower.compute_flow(a4, b4, mode="TC", do_sigmoid=True)
     np.savez_compressed(GOLD / "wrapper_tc_128x160_it4.npz", img1=a, img2=b, seed=7, iters=4,
                         src=src.numpy(), dst=dst.numpy(), w=w.numpy(), flow=fl.numpy(), w_logit=wf.numpy(),
-                        src_pad=src2.numpy(), dst_pad=dst2.numpy(), w_pad=w2.numpy())
+                        src_pad=src2.numpy(), dst_pad=dst2.numpy(), w_pad=w2.numpy(),
+                        src_crop=src4.numpy(), dst_crop=dst4.numpy(), w_crop=w4.numpy())
 
 
 @torch.no_grad()
@@ -263,9 +269,13 @@ def main():
     GOLD.mkdir(parents=True, exist_ok=True)
     install_stubs()
     torch.manual_seed(0)
-    gen_flow()
-    gen_wrapper()
-    gen_hfit()
+    only = os.environ.get("GOLDEN_ONLY")
+    if only in (None, "flow"):
+        gen_flow()
+    if only in (None, "wrapper"):
+        gen_wrapper()
+    if only in (None, "hfit"):
+        gen_hfit()
     for p in sorted(GOLD.iterdir()):
         print(f"{p.name:40s} {p.stat().st_size/1024:9.1f} KB")
 

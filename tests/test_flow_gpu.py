@@ -150,6 +150,16 @@ def test_operator_tc_boundary(golden_dir):
     assert np.array_equal(s2.cpu().numpy(), g["src_pad"])
     assert np.abs(d2.cpu().numpy() - g["dst_pad"]).max() < 1e-2
     assert np.abs(w2.cpu().numpy() - g["w_pad"]).max() < 1e-4
+    fc3 = _flow_config(sd, int(g["iters"]), padding_mode="crop")
+    fl3 = fc3.of_class(fc3)
+    s4, d4, w4 = fl3.compute_flow(g["img1"][:, :157].copy(), g["img2"][:, :157].copy(), mode="TC", do_sigmoid=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(s4.cpu().numpy(), g["src_crop"])
+    assert np.abs(d4.cpu().numpy() - g["dst_crop"]).max() < 1e-2
+    assert np.abs(w4.cpu().numpy() - g["w_crop"]).max() < 1e-4
+    with pytest.raises(NotImplementedError):
+        fc4 = _flow_config(sd, 2, padding_mode="Michal")
+        fc4.of_class(fc4).compute_flow(g["img1"], g["img2"], mode="TC")
 
 
 @torch.no_grad()

@@ -108,6 +108,11 @@ def test_wrapper_boundary(golden_dir):
     assert np.array_equal(s2.numpy(), g["src_pad"])
     assert np.abs(d2.numpy() - g["dst_pad"]).max() < 1e-3
     assert np.abs(w2.numpy() - g["w_pad"]).max() < 1e-5
+    a4, b4 = g["img1"][:, :157].copy(), g["img2"][:, :157].copy()       # 'crop': outputs keep the cropped 128x152
+    s4, d4, w4 = raft_ref.compute_flow(sd, a4, b4, int(g["iters"]), mode="TC", do_sigmoid=True, padding_mode="crop")
+    assert np.array_equal(s4.numpy(), g["src_crop"]) and tuple(s4.shape) == (2, 128 * 152)
+    assert np.abs(d4.numpy() - g["dst_crop"]).max() < 1e-3
+    assert np.abs(w4.numpy() - g["w_crop"]).max() < 1e-5
 
 
 def _corner_err(Ha, Hb):

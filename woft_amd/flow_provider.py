@@ -30,7 +30,10 @@ def _pad_geometry(h, w, mode):
         pw = (((w // 8) + 1) * 8 - w) % 8
         return h + ph, w + pw, ph // 2, pw // 2, h, w, h, w
     if mode == "Michal":
-        raise NotImplementedError("padding_mode 'Michal' (bilinear rescale, raft.py:250-271) is not on the HIP path")
+        # the reference's MichalPadder.unpad(None) raises AttributeError for raft_type 'orig' / 'weighted'
+        # (raft.py:148-150,264-265): the mode is unreachable in every shipped configuration
+        raise NotImplementedError("padding_mode 'Michal' (raft.py:250-271) fails in the reference itself for "
+                                  "raft_type 'orig'/'weighted'; it is not provided on the HIP path")
     raise ValueError(f"invalid padding_mode '{mode}'")
 
 
