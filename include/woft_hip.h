@@ -94,6 +94,15 @@ int woft_conv2d(const woft_conv_params* p, void* stream);
 /* fp32 array (n % 4 == 0) -> bf16 planes hi = bf16(x), lo = bf16(x - hi) (lo may be NULL): the
  * split form of a dynamic B operand (fmap2 in the correlation GEMM). */
 int woft_split_bf16(const float* x, int64_t n, void* hi, void* lo, void* stream);
+/* x (n floats, n % 32 == 0) -> n/32 lines of 128 bytes, line = [bf16 hi of 32 values | bf16 lo of the same 32],
+ * hi = bf16(x), lo = bf16(x - hi): the operand format of woft_corr_gemm_bf16 with terms = 3. */
+int woft_split_bf16_lines(const float* x, int64_t n, void* out, void* stream);
+/* All-pairs correlation (corr.py:62-69) on pre-split operands: out[i][j] = alpha * <A[i], B[j]>, i < m, j < n.
+ * terms = 3 (hi*hi + hi*lo + lo*hi, fp32-emulating): a / b = woft_split_bf16_lines of fmap1 [rows_a][k] /
+ * of woft_tile_rows(fmap2) [rows_b][k]; terms = 1: a / b = their plain bf16 planes (woft_split_bf16 hi), k % 64 == 0.
+ * rows_a, rows_b: allocated rows, multiples of 128 (rows beyond m / n are read, their products never stored). */
+int woft_corr_gemm_bf16(const void* a, const void* b, int64_t m, int64_t n, int64_t rows_a, int64_t rows_b, int32_t k,
+                        float alpha, float* out, int64_t ldo, int32_t terms, void* stream);
 
 /* InstanceNorm (extractor.py:28-32,129-130; nn.InstanceNorm2d eps=1e-5, biased variance):
  * finalize per-channel statistics from the conv epilogue's partial sums ... */

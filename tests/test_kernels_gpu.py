@@ -231,7 +231,7 @@ def test_preprocess_and_pool(ops):
 # ------------------------------------------------------------------------------------------
 # correlation volume + lookup
 # ------------------------------------------------------------------------------------------
-def _build_pyramid_gpu(ops, f1, f2, precision="fp32"):
+def _build_pyramid_gpu(ops, f1, f2, precision="fp32", presplit=False):
     """f1, f2: (1, C, H, W) cpu tensors -> tiled volumes [P][ht*wt*16] on the GPU via tile_rows + conv/GEMM."""
     _, c, h, w = f1.shape
     a1, a2 = ops.act_from_nchw(f1), ops.act_from_nchw(f2)
@@ -246,7 +246,23 @@ def _build_pyramid_gpu(ops, f1, f2, precision="fp32"):
         hi, lo = torch.zeros_like(rows, dtype=torch.bfloat16), torch.zeros_like(rows, dtype=torch.bfloat16)
         if precision != "fp32":
             ops.split_bf16(rows, hi, lo)
-        ops.run_conv(ops.corr_volume(a1, rows, n, vol, 1.0 / math.sqrt(c), precision=precision, f2_hi=hi, f2_lo=lo))
+        if presplit:            # the engine's path: both operands pre-split, woft_corr_gemm_bf16
+            arows = torch.zeros(ops._round_up(h * w, 128), c, device="cuda")
+            arows[:h * w] = a1.t
+            if precision == "bf16x3":
+                sa = torch.zeros(arows.shape[0], 2 * c, dtype=torch.bfloat16, device="cuda")
+                sb = torch.zeros(rows.shape[0], 2 * c, dtype=torch.bfloat16, device="cuda")
+                ops.split_bf16_lines(arows, sa)
+                ops.split_bf16_lines(rows, sb)
+                # line format: per 32 values [32 hi | 32 lo]
+                assert torch.equal(sb.view(-1, 2, 32)[:, 0].reshape(-1, c), hi)
+                assert torch.equal(sb.view(-1, 2, 32)[:, 1].reshape(-1, c), lo)
+            else:
+                sa, sb = torch.zeros_like(arows, dtype=torch.bfloat16), hi
+                ops.split_bf16(arows, sa, None)
+            ops.corr_gemm_bf16(sa, sb, h * w, n, 1.0 / math.sqrt(c), vol, 3 if precision == "bf16x3" else 1)
+        else:
+            ops.run_conv(ops.corr_volume(a1, rows, n, vol, 1.0 / math.sqrt(c), precision=precision, f2_hi=hi, f2_lo=lo))
         vols.append(vol)
         dims.append((hl, wl))
         if l < 3:
@@ -282,6 +298,21 @@ def test_corr_volume_and_lookup(ops, h, w, precision, tol):
     got = out[:, :324].reshape(1, h, w, 324).permute(0, 3, 1, 2)
     _close(got, ref, 1e-4, what="lookup")
     assert float(out[:, 324:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("h,w,precision,tol", [(17, 25, "bf16x3", 2e-4), (24, 40, "bf16x3", 2e-4), (16, 20, "bf16", 5e-2)])
+def test_corr_gemm_presplit(ops, h, w, precision, tol):
+    """woft_corr_gemm_bf16 (both operands pre-split, LDS-DMA fed) == the per-tap conv kernel's volume in the same
+    precision mode (same products; the accumulation order inside a K step differs in bf16 mode), and == the oracle
+    within tolerance."""
+    f1, f2 = _rand(1, 256, h, w, seed=41), _rand(1, 256, h, w, seed=42)
+    pyr = raft_ref.corr_pyramid(f1, f2)
+    vols, dims = _build_pyramid_gpu(ops, f1, f2, precision, presplit=True)
+    ref, _ = _build_pyramid_gpu(ops, f1, f2, precision)
+    for l in range(4):
+        hl, wl = dims[l]
+        _close(ops.untile_planes(vols[l], hl, wl), pyr[l][:, 0], tol, what=f"volume level {l}")
+        _close(vols[l], ref[l], tol * 0.1, what=f"level {l}: pre-split GEMM vs the conv kernel")
 
 
 @pytest.mark.parametrize("radius", [4, 3])

@@ -25,6 +25,8 @@
 //    (conflict-free ds_read_b128 fragment reads).
 //
 // In both modes the global loads for step k+1 are issued into registers before the MFMAs of step k.
+#include <type_traits>
+
 #include "conv_common.h"
 
 namespace {
@@ -34,8 +36,27 @@ using woft::BK;
 
 // developer tuning knobs (A/B experiments only; set once at start-up, never from the hot path):
 //   [0] gather kernel: 0 = register-staged operands, one LDS stage; 1 = B by LDS-DMA, two stages, one barrier per step
-//   [1] halo kernel:   0 = weight tile through registers, 1 = weight tile by LDS-DMA (global_load_lds; default)
+//   [1] unused (was: halo kernel weight path);  [2] corr GEMM ablation bits
 int g_tuning[4] = {0, 1, 0, 0};
+
+// One LDS-DMA wave instruction: lane L copies 16 bytes from (gbase + lane_off) to LDS byte address lds_addr + 16 L.
+// gbase and lds_addr are wave-uniform (SGPRs).  Written as inline assembly so that (1) the address is the
+// scalar-base + 32-bit-lane-offset form and (2) the compiler does not count it: it would otherwise drain EVERY
+// outstanding global load (vmcnt(0)) at the next barrier, including prefetches that are meant to stay in flight.
+// The caller orders it explicitly with dma_wait<N>() before the barrier that publishes the data.
+__device__ __forceinline__ void lds_dma16(const void* gbase, uint32_t lane_off, uint32_t lds_addr) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                 :
+                 : "s"(lds_addr), "v"(lane_off), "s"(gbase)
+                 : "memory", "m0");
+}
+template <int N>
+__device__ __forceinline__ void dma_wait() {             // at most N vector-memory loads still in flight
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
 
 constexpr int LDS_LD = 36;   // fp32 tiles: floats per row (144 B: 16-B aligned, conflict-free b128 reads)
 
@@ -319,138 +340,266 @@ struct HaloRowMap {
     }
 };
 
-template <int TY, int TX, int G, int BN, int TERMS, int NWAVES, int WM, bool DMA>
-__global__ __launch_bounds__(NWAVES * 64) void conv_halo_bf16_kernel(const woft_conv_params p) {
-    constexpr int NT = NWAVES * 64;
+// LDS-halo convolution, stride 1, KY x KX taps in {3x3, 1x5, 5x1}, split-bf16 MFMA.
+//
+// A workgroup (4 waves) owns a TY x TX output patch of one image and BN output channels.  Per 32-channel
+// chunk it stages the (TY+KY-1) x (TX+KX-1) input halo ONCE into LDS (fp32 -> bf16 hi / lo planes, 80-byte
+// pixel rows) and all KY*KX taps read their A fragments from it at compile-time offsets -- the per-tap
+// gather kernel re-loads and re-converts the same pixels for every tap.  The weight tile of each (chunk, tap)
+// K step is copied global -> LDS by global_load_lds one step ahead into one of two stages of unpadded 64-byte
+// rows whose four 16-byte chunks are XOR-swizzled with (row >> 2) & 3 on the SOURCE side (the DMA image is
+// lane-linear), which keeps the ds_read_b128 fragment reads conflict-free.
+//
+// The loop is built to ISSUE little besides MFMAs (the first version spent ~250 scalar/vector bookkeeping
+// instructions per 24 MFMAs -- runtime tap divisions, 64-bit per-lane DMA addresses, exec-masked loads -- and
+// was issue bound at a third of the matrix peak): taps are unrolled (A offsets are ds_read immediates), the
+// wave id is made scalar so DMA bases and LDS destinations live in SGPRs, every lane offset is one 32-bit VGPR
+// computed once, halo loads are unconditional (clamped address + select).
+template <int TY, int TX, int KY, int KX, int BN, int TERMS, int WM>
+__global__ __launch_bounds__(256) void conv_halo_bf16_kernel(const woft_conv_params p) {
+    constexpr int NWAVES = 4;
     constexpr int NPIX = TY * TX;
-    constexpr int BMG = (NPIX + 31) / 32 * 32;          // rows per group (padded to MFMA tiles)
-    constexpr int BM = G * BMG;
+    constexpr int BM = (NPIX + 31) / 32 * 32;           // rows (padded to MFMA tiles)
     constexpr int WN = NWAVES / WM;
     constexpr int WROWS = BM / WM, WCOLS = BN / WN;
     constexpr int TM = WROWS / 32, TN = WCOLS / 32;
     static_assert(BM % (32 * WM) == 0 && WCOLS % 32 == 0 && TM >= 1 && TN >= 1, "bad wave layout");
     constexpr int NP = (TERMS == 3) ? 2 : 1;
-    constexpr int H33 = (TY + 2) * (TX + 2), H15 = TY * (TX + 4), H51 = (TY + 4) * TX;
-    constexpr int HROWS = (H33 > H15 ? (H33 > H51 ? H33 : H51) : (H15 > H51 ? H15 : H51));   // per group
-    constexpr int HTOT = G * HROWS;
-    constexpr int LROWS = NT / 8;                        // halo rows covered per loader pass
-    constexpr int RH = (HTOT + LROWS - 1) / LROWS;       // halo float4 rows per thread
-    constexpr int BROWS = NT / 4;                        // weight rows covered per loader pass
-    constexpr int RB = (BN + BROWS - 1) / BROWS;
-    // DMA variant: the weight tile is copied global -> LDS by global_load_lds (no staging registers, no
-    // ds_write pass) into one of TWO stages of unpadded 64-byte rows whose four 16-byte chunks are XOR
-    // swizzled with (row >> 2) & 3 on the SOURCE side (the DMA image is lane-linear), which keeps the
-    // ds_read_b128 fragment reads conflict free; a K step then needs a single block barrier.
-    constexpr int LDBB = DMA ? 32 : LDB;                 // B row pitch in elements
-    constexpr int A_ELEMS = NP * HTOT * LDB, B_ELEMS = NP * BN * LDBB;
-    constexpr int NBST = DMA ? 2 : 1;
+    constexpr int TAPS = KY * KX;
+    constexpr int HX = TX + KX - 1, HY = TY + KY - 1, HROWS = HX * HY;
+    constexpr int RH = (HROWS + 31) / 32;               // halo float4 rows per thread (32 rows per pass)
+    constexpr int A_PLANE = HROWS * LDB, A_ELEMS = NP * A_PLANE;
+    constexpr int B_PLANE = BN * 32, B_STAGE = NP * B_PLANE;
     constexpr int STAGE_ELEMS = 2 * NWAVES * woft::STAGE_FLOATS;
-    constexpr int SMEM_ELEMS = (A_ELEMS + NBST * B_ELEMS > STAGE_ELEMS) ? A_ELEMS + NBST * B_ELEMS : STAGE_ELEMS;
+    constexpr int SMEM_ELEMS = (A_ELEMS + 2 * B_STAGE > STAGE_ELEMS) ? A_ELEMS + 2 * B_STAGE : STAGE_ELEMS;
     __shared__ __attribute__((aligned(16))) __bf16 smem[SMEM_ELEMS];
     __bf16* As = smem;
     __bf16* Bs = smem + A_ELEMS;
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: DMA bookkeeping stays on the SALU
     const int wm = wave / WN, wn = wave % WN;
     const int r32 = lane & 31, hh = lane >> 5;
     const int v = tid & 7, r0 = tid >> 3;
-    const int vb = tid & 3, rb0 = tid >> 2;
 
     const int tyn = (p.ho + TY - 1) / TY, txn = (p.wo + TX - 1) / TX;
-    const int img_groups = (p.n_img + G - 1) / G;
     int m_tile, n_tile;
-    woft::tile_of_block(blockIdx.x, img_groups * tyn * txn, p.cout_pad / BN, m_tile, n_tile);
-    const int ig = m_tile / (tyn * txn);
-    const int trem = m_tile - ig * (tyn * txn);
-    const int img0 = ig * G;
+    woft::tile_of_block(blockIdx.x, p.n_img * tyn * txn, p.cout_pad / BN, m_tile, n_tile);
+    const int img0 = m_tile / (tyn * txn);
+    const int trem = m_tile - img0 * (tyn * txn);
     const int y0 = (trem / txn) * TY, x0 = (trem % txn) * TX;
     const int n0 = n_tile * BN;
-    const int taps = p.taps_y * p.taps_x;
     const int nchunk = p.cin_pad / BK;
-    const int nk = taps * nchunk;
-    const int64_t ktot = (int64_t)nk * BK;
-    const int HX = TX + p.taps_x - 1;
-    const int hrows = (TY + p.taps_y - 1) * HX;          // used halo rows per group (<= HROWS)
+    const int ktot = TAPS * p.cin_pad;                  // (< 2^20: validated by the launcher)
 
-    // halo pixels owned by this thread (rows r0 + LROWS j): global pixel index or -1 (zero fill)
-    int hpix[RH];                // (n_img * h * w < 2^31: validated by the launcher)
+    // halo pixels owned by this thread (rows r0 + 32 j): element offset of the pixel's channel vector / cs,
+    // clamped to pixel 0 where there is no pixel (then the loaded value is replaced by zero)
+    int hpix[RH];
+    bool hok[RH];
 #pragma unroll
     for (int j = 0; j < RH; ++j) {
-        const int ht = r0 + LROWS * j;
-        const int g = ht / HROWS, h = ht - g * HROWS;
-        const int hy = h / HX, hx = h - hy * HX;
+        const int ht = r0 + 32 * j;
+        const int hy = ht / HX, hx = ht - hy * HX;
         const int iy = y0 + hy - p.pad_y, ix = x0 + hx - p.pad_x;
-        const bool ok = ht < HTOT && h < hrows && img0 + g < p.n_img && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w;
-        hpix[j] = ok ? ((img0 + g) * p.h + iy) * p.w + ix : -1;
+        hok[j] = ht < HROWS && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w;
+        hpix[j] = hok[j] ? (img0 * p.h + iy) * p.w + ix : 0;
     }
-    const __bf16* bsrc[NP];
-    bsrc[0] = (const __bf16*)p.wgt_hi;
-    if (NP == 2) bsrc[NP - 1] = (const __bf16*)p.wgt_lo;
-
     f32x4 rh[RH];
-    bf16x8 rb[NP][RB];
-    auto load_halo = [&](int chunk) {
+    auto load_halo = [&](int chunk) {                    // RH unconditional 16-byte loads (counted by vmcnt below)
         const int c0 = chunk * BK;
         const bool second = (p.in1 != nullptr) && (c0 >= p.c_split);
-        const float* src = second ? p.in1 : p.in0;
+        const float* src = (second ? p.in1 + (c0 - p.c_split) : p.in0 + c0) + 4 * v;
         const int cs = second ? p.cs1 : p.cs0;
-        const int cc = (second ? c0 - p.c_split : c0) + 4 * v;
 #pragma unroll
-        for (int j = 0; j < RH; ++j) {
-            f32x4 val = {0.f, 0.f, 0.f, 0.f};
-            if (hpix[j] >= 0) val = *(const f32x4*)(src + (int64_t)hpix[j] * cs + cc);
-            rh[j] = val;
-        }
+        for (int j = 0; j < RH; ++j) rh[j] = *(const f32x4*)(src + (uint32_t)(hpix[j] * cs));
     };
     auto store_halo = [&]() {
+        // (pins the use of the prefetched registers HERE: the conversions must not be scheduled up into the taps,
+        //  where their wait would drain the weight DMA queue early)
+#pragma unroll
+        for (int j = 0; j < RH; ++j) asm volatile("" : "+v"(rh[j]));
 #pragma unroll
         for (int j = 0; j < RH; ++j) {
-            const int ht = r0 + LROWS * j;
-            if (ht >= HTOT) continue;
-            const bf16x4 hi = __builtin_convertvector(rh[j], bf16x4);
+            const int ht = r0 + 32 * j;
+            if (RH * 32 > HROWS && ht >= HROWS) continue;
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 val = hok[j] ? rh[j] : zero;
+            const bf16x4 hi = __builtin_convertvector(val, bf16x4);
             *(bf16x4*)(As + ht * LDB + 4 * v) = hi;
             if (NP == 2) {
-                const f32x4 rem = rh[j] - __builtin_convertvector(hi, f32x4);
-                *(bf16x4*)(As + HTOT * LDB + ht * LDB + 4 * v) = __builtin_convertvector(rem, bf16x4);
+                const f32x4 rem = val - __builtin_convertvector(hi, f32x4);
+                *(bf16x4*)(As + A_PLANE + ht * LDB + 4 * v) = __builtin_convertvector(rem, bf16x4);
             }
         }
     };
-    auto load_b = [&](int ks) {
-        const int chunk = ks / taps, tap = ks - chunk * taps;
-        const int64_t koff = (int64_t)tap * p.cin_pad + chunk * BK + 8 * vb;
+
+    // weight DMA: one wave instruction moves 16 rows x 64 B; lane L -> (row L/4, physical chunk L%4) which holds
+    // logical chunk (L%4) ^ ((row >> 2) & 3) = (L%4) ^ ((L >> 4) & 3) for every 16-row group
+    constexpr int DMA_PER_PLANE = BN / 16, DMA_TOTAL = NP * DMA_PER_PLANE, DMA_PER_WAVE = DMA_TOTAL / NWAVES;
+    static_assert(DMA_TOTAL % NWAVES == 0, "weight DMA instructions must divide over the waves");
+    const uint32_t dma_lane = (uint32_t)(((lane >> 2) * ktot + (((lane & 3) ^ ((lane >> 4) & 3)) * 8)) * 2);   // bytes
+    const char* wrow[DMA_PER_WAVE];                      // scalar: plane base + first row of the 16-row group
+    uint32_t wdst[DMA_PER_WAVE];                         // scalar: LDS byte address inside stage 0
+    const uint32_t bs_addr = lds_addr_of(Bs);
 #pragma unroll
-        for (int pl = 0; pl < NP; ++pl)
+    for (int t = 0; t < DMA_PER_WAVE; ++t) {
+        const int q = wave + t * NWAVES;
+        const int pl = q / DMA_PER_PLANE, cb = q - pl * DMA_PER_PLANE;
+        wrow[t] = (const char*)((NP == 2 && pl == 1) ? p.wgt_lo : p.wgt_hi) + ((int64_t)(n0 + cb * 16) * ktot) * 2;
+        wdst[t] = bs_addr + (uint32_t)(pl * B_PLANE + cb * 16 * 32) * 2;
+    }
+    auto dma_b = [&](int koff, int stage) {              // koff: first k of the step (elements), scalar
 #pragma unroll
-            for (int j = 0; j < RB; ++j)
-                if (rb0 + BROWS * j < BN)
-                    rb[pl][j] = *(const bf16x8*)(bsrc[pl] + (int64_t)(n0 + rb0 + BROWS * j) * ktot + koff);
-    };
-    auto store_b = [&]() {
-#pragma unroll
-        for (int pl = 0; pl < NP; ++pl)
-#pragma unroll
-            for (int j = 0; j < RB; ++j)
-                if (rb0 + BROWS * j < BN) *(bf16x8*)(Bs + pl * BN * LDB + (rb0 + BROWS * j) * LDB + 8 * vb) = rb[pl][j];
+        for (int t = 0; t < DMA_PER_WAVE; ++t)
+            lds_dma16(wrow[t] + (int64_t)koff * 2, dma_lane, wdst[t] + (uint32_t)(stage * B_STAGE * 2));
     };
 
-    // DMA: one wave instruction moves 16 rows x 64 B (1 KiB); lane L -> (row L/4, physical chunk L%4)
-    constexpr int DMA_PER_PLANE = BN / 16, DMA_TOTAL = NP * DMA_PER_PLANE;
-    auto dma_b = [&](int ks, int stage) {
-        const int chunk = ks / taps, tap = ks - chunk * taps;
-        const int64_t koff = (int64_t)tap * p.cin_pad + chunk * BK;
+    f32x16 acc[TM][TN];
 #pragma unroll
-        for (int t = 0; t < (DMA_TOTAL + NWAVES - 1) / NWAVES; ++t) {
-            const int q = wave + t * NWAVES;               // wave-uniform instruction index
-            if (q < DMA_TOTAL) {
-                const int pl = q / DMA_PER_PLANE, cb = q - pl * DMA_PER_PLANE;
-                const int row = cb * 16 + (lane >> 2);
-                const int c = (lane & 3) ^ ((row >> 2) & 3);
-                const __bf16* src = bsrc[pl] + (int64_t)(n0 + row) * ktot + koff + c * 8;
-                __bf16* dstl = Bs + stage * B_ELEMS + pl * BN * LDBB + cb * 16 * LDBB;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)dstl, 16, 0, 0);
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment addresses: one VGPR each, everything else is an immediate
+    const __bf16* a_frag[TM];        // output pixel (ty, tx) reads halo row (ty + ky) * HX + (tx + kx)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int pl = wm * WROWS + i * 32 + r32;
+        a_frag[i] = As + ((pl < NPIX) ? (pl / TX) * HX + (pl % TX) : 0) * LDB + hh * 8;
+    }
+    const int sw = (r32 >> 2) & 3;
+    int b_frag[2];                   // element offset of logical chunk (s*2 + hh) in this lane's B rows
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) b_frag[s2] = (wn * WCOLS + r32) * 32 + (((s2 * 2 + hh) ^ sw) * 8);
+
+    load_halo(0);
+    dma_b(0, 0);
+    store_halo();
+    dma_wait<0>();                                       // this wave's DMA has landed before the others read it
+    __syncthreads();
+    int stage = 0;
+    // one 32-channel chunk = TAPS unrolled K steps; MORE (compile time: the last chunk is peeled, so the compiler
+    // can pair each prefetch with its store) = another chunk follows
+    auto run_chunk = [&](int chunk, auto more_tag) {
+        constexpr bool more = decltype(more_tag)::value;
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            // next step's weights (and, during the first tap, the next chunk's halo: RH loads issued AFTER the DMA,
+            // so that "at most RH loads in flight" = DMA complete while the halo loads cross the barrier)
+            if (tap + 1 < TAPS) dma_b((tap + 1) * p.cin_pad + chunk * BK, stage ^ 1);
+            else if (more) dma_b((chunk + 1) * BK, stage ^ 1);
+            if (tap == 0 && more) load_halo(chunk + 1);
+            const int ky = tap / KX, kx = tap - ky * KX;
+            const __bf16* bst = Bs + stage * B_STAGE;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                bf16x8 b[NP][TN];
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) b[pl][j] = *(const bf16x8*)(bst + b_frag[s2] + pl * B_PLANE + j * 32 * 32);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    bf16x8 a[NP];
+#pragma unroll
+                    for (int pl = 0; pl < NP; ++pl)
+                        a[pl] = *(const bf16x8*)(a_frag[i] + pl * A_PLANE + (ky * HX + kx) * LDB + s2 * 16);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        if (NP == 2) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[NP - 1], b[0][j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[NP - 1][j], acc[i][j], 0, 0, 0);
+                        }
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0][j], acc[i][j], 0, 0, 0);
+                    }
+                }
             }
+            if (tap == 0 && more) dma_wait<RH>();
+            else dma_wait<0>();
+            __syncthreads();
+            stage ^= 1;
+        }
+        if (more) {
+            store_halo();
+            __syncthreads();
+        }
+    };
+    for (int chunk = 0; chunk + 1 < nchunk; ++chunk) run_chunk(chunk, std::true_type{});
+    run_chunk(nchunk - 1, std::false_type{});
+    const HaloRowMap<TY, TX, 1> rowmap{img0, p.n_img, y0, x0, p.ho, p.wo};
+    woft::conv_epilogue_t<TM, TN, WROWS, WCOLS>(p, acc, (float*)smem + wave * woft::STAGE_FLOATS, rowmap, n0, wm, wn,
+                                                lane, m_tile);
+}
+
+template <int TY, int TX, int BN, int WM>
+int launch_halo(const woft_conv_params& p, hipStream_t s) {
+    const int tyn = (p.ho + TY - 1) / TY, txn = (p.wo + TX - 1) / TX;
+    const int64_t mt = (int64_t)p.n_img * tyn * txn;
+    dim3 grid((unsigned)(mt * (p.cout_pad / BN)));
+#define HALO_LAUNCH(KY, KX, T) \
+    hipLaunchKernelGGL((conv_halo_bf16_kernel<TY, TX, KY, KX, BN, T, WM>), grid, dim3(256), 0, s, p)
+#define HALO_TAPS(T)                                                   \
+    if (p.taps_y == 3 && p.taps_x == 3) HALO_LAUNCH(3, 3, T);          \
+    else if (p.taps_y == 1 && p.taps_x == 5) HALO_LAUNCH(1, 5, T);     \
+    else if (p.taps_y == 5 && p.taps_x == 1) HALO_LAUNCH(5, 1, T);     \
+    else return WOFT_EINVAL
+    if (p.precision == 1) { HALO_TAPS(3); } else { HALO_TAPS(1); }
+#undef HALO_TAPS
+#undef HALO_LAUNCH
+    return woft_launch_status();
+}
+
+// ---- all-pairs correlation GEMM on pre-split operands -------------------------------------------
+// vol[p][q] = alpha * <f1[p], f2[q]> (corr.py:62-69) with BOTH feature maps already converted to bf16 once
+// (the per-tap kernel above re-splits the fp32 A tile in each of the ~255 column-tile workgroups that share
+// it).  Operand rows are sequences of 128-byte LINES, one line per K step:
+//   TERMS 3: line = [hi of 32 k | lo of 32 k]   (woft_split_bf16_lines)      K step = 32
+//   TERMS 1: line = 64 k of the bf16 plane       (woft_split_bf16, hi only)   K step = 64
+// so that every global_load_lds wave instruction moves 8 rows x one full 128-B line (half-line pieces cost
+// the texture-addresser twice the cycles).  LDS image of a tile: [128 rows][8 chunks of 16 B], chunk c of row r
+// stored at c ^ ((r >> 1) & 7) -- applied on the global side, the DMA destination is lane-linear -- which
+// makes the ds_read_b128 fragment reads conflict-free (rows of equal parity alias mod 256 B; each 16-lane
+// service group holds 8 even and 8 odd rows whose (r >> 1) & 7 are all different).
+// One stage only (32 KiB): four workgroups per CU overlap each other's load, MFMA and store-drain phases,
+// which measured faster than two stages with two workgroups (tools/bench_cgemm.py).
+template <int TERMS>
+__global__ __launch_bounds__(256, 4) void corr_gemm_bf16_kernel(const __bf16* __restrict__ a, const __bf16* __restrict__ b,
+                                                                int line_elems_per_row, const woft_conv_params p, int abl) {
+    constexpr int BM = 128, BN = 128, TM = 2, TN = 2;
+    constexpr int PL = 128 * 64;                        // elements of one operand tile stage (128 rows x 128 B)
+    constexpr int SMEM_ELEMS = (2 * PL > 8 * woft::STAGE_FLOATS) ? 2 * PL : 8 * woft::STAGE_FLOATS;
+    __shared__ __attribute__((aligned(16))) __bf16 smem[SMEM_ELEMS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r32 = lane & 31, hh = lane >> 5;
+    const int64_t M = (int64_t)p.n_img * p.ho * p.wo;
+    int m_tile, n_tile;
+    woft::tile_of_block(blockIdx.x, (int)((M + BM - 1) / BM), p.cout_pad / BN, m_tile, n_tile);
+    const int64_t m0 = (int64_t)m_tile * BM;
+    const int n0 = n_tile * BN;
+    const int ld = line_elems_per_row;                  // elements per operand row (all its lines)
+    const int nk = ld / 64;
+
+    // wave instruction q of a step: operand q / 16, rows (q % 16) * 8 + lane / 8, physical chunk lane % 8
+    const __bf16* src[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const int q = wave + t * 4;
+        const int row = (q & 15) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        src[t] = (q < 16 ? a + (m0 + row) * ld : b + (int64_t)(n0 + row) * ld) + c * 8;
+    }
+    auto dma = [&](int ks) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int q = wave + t * 4;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[t] + ks * 64),
+                                             (__attribute__((address_space(3))) void*)(smem + q * 512), 16, 0, 0);
         }
     };
 
@@ -462,130 +611,93 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_halo_bf16_kernel(const woft_
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // A fragment rows: output pixel (ty, tx) of group g reads halo row g*HROWS + (ty + ky) * HX + (tx + kx)
-    int abase[TM];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int ml = wm * WROWS + i * 32 + r32;
-        const int g = ml / BMG, pl = ml - g * BMG;
-        abase[i] = g * HROWS + ((pl < NPIX) ? (pl / TX) * HX + (pl % TX) : 0);
-    }
-    const __bf16* b_frag = Bs + (wn * WCOLS + r32) * LDB + hh * 8;
-
-    if (DMA) {
-        // physical 16-byte chunk of logical chunk (s*2 + hh) in this lane's B rows (rows = 32*j + r32 + const)
-        const int sw = (r32 >> 2) & 3;
-        const __bf16* bfr = Bs + (wn * WCOLS + r32) * LDBB;
-        load_halo(0);
-        dma_b(0, 0);
-        store_halo();
+    const int sw = (r32 >> 1) & 7;
+    const __bf16* a_rows = smem + (wm * 64 + r32) * 64;
+    const __bf16* b_rows = smem + PL + (wn * 64 + r32) * 64;
+    for (int ks = 0; ks < nk; ++ks) {
+        if (!(abl & 4) || ks == 0) dma(ks);
         __syncthreads();
-        for (int ks = 0; ks < nk; ++ks) {
-            const int chunk = ks / taps, tap = ks - chunk * taps;
-            const bool nxt = ks + 1 < nk;
-            const bool new_chunk = nxt && (tap + 1 == taps);
-            if (nxt) dma_b(ks + 1, (ks + 1) & 1);          // lands while this step computes
-            if (new_chunk) load_halo(chunk + 1);
-            const int ky = tap / p.taps_x, kx = tap - ky * p.taps_x;
-            const int toff = (ky * HX + kx) * LDB + hh * 8;
-            const __bf16* bst = bfr + (ks & 1) * B_ELEMS;
+        if (!(abl & 8)) {
+            if (TERMS == 3) {
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const int pc = ((s * 2 + hh) ^ sw) * 8;
-                bf16x8 b[NP][TN];
+                for (int s = 0; s < 2; ++s) {
+                    const int ch = ((s * 2 + hh) ^ sw) * 8, cl = ((4 + s * 2 + hh) ^ sw) * 8;
+                    bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
-                for (int pl = 0; pl < NP; ++pl)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) b[pl][j] = *(const bf16x8*)(bst + pl * BN * LDBB + j * 32 * LDBB + pc);
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    bf16x8 a[NP];
-#pragma unroll
-                    for (int pl = 0; pl < NP; ++pl) a[pl] = *(const bf16x8*)(As + pl * HTOT * LDB + abase[i] * LDB + toff + s * 16);
+                    for (int i = 0; i < TM; ++i) {
+                        ah[i] = *(const bf16x8*)(a_rows + i * 32 * 64 + ch);
+                        al[i] = *(const bf16x8*)(a_rows + i * 32 * 64 + cl);
+                    }
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
-                        if (NP == 2) {
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[NP - 1], b[0][j], acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[NP - 1][j], acc[i][j], 0, 0, 0);
+                        bh[j] = *(const bf16x8*)(b_rows + j * 32 * 64 + ch);
+                        bl[j] = *(const bf16x8*)(b_rows + j * 32 * 64 + cl);
+                    }
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {      // small terms first, as in conv_mfma_bf16_kernel
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                         }
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0][j], acc[i][j], 0, 0, 0);
-                    }
                 }
-            }
-            __syncthreads();                             // (drains the DMA: the next stage is complete)
-            if (new_chunk) {
-                store_halo();
-                __syncthreads();
-            }
-        }
-        const HaloRowMap<TY, TX, G> rowmap_d{img0, p.n_img, y0, x0, p.ho, p.wo};
-        woft::conv_epilogue_t<TM, TN, WROWS, WCOLS>(p, acc, (float*)smem + wave * woft::STAGE_FLOATS, rowmap_d, n0, wm,
-                                                    wn, lane, m_tile);
-        return;
-    }
-
-    load_halo(0);
-    load_b(0);
-    store_halo();
-    store_b();
-    __syncthreads();
-    for (int ks = 0; ks < nk; ++ks) {
-        const int chunk = ks / taps, tap = ks - chunk * taps;
-        const bool nxt = ks + 1 < nk;
-        const bool new_chunk = nxt && (tap + 1 == taps);
-        if (nxt) load_b(ks + 1);
-        if (new_chunk) load_halo(chunk + 1);
-        const int ky = tap / p.taps_x, kx = tap - ky * p.taps_x;
-        const int toff = (ky * HX + kx) * LDB + hh * 8;
+            } else {
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            bf16x8 b[NP][TN];
+                for (int s = 0; s < 4; ++s) {
+                    const int ch = ((s * 2 + hh) ^ sw) * 8;
+                    bf16x8 ah[TM], bh[TN];
 #pragma unroll
-            for (int pl = 0; pl < NP; ++pl)
+                    for (int i = 0; i < TM; ++i) ah[i] = *(const bf16x8*)(a_rows + i * 32 * 64 + ch);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) b[pl][j] = *(const bf16x8*)(b_frag + pl * BN * LDB + j * 32 * LDB + s * 16);
+                    for (int j = 0; j < TN; ++j) bh[j] = *(const bf16x8*)(b_rows + j * 32 * 64 + ch);
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                bf16x8 a[NP];            // A fragments are loaded per row tile: keeps tall wave tiles in registers
+                    for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int pl = 0; pl < NP; ++pl) a[pl] = *(const bf16x8*)(As + pl * HTOT * LDB + abase[i] * LDB + toff + s * 16);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    if (NP == 2) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[NP - 1], b[0][j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[NP - 1][j], acc[i][j], 0, 0, 0);
-                    }
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0][j], acc[i][j], 0, 0, 0);
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                 }
             }
         }
         __syncthreads();
-        if (nxt) {
-            store_b();
-            if (new_chunk) store_halo();
-            __syncthreads();
-        }
     }
-    const HaloRowMap<TY, TX, G> rowmap{img0, p.n_img, y0, x0, p.ho, p.wo};
-    woft::conv_epilogue_t<TM, TN, WROWS, WCOLS>(p, acc, (float*)smem + wave * woft::STAGE_FLOATS, rowmap, n0, wm, wn,
-                                                lane, m_tile);
-}
-
-template <int TY, int TX, int G, int BN, int NWAVES, int WM>
-int launch_halo(const woft_conv_params& p, hipStream_t s) {
-    const int tyn = (p.ho + TY - 1) / TY, txn = (p.wo + TX - 1) / TX;
-    const int64_t mt = (int64_t)((p.n_img + G - 1) / G) * tyn * txn;
-    dim3 grid((unsigned)(mt * (p.cout_pad / BN)));
-    const bool dma = g_tuning[1] != 0;
-    if (p.precision == 1 && dma)
-        hipLaunchKernelGGL((conv_halo_bf16_kernel<TY, TX, G, BN, 3, NWAVES, WM, true>), grid, dim3(NWAVES * 64), 0, s, p);
-    else if (p.precision == 1)
-        hipLaunchKernelGGL((conv_halo_bf16_kernel<TY, TX, G, BN, 3, NWAVES, WM, false>), grid, dim3(NWAVES * 64), 0, s, p);
-    else if (dma)
-        hipLaunchKernelGGL((conv_halo_bf16_kernel<TY, TX, G, BN, 1, NWAVES, WM, true>), grid, dim3(NWAVES * 64), 0, s, p);
-    else
-        hipLaunchKernelGGL((conv_halo_bf16_kernel<TY, TX, G, BN, 1, NWAVES, WM, false>), grid, dim3(NWAVES * 64), 0, s, p);
-    return woft_launch_status();
+    if (abl & 2) {          // ablation: no epilogue at all (keep the accumulators live)
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t += acc[i][j][r];
+        if (t == 12345.678f) p.out[0] = t;
+        return;
+    }
+    // epilogue: alpha * acc, transposed 32x32 at a time through this wave's LDS stage into 16-byte row stores
+    // (8 rows x 128 B per wave instruction).  cout % 4 == 0 and ldo % 4 == 0 (validated by the launcher).
+    float* stage = (float*)smem + wave * woft::STAGE_FLOATS;
+    constexpr int LD = woft::STAGE_LD;
+    const int rr = lane >> 3, c4 = (lane & 7) * 4;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * hh) * LD + r32] = acc[i][j][r];
+            __builtin_amdgcn_wave_barrier();
+            const int n = n0 + wn * 64 + j * 32 + c4;
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int row = rr + 8 * pass;
+                const int64_t m = m0 + wm * 64 + i * 32 + row;
+                f32x4 v = *(const f32x4*)(stage + row * LD + c4);
+                if (m >= M || n >= p.cout || (abl & 1)) continue;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
+                if (abl & 16) __builtin_nontemporal_store(v, (f32x4*)(p.out + m * p.ldo + n));
+                else *(f32x4*)(p.out + m * p.ldo + n) = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
 }
 
 // fp32 matrix -> hi / lo bf16 planes (used for the dynamic B operand of the correlation GEMM)
@@ -648,15 +760,16 @@ extern "C" int woft_conv2d(const woft_conv_params* pp, void* stream) {
     if ((p.stat_sum == nullptr) != (p.stat_sq == nullptr)) return WOFT_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     if (p.halo != 0) {
-        // LDS-halo kernels: split-bf16 precisions, stride 1, multi-tap, non-flat, same-size output
-        if (p.precision == 0 || p.flat || p.stride != 1 || p.taps_y * p.taps_x < 2) return WOFT_EINVAL;
-        if (p.taps_y + p.taps_x > 6 || p.taps_y > 5 || p.taps_x > 5) return WOFT_EINVAL;      // 3x3, 1x5, 5x1 (and smaller)
+        // LDS-halo kernels: split-bf16 precisions, stride 1, 3x3 / 1x5 / 5x1 taps, non-flat, same-size output
+        if (p.precision == 0 || p.flat || p.stride != 1) return WOFT_EINVAL;
         if (p.ho != p.h + 2 * p.pad_y - p.taps_y + 1 || p.wo != p.w + 2 * p.pad_x - p.taps_x + 1) return WOFT_EINVAL;
-        if ((int64_t)p.n_img * p.h * p.w >= (1ll << 31)) return WOFT_EINVAL;
-        if (p.halo == 1 && p.tile_n == 128) return launch_halo<8, 16, 1, 128, 4, 2>(p, s);
-        if (p.halo == 1 && p.tile_n == 64) return launch_halo<8, 16, 1, 64, 4, 2>(p, s);
-        if (p.halo == 2 && p.tile_n == 128 && p.ho == 9 && p.wo == 9) return launch_halo<9, 9, 1, 128, 4, 1>(p, s);
-        if (p.halo == 4 && p.tile_n == 128) return launch_halo<4, 16, 1, 128, 4, 2>(p, s);
+        const int64_t cs_max = (p.in1 != nullptr && p.cs1 > p.cs0) ? p.cs1 : p.cs0;
+        if ((int64_t)p.n_img * p.h * p.w * cs_max >= (1ll << 31)) return WOFT_EINVAL;     // 32-bit element offsets
+        if ((int64_t)p.taps_y * p.taps_x * p.cin_pad >= (1 << 20)) return WOFT_EINVAL;
+        if (p.halo == 1 && p.tile_n == 128) return launch_halo<8, 16, 128, 2>(p, s);
+        if (p.halo == 1 && p.tile_n == 64) return launch_halo<8, 16, 64, 2>(p, s);
+        if (p.halo == 2 && p.tile_n == 128 && p.ho == 9 && p.wo == 9) return launch_halo<9, 9, 128, 1>(p, s);
+        if (p.halo == 4 && p.tile_n == 128) return launch_halo<4, 16, 128, 2>(p, s);
         return WOFT_EINVAL;
     }
     if (p.tile_m == 128 && p.tile_n == 128) return launch_conv<128, 128>(p, s);
@@ -665,10 +778,50 @@ extern "C" int woft_conv2d(const woft_conv_params* pp, void* stream) {
     return launch_conv<64, 64>(p, s);
 }
 
+extern "C" int woft_corr_gemm_bf16(const void* a, const void* b, int64_t m, int64_t n, int64_t rows_a, int64_t rows_b,
+                                   int32_t k, float alpha, float* out, int64_t ldo, int32_t terms, void* stream) {
+    if (!a || !b || !out || m <= 0 || n <= 0 || k <= 0 || ldo < n || n % 4 != 0 || ldo % 4 != 0) return WOFT_EINVAL;
+    if (terms != 1 && terms != 3) return WOFT_EINVAL;
+    if (k % (terms == 3 ? 32 : 64) != 0) return WOFT_EINVAL;
+    if (rows_a % 128 != 0 || rows_b % 128 != 0 || rows_a < m || rows_b < n || m >= (1ll << 31)) return WOFT_EINVAL;
+    woft_conv_params p = {};
+    p.n_img = 1; p.ho = 1; p.wo = (int32_t)m;            // M = m rows
+    p.alpha = alpha;
+    p.cout = (int32_t)n; p.cout_pad = (int32_t)rows_b;
+    p.out = out; p.ldo = ldo;
+    p.epi = WOFT_EPI_LINEAR;
+    const int abl = g_tuning[2];                         // ablation bits (tools/bench_cgemm.py); 0 in production
+    dim3 grid((unsigned)(ceil_div64(m, 128) * (rows_b / 128)));
+    if (terms == 3)
+        hipLaunchKernelGGL((corr_gemm_bf16_kernel<3>), grid, dim3(256), 0, (hipStream_t)stream, (const __bf16*)a,
+                           (const __bf16*)b, 2 * k, p, abl);
+    else
+        hipLaunchKernelGGL((corr_gemm_bf16_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, (const __bf16*)a,
+                           (const __bf16*)b, k, p, abl);
+    return woft_launch_status();
+}
+
 extern "C" int woft_set_tuning(int key, int value) {
     if (key < 0 || key >= 4) return WOFT_EINVAL;
     g_tuning[key] = value;
     return WOFT_OK;
+}
+
+__global__ void split_bf16_lines_kernel(const float* __restrict__ x, int64_t n4, __bf16* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const f32x4 vv = *(const f32x4*)(x + i * 4);
+    const bf16x4 h = __builtin_convertvector(vv, bf16x4);
+    __bf16* line = out + (i >> 3) * 64 + (i & 7) * 4;       // 32 inputs -> one 128-byte line [32 hi | 32 lo]
+    *(bf16x4*)line = h;
+    *(bf16x4*)(line + 32) = __builtin_convertvector(vv - __builtin_convertvector(h, f32x4), bf16x4);
+}
+
+extern "C" int woft_split_bf16_lines(const float* x, int64_t n, void* out, void* stream) {
+    if (!x || !out || n <= 0 || n % 32 != 0) return WOFT_EINVAL;
+    hipLaunchKernelGGL(split_bf16_lines_kernel, dim3((unsigned)ceil_div64(n / 4, 256)), dim3(256), 0, (hipStream_t)stream,
+                       x, n / 4, (__bf16*)out);
+    return woft_launch_status();
 }
 
 extern "C" int woft_split_bf16(const float* x, int64_t n, void* hi, void* lo, void* stream) {

@@ -157,19 +157,24 @@ class _Plan:
 
         self.img = [new_act(1, hp, wp, 3, cs=4), new_act(1, hp, wp, 3, cs=4)]
         # feature maps: f1 (source) and f2 rows (target, zero padded to the GEMM N tile)
-        self.f1 = new_act(1, hf, wf, sp.fdim, zero=True)
+        # source features: rows padded to the 128-row GEMM tile (pad rows stay zero), + their bf16 hi/lo planes
+        self.f1rows = z(_ru(P, 128), sp.fdim)
+        self.f1 = Act(self.f1rows[:P], 1, hf, wf, sp.fdim)
+        x3 = self.prec == "bf16x3"
+        bf = lambda rows: (torch.zeros(rows.shape[0], rows.shape[1] * (2 if x3 else 1), dtype=torch.bfloat16, device=dev)
+                           if self.prec != "fp32" else None)       # GEMM operand: [hi|lo] lines / bf16 plane
+        self.f1s = bf(self.f1rows)
         # target feature pyramid: linear NHWC maps (f2act) and their rows in 4x4-tile order (f2rows, the B
         # operand of the correlation GEMM, zero padded to the N tile) -> volumes in the tiled layout
         self.dims, self.f2rows, self.f2act, self.vol = [], [], [], []
-        self.f2hi, self.f2lo = [], []
+        self.f2s = []
         h, w = hf, wf
         for _ in range(sp.levels):
             self.dims.append((h, w))
             n = ops.tiled_dims(h, w)[2]
             rows = z(_ru(n, 128), sp.fdim)
             self.f2rows.append(rows)
-            self.f2hi.append(torch.zeros_like(rows, dtype=torch.bfloat16))
-            self.f2lo.append(torch.zeros_like(rows, dtype=torch.bfloat16))
+            self.f2s.append(bf(rows))
             self.f2act.append(new_act(1, h, w, sp.fdim, zero=True))
             self.vol.append(z(P, n))
             h, w = h // 2, w // 2
@@ -271,15 +276,18 @@ class _Plan:
     def _volume_program(self):
         sp = self.eng.spec
         prog = []
+        alpha = 1.0 / math.sqrt(float(sp.fdim))
+        x3 = self.prec == "bf16x3"
         for l in range(sp.levels):
             if l > 0:
                 prog.append(("pool", (self.f2act[l - 1], self.f2act[l])))
             prog.append(("tile", (self.f2act[l], self.f2rows[l])))
-            if self.prec != "fp32":
-                prog.append(("split", (self.f2rows[l], self.f2hi[l], self.f2lo[l] if self.prec == "bf16x3" else None)))
-            prog.append(("conv", ops.corr_volume(self.f1, self.f2rows[l], self.vol[l].shape[1], self.vol[l],
-                                                 1.0 / math.sqrt(float(sp.fdim)), precision=self.prec,
-                                                 f2_hi=self.f2hi[l], f2_lo=self.f2lo[l])))
+            if self.prec == "fp32":
+                prog.append(("conv", ops.corr_volume(self.f1, self.f2rows[l], self.vol[l].shape[1], self.vol[l], alpha)))
+            else:               # both operands pre-split once, GEMM fed by LDS-DMA (woft_corr_gemm_bf16)
+                prog.append(("split", (self.f2rows[l], self.f2s[l])))
+                prog.append(("cgemm", (self.f1s, self.f2s[l], self.P, self.vol[l].shape[1], alpha, self.vol[l],
+                                       3 if x3 else 1)))
         return prog
 
     # ---- one refinement iteration (update.py:106-112,127-136; weighted_raft.py:228-237) ----
@@ -329,9 +337,11 @@ class _Plan:
             elif kind == "pool":
                 ops.avgpool2(a[0], a[1])
             elif kind == "split":
-                ops.split_bf16(a[0], a[1], a[2])
+                self._split(a[0], a[1])
             elif kind == "tile":
                 ops.tile_rows(a[0], a[1])
+            elif kind == "cgemm":
+                ops.corr_gemm_bf16(*a)
             elif kind == "lookup":
                 self._lookup(a)
             elif kind == "copy":
@@ -353,6 +363,13 @@ class _Plan:
         e.record()
         self.lookup_events.append((s, e))
 
+    def _split(self, rows, out):
+        """fp32 rows -> the correlation GEMM's bf16 operand: [hi | lo] lines (bf16x3) or the bf16 plane (bf16)."""
+        if self.prec == "bf16x3":
+            ops.split_bf16_lines(rows, out)
+        else:
+            ops.split_bf16(rows, out, None)
+
     def load_image(self, slot, img_u8, pad_top, pad_left):
         ops.preprocess(img_u8, self.img[slot], self.hp, self.wp, pad_top, pad_left)
 
@@ -360,6 +377,8 @@ class _Plan:
         """fmap1, net, inp of the source image in img[0] (cacheable across frames)."""
         self.run(self.prog_f_src)
         self.run(self.prog_c_src)
+        if self.prec != "fp32":
+            self._split(self.f1rows, self.f1s)
 
     def flow(self, iters, crop, h, w, flow_up=None, dst=None, wout=None, do_sigmoid=False, trace=None):
         """Target features -> volume -> `iters` refinements -> full-resolution outputs."""

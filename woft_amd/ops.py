@@ -256,6 +256,18 @@ def split_bf16(x, hi, lo=None):
     check(_lib.load().woft_split_bf16(ptr(x), x.numel(), ptr(hi), ptr(lo), stream_ptr()), "woft_split_bf16")
 
 
+def split_bf16_lines(x, out):
+    """x fp32 [rows][k] -> out bf16 [rows][2k]: per 32 values one 128-byte line [hi | lo] (woft_split_bf16_lines)."""
+    check(_lib.load().woft_split_bf16_lines(ptr(x), x.numel(), ptr(out), stream_ptr()), "woft_split_bf16_lines")
+
+
+def corr_gemm_bf16(a, b, m, n, alpha, out, terms):
+    """out[:m, :n] = alpha * A B^T on pre-split bf16 operands (rows padded to 128); see woft_corr_gemm_bf16."""
+    k = a.shape[1] // 2 if terms == 3 else a.shape[1]
+    check(_lib.load().woft_corr_gemm_bf16(ptr(a), ptr(b), m, n, a.shape[0], b.shape[0], k, float(alpha), ptr(out),
+                                          out.shape[1], terms, stream_ptr()), "woft_corr_gemm_bf16")
+
+
 def corr_volume(f1, f2_rows, n_q, out, alpha, precision=0, f2_hi=None, f2_lo=None):
     """out[p][q] = alpha * <f1[p], f2_rows[q]>, q < n_q (rows of f2 already in the order the volume wants).
     f1: Act (P, C); f2_rows: tensor (rows_pad, C) zero padded to a multiple of 128 rows;
