@@ -94,6 +94,13 @@ int woft_conv2d(const woft_conv_params* p, void* stream);
 /* fp32 array (n % 4 == 0) -> bf16 planes hi = bf16(x), lo = bf16(x - hi) (lo may be NULL): the
  * split form of a dynamic B operand (fmap2 in the correlation GEMM). */
 int woft_split_bf16(const float* x, int64_t n, void* hi, void* lo, void* stream);
+/* 3x3, stride 1, zero padding 1, cout in {1, 2}, cin_pad in {128, 256} (the flow head's second conv,
+ * update.py:10-17: hidden -> 2), exact fp32 FMAs on the vector ALUs instead of a 97 % padded matrix-core tile.
+ * in: NHWC fp32 with channel stride cs; wgt: packed fp32 rows [cout][9 * cin_pad] (k = tap * cin_pad + c, as
+ * woft_conv2d's fp32 weights); out[pixel * ldo + co_off + o] = bias[o] + sum. */
+int woft_conv3x3_narrow(const float* in, int32_t cs, int32_t n_img, int32_t h, int32_t w, int32_t cin_pad,
+                        const float* wgt, const float* bias, int32_t cout, float* out, int64_t ldo, int32_t co_off,
+                        void* stream);
 /* x (n floats, n % 32 == 0) -> n/32 lines of 128 bytes, line = [bf16 hi of 32 values | bf16 lo of the same 32],
  * hi = bf16(x), lo = bf16(x - hi): the operand format of woft_corr_gemm_bf16 with terms = 3. */
 int woft_split_bf16_lines(const float* x, int64_t n, void* out, void* stream);

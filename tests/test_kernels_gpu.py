@@ -64,6 +64,23 @@ def test_conv_plain(ops, cin, cout, k, stride, h, w, tiles, precision, tol):
     assert float(big.t[:, :8].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("cin,cout,h,w", [(256, 2, 19, 37), (256, 1, 5, 16), (128, 2, 17, 33), (256, 2, 3, 3)])
+def test_conv3x3_narrow(ops, cin, cout, h, w):
+    """Flow head conv2 (update.py:10-17) on the vector ALUs: exact fp32 products, written at a channel offset."""
+    x = F.relu(_rand(2, cin, h, w, seed=61))
+    wt = _rand(cout, cin, 3, 3, seed=62, scale=1 / math.sqrt(cin * 9))
+    b = _rand(cout, seed=63, scale=0.1)
+    ref = F.conv2d(x.double(), wt.double(), b.double(), padding=1).float()
+    pc = ops.pack_conv(wt, b)
+    xa = ops.act_from_nchw(x)
+    assert ops.narrow_ok(xa, pc)
+    out = ops.new_act(2, h, w, 4, cs=4, zero=True)
+    ops.conv3x3_narrow(xa, pc, out, co_off=1)
+    torch.cuda.synchronize()
+    _close(out.nchw()[:, 1:1 + cout], ref, 2e-6, rtol=2e-6, what="narrow conv")
+    assert float(out.t[:, 0].abs().max()) == 0.0 and float(out.t[:, 1 + cout:].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("kh,kw", [(1, 5), (5, 1), (3, 3)])
 @pytest.mark.parametrize("precision,tol", [("fp32", 1.0), ("bf16x3", 4.0)])
 def test_conv_gru_epilogues(ops, kh, kw, precision, tol):

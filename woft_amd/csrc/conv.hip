@@ -156,31 +156,32 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int LDB = 40;      // bf16 tiles: elements per row (80 B: 16-B aligned, conflict-free b128 reads)
 
-template <int BM, int BN, int TERMS, bool DEEP>
+// Per-tap ("gather") implicit GEMM on split-bf16 operands: any stride / tap shape / flat packing, 1x1 included.
+// A rows (fp32, NHWC) are fetched one K step ahead into registers, split into bf16 hi / lo and written to the idle
+// one of two LDS stages; the weight tile goes global -> LDS by LDS-DMA into the idle one of two stages (unpadded
+// 64-byte rows, source-side XOR swizzle, as in conv_halo_bf16_kernel); one barrier per K step.
+// Like the halo kernel the loop is written to issue little besides MFMAs: (tap, chunk) advance by counters instead
+// of divisions, the per-row pixel offsets are recomputed once per TAP (32-bit), loads are unconditional (clamped
+// offset + select), the wave id is scalar so the DMA bookkeeping stays on the SALU.
+template <int BM, int BN, int TERMS>
 __global__ __launch_bounds__(256) void conv_mfma_bf16_kernel(const woft_conv_params p) {
-    // DEEP = false: register-staged operands, one LDS stage, two barriers per K step.
-    // DEEP = true : B (pre-split bf16) is copied global -> LDS by global_load_lds into two stages of unpadded,
-    //               source-swizzled 64-byte rows; A (fp32 -> hi/lo) goes through registers into two stages;
-    //               one barrier per K step, no staging registers for B.
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int RA = BM / 32;            // float4 rows per thread (A, fp32 source)
-    constexpr int RB = BN / 64;            // 16-B rows per thread and plane (B, pre-split bf16; register path)
     constexpr int NP = (TERMS == 3) ? 2 : 1;
-    constexpr int LDBB = DEEP ? 32 : LDB;
-    constexpr int A_ELEMS = NP * BM * LDB, B_ELEMS = NP * BN * LDBB;
-    constexpr int NST = DEEP ? 2 : 1;
-    constexpr int SMEM_ELEMS = (NST * (A_ELEMS + B_ELEMS) > 8 * woft::STAGE_FLOATS) ? NST * (A_ELEMS + B_ELEMS)
-                                                                                     : 8 * woft::STAGE_FLOATS;
+    constexpr int A_PLANE = BM * LDB, A_STAGE = NP * A_PLANE;
+    constexpr int B_PLANE = BN * 32, B_STAGE = NP * B_PLANE;
+    constexpr int SMEM_ELEMS = (2 * (A_STAGE + B_STAGE) > 8 * woft::STAGE_FLOATS) ? 2 * (A_STAGE + B_STAGE)
+                                                                                   : 8 * woft::STAGE_FLOATS;
     __shared__ __attribute__((aligned(16))) __bf16 smem[SMEM_ELEMS];
-    __bf16* Asm = smem;                                // [NST][NP][BM][LDB]
-    __bf16* Bsm = smem + NST * A_ELEMS;                // [NST][NP][BN][LDBB]
+    __bf16* Asm = smem;                                // [2][NP][BM][LDB]
+    __bf16* Bsm = smem + 2 * A_STAGE;                  // [2][NP][BN][32]
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int r32 = lane & 31, hh = lane >> 5;
     const int v = tid & 7, r0 = tid >> 3;              // A loader: float4 column, base row
-    const int vb = tid & 3, rb0 = tid >> 2;            // B loader: 16-B column, base row
 
     const int64_t M = (int64_t)p.n_img * p.ho * p.wo;
     int m_tile, n_tile;
@@ -188,60 +189,97 @@ __global__ __launch_bounds__(256) void conv_mfma_bf16_kernel(const woft_conv_par
     const int64_t m0 = (int64_t)m_tile * BM;
     const int n0 = n_tile * BN;
     const int nchunk = p.cin_pad / BK;
-    const int nk = p.taps_y * p.taps_x * nchunk;
-    const int64_t ktot = (int64_t)nk * BK;
+    const int taps = p.taps_y * p.taps_x;
+    const int nk = taps * nchunk;
+    const int ktot = nk * BK;                           // (< 2^20: validated by the launcher)
 
-    ARows<RA> arows;
-    woft::a_rows_init<RA>(p, m0, r0, M, arows);
-    const __bf16* bsrc[NP];
-    bsrc[0] = (const __bf16*)p.wgt_hi;
-    if (NP == 2) bsrc[NP - 1] = (const __bf16*)p.wgt_lo;
-
-    f32x4 ra[RA];
-    bf16x8 rb[NP][RB];
-    auto load_a = [&](int ks) { woft::a_load<RA>(p, arows, ks, nchunk, v, ra); };
-    auto store_a = [&](int stage) {
-        __bf16* As = Asm + stage * A_ELEMS;
+    // rows of this thread: top-left input pixel of the receptive field (32-bit pixel index: validated)
+    int iy0[RA], ix0[RA], ibase[RA];
+    bool mvalid[RA];
+    {
+        const int hw = p.ho * p.wo;
 #pragma unroll
         for (int j = 0; j < RA; ++j) {
-            const bf16x4 hi = __builtin_convertvector(ra[j], bf16x4);
+            int64_t m = m0 + r0 + 32 * j;
+            mvalid[j] = m < M;
+            if (!mvalid[j]) m = 0;
+            const int img = (int)(m / hw);
+            const int rem = (int)(m - (int64_t)img * hw);
+            const int oy = rem / p.wo, ox = rem - oy * p.wo;
+            iy0[j] = oy * p.stride - p.pad_y;
+            ix0[j] = ox * p.stride - p.pad_x;
+            ibase[j] = img * p.h * p.w;
+        }
+    }
+    // prefetch position (tap (ky, kx), chunk) and, per tap, each row's element offset / validity
+    int pf_chunk = 0, pf_ky = 0, pf_kx = 0;
+    uint32_t poff[RA];                                  // pixel index of the tap (0 where there is none)
+    bool pok[RA];
+    const int flat_dpix = p.flat ? (4 * v) / p.cs0 : 0;
+    auto tap_rows = [&]() {
+#pragma unroll
+        for (int j = 0; j < RA; ++j) {
+            const int iy = iy0[j] + pf_ky, ix = ix0[j] + pf_kx;
+            const int ixp = ix + flat_dpix;             // flat: the float4 covers pixel ix + dpix of the row segment
+            pok[j] = mvalid[j] && iy >= 0 && iy < p.h && ixp >= 0 && ixp < p.w;
+            poff[j] = pok[j] ? (uint32_t)(ibase[j] + iy * p.w + ix) : 0u;
+        }
+    };
+    f32x4 ra[RA];
+    bool rok[RA];
+    auto load_a = [&]() {                               // the step at the prefetch position
+        const int c0 = pf_chunk * BK;
+        const bool second = (p.in1 != nullptr) && (c0 >= p.c_split);
+        const float* src = (second ? p.in1 + (c0 - p.c_split) : p.in0 + (p.flat ? 0 : c0)) + 4 * v;
+        const int cs = second ? p.cs1 : p.cs0;
+#pragma unroll
+        for (int j = 0; j < RA; ++j) {
+            // (flat: poff may address up to dpix pixels left of a valid one; still inside the image row segment)
+            ra[j] = *(const f32x4*)(src + (int64_t)(int32_t)(poff[j] * (uint32_t)cs));
+            rok[j] = pok[j];
+        }
+    };
+    auto advance = [&]() {                              // next K step: chunk, then tap
+        if (++pf_chunk == nchunk) {
+            pf_chunk = 0;
+            if (++pf_kx == p.taps_x) { pf_kx = 0; ++pf_ky; }
+            tap_rows();
+        }
+    };
+    auto store_a = [&](int stage) {
+        __bf16* As = Asm + stage * A_STAGE;
+#pragma unroll
+        for (int j = 0; j < RA; ++j) {
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 val = rok[j] ? ra[j] : zero;
+            const bf16x4 hi = __builtin_convertvector(val, bf16x4);
             *(bf16x4*)(As + (r0 + 32 * j) * LDB + 4 * v) = hi;
             if (NP == 2) {
-                const f32x4 rem = ra[j] - __builtin_convertvector(hi, f32x4);
-                *(bf16x4*)(As + BM * LDB + (r0 + 32 * j) * LDB + 4 * v) = __builtin_convertvector(rem, bf16x4);
+                const f32x4 rem = val - __builtin_convertvector(hi, f32x4);
+                *(bf16x4*)(As + A_PLANE + (r0 + 32 * j) * LDB + 4 * v) = __builtin_convertvector(rem, bf16x4);
             }
         }
     };
-    auto load_b = [&](int ks) {
+
+    // weight DMA (see conv_halo_bf16_kernel)
+    constexpr int DMA_PER_PLANE = BN / 16, DMA_TOTAL = NP * DMA_PER_PLANE, DMA_PER_WAVE = DMA_TOTAL / 4;
+    static_assert(DMA_TOTAL % 4 == 0 || DMA_TOTAL < 4, "weight DMA instructions must divide over the waves");
+    constexpr int DMA_LOOPS = DMA_PER_WAVE > 0 ? DMA_PER_WAVE : 1;
+    const uint32_t dma_lane = (uint32_t)(((lane >> 2) * ktot + (((lane & 3) ^ ((lane >> 4) & 3)) * 8)) * 2);
+    const char* wrow[DMA_LOOPS];
+    uint32_t wdst[DMA_LOOPS];
+    const uint32_t bs_addr = lds_addr_of(Bsm);
 #pragma unroll
-        for (int pl = 0; pl < NP; ++pl)
-#pragma unroll
-            for (int j = 0; j < RB; ++j)
-                rb[pl][j] = *(const bf16x8*)(bsrc[pl] + (int64_t)(n0 + rb0 + 64 * j) * ktot + (int64_t)ks * BK + 8 * vb);
-    };
-    auto store_b = [&]() {
-#pragma unroll
-        for (int pl = 0; pl < NP; ++pl)
-#pragma unroll
-            for (int j = 0; j < RB; ++j) *(bf16x8*)(Bsm + pl * BN * LDB + (rb0 + 64 * j) * LDB + 8 * vb) = rb[pl][j];
-    };
-    // LDS-DMA of the B tile: one wave instruction = 16 rows x 64 B; lane L -> (row L/4, physical chunk L%4),
-    // logical chunk = physical ^ ((row >> 2) & 3)  (swizzle applied on the source side)
-    constexpr int DMA_PER_PLANE = BN / 16, DMA_TOTAL = NP * DMA_PER_PLANE;
+    for (int t = 0; t < DMA_LOOPS; ++t) {
+        const int q = (wave + t * 4) % DMA_TOTAL;       // (DMA_TOTAL < 4: the spare waves repeat a piece, harmless)
+        const int pl = q / DMA_PER_PLANE, cb = q - pl * DMA_PER_PLANE;
+        wrow[t] = (const char*)((NP == 2 && pl == 1) ? p.wgt_lo : p.wgt_hi) + ((int64_t)(n0 + cb * 16) * ktot) * 2;
+        wdst[t] = bs_addr + (uint32_t)(pl * B_PLANE + cb * 16 * 32) * 2;
+    }
     auto dma_b = [&](int ks, int stage) {
 #pragma unroll
-        for (int t = 0; t < (DMA_TOTAL + 3) / 4; ++t) {
-            const int q = wave + t * 4;
-            if (q < DMA_TOTAL) {
-                const int pl = q / DMA_PER_PLANE, cb = q - pl * DMA_PER_PLANE;
-                const int row = cb * 16 + (lane >> 2);
-                const int c = (lane & 3) ^ ((row >> 2) & 3);
-                const __bf16* src = bsrc[pl] + (int64_t)(n0 + row) * ktot + (int64_t)ks * BK + c * 8;
-                __bf16* dstl = Bsm + stage * B_ELEMS + pl * BN * LDBB + cb * 16 * LDBB;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)dstl, 16, 0, 0);
-            }
-        }
+        for (int t = 0; t < DMA_LOOPS; ++t)
+            lds_dma16(wrow[t] + (int64_t)ks * (BK * 2), dma_lane, wdst[t] + (uint32_t)(stage * B_STAGE * 2));
     };
 
     f32x16 acc[TM][TN];
@@ -253,21 +291,23 @@ __global__ __launch_bounds__(256) void conv_mfma_bf16_kernel(const woft_conv_par
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // lane (r32, hh) feeds k = s*16 + hh*8 + [0,8) of the step for both operands
-    const int a_off = (wm * (BM / 2) + r32) * LDB + hh * 8;
+    const __bf16* a_frag = Asm + (wm * (BM / 2) + r32) * LDB + hh * 8;
     const int sw = (r32 >> 2) & 3;
-    auto compute = [&](int stage) {
-        const __bf16* a_frag = Asm + stage * A_ELEMS + a_off;
-        const __bf16* b_rows = Bsm + stage * B_ELEMS + (wn * (BN / 2) + r32) * LDBB;
+    int b_frag[2];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int bcol = DEEP ? (((s * 2 + hh) ^ sw) * 8) : (hh * 8 + s * 16);
+    for (int s2 = 0; s2 < 2; ++s2) b_frag[s2] = (wn * (BN / 2) + r32) * 32 + (((s2 * 2 + hh) ^ sw) * 8);
+    auto compute = [&](int stage) {
+        const __bf16* af = a_frag + stage * A_STAGE;
+        const __bf16* bf = Bsm + stage * B_STAGE;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
             bf16x8 a[NP][TM], b[NP][TN];
 #pragma unroll
             for (int pl = 0; pl < NP; ++pl) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) a[pl][i] = *(const bf16x8*)(a_frag + pl * BM * LDB + i * 32 * LDB + s * 16);
+                for (int i = 0; i < TM; ++i) a[pl][i] = *(const bf16x8*)(af + pl * A_PLANE + i * 32 * LDB + s2 * 16);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) b[pl][j] = *(const bf16x8*)(b_rows + pl * BN * LDBB + j * 32 * LDBB + bcol);
+                for (int j = 0; j < TN; ++j) b[pl][j] = *(const bf16x8*)(bf + b_frag[s2] + pl * B_PLANE + j * 32 * 32);
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -282,61 +322,92 @@ __global__ __launch_bounds__(256) void conv_mfma_bf16_kernel(const woft_conv_par
         }
     };
 
-    if (!DEEP) {
-        load_a(0);
-        load_b(0);
-        store_a(0);
-        store_b();
+    tap_rows();
+    dma_b(0, 0);
+    load_a();
+    store_a(0);
+    dma_wait<0>();
+    __syncthreads();
+    int stage = 0;
+    for (int ks = 0; ks + 1 < nk; ++ks) {
+        dma_b(ks + 1, stage ^ 1);                       // lands in the idle stage while this step computes
+        advance();
+        load_a();
+        compute(stage);
+        store_a(stage ^ 1);                             // idle A stage: last read in step ks-1, a barrier ago
+        dma_wait<0>();
         __syncthreads();
-        for (int ks = 0; ks < nk; ++ks) {
-            if (ks + 1 < nk) { load_a(ks + 1); load_b(ks + 1); }
-            compute(0);
-            __syncthreads();
-            if (ks + 1 < nk) {
-                store_a(0);
-                store_b();
-                __syncthreads();
-            }
-        }
-    } else {
-        load_a(0);
-        dma_b(0, 0);
-        store_a(0);
-        __syncthreads();
-        for (int ks = 0; ks < nk; ++ks) {
-            const bool nxt = ks + 1 < nk;
-            if (nxt) {
-                dma_b(ks + 1, (ks + 1) & 1);         // lands in the idle stage while this step computes
-                load_a(ks + 1);
-            }
-            compute(ks & 1);
-            if (nxt) store_a((ks + 1) & 1);          // idle A stage: last read in step ks-1, a barrier ago
-            __syncthreads();                         // (drains the DMA)
-        }
+        stage ^= 1;
     }
-    // every path leaves the loop through a block barrier: the operand stages are dead, reuse them
+    compute(stage);
+    __syncthreads();
+    // the operand stages are dead: reuse them
     woft::conv_epilogue<BM, BN>(p, acc, (float*)smem + wave * woft::STAGE_FLOATS, m0, n0, wm, wn, lane, M, m_tile);
 }
 
-// ---- split-bf16 kernel with an LDS-resident input halo -----------------------------------------
-// Stride-1 multi-tap convolutions (3x3, 1x5, 5x1): the workgroup's M tile is a TY x TX patch of output
-// pixels of one image; for every 32-channel chunk the (TY+kh-1) x (TX+kw-1) input halo is converted
-// and written to LDS ONCE and all kh*kw taps read their A fragments from it at shifted rows, so the
-// A-side L2->LDS traffic, the fp32->bf16 splitting and the LDS writes drop by the number of taps;
-// only the weight tile is re-staged per tap.  TY x TX = 8 x 16 for images, 9 x 9 (= the whole image)
-// for the weight head's patches (weighted_raft.py:363-376).
-// One workgroup = G tiles ("groups") of TY x TX output pixels (G > 1: consecutive images, i.e. weight-head
-// patches) x BN output channels, NWAVES waves laid out WM (rows) x NWAVES/WM (columns).  The weight
-// tile staged per tap is shared by all G*TY*TX rows: the more rows, the less weight traffic per MAC.
-template <int TY, int TX, int G>
+// ---- which pixel of the TY x TX patch each MFMA tile row holds ----------------------------------
+// ds_read_b128 serves a wave in four groups of 16 lanes -- {0-3,12-15,20-27}, {4-11,16-19,28-31} and the same +32
+// -- one LDS cycle per group when the 16 addresses fall into 16 different 16-byte slots of a 256-byte line.  The
+// halo rows have an 80-byte pitch (5 slots), so two pixels collide iff their halo row indices are congruent
+// mod 16; a tap only adds a constant to all of them.  The row <-> pixel assignment is ours to choose, so it is
+// chosen per group:
+//   TX == 16: a group = the 16 pixels of ONE patch row (halo rows r .. r+15: all residues)          [tile_row_perm]
+//   9 x 9   : the 81 pixels are dealt by residue of (11 ty + tx) mod 16 -- no residue class has more than 6
+//             members, there are 6 groups -- so each group gets at most one pixel per residue             [kPerm9]
+// (rows without a pixel repeat another pixel of their group: same address = broadcast, and are never stored).
+__device__ __forceinline__ constexpr int tile_row_perm(int l) {          // lane (0..31) -> 16 * group + slot
+    return l < 4 ? l : l < 12 ? l + 12 : l < 16 ? l - 8 : l < 20 ? l + 8 : l < 28 ? l - 12 : l;
+}
+constexpr int lane_of_slot(int g, int t) {                               // inverse of tile_row_perm
+    return g == 0 ? (t < 4 ? t : t < 8 ? t + 8 : t + 12) : (t < 8 ? t + 4 : t < 12 ? t + 8 : t + 16);
+}
+struct Perm9 {
+    unsigned char v[96];                                                 // pixel index (0..80) | 0x80 if filler
+};
+constexpr Perm9 make_perm9() {
+    Perm9 t{};
+    for (int i = 0; i < 96; ++i) t.v[i] = 0xFF;
+    int cnt[16] = {};
+    for (int pix = 0; pix < 81; ++pix) {
+        const int c = ((pix / 9) * 11 + pix % 9) % 16;
+        const int k = cnt[c]++;                                          // group 0..5 = (tile k/2, half k%2)
+        t.v[(k / 2) * 32 + lane_of_slot(k % 2, c)] = (unsigned char)pix;
+    }
+    for (int k = 0; k < 6; ++k) {
+        int filler = 0;
+        for (int c = 0; c < 16; ++c)
+            if (t.v[(k / 2) * 32 + lane_of_slot(k % 2, c)] != 0xFF) { filler = t.v[(k / 2) * 32 + lane_of_slot(k % 2, c)]; break; }
+        for (int c = 0; c < 16; ++c)
+            if (t.v[(k / 2) * 32 + lane_of_slot(k % 2, c)] == 0xFF) t.v[(k / 2) * 32 + lane_of_slot(k % 2, c)] = (unsigned char)(filler | 0x80);
+    }
+    return t;
+}
+__device__ const Perm9 kPerm9 = make_perm9();
+
+// tile row (0 .. BM-1) -> pixel of the patch (ty * TX + tx) and whether the row holds a pixel at all
+template <int TY, int TX>
+__device__ __forceinline__ int halo_row_pixel(int row, bool& valid) {
+    if constexpr (TY == 9 && TX == 9) {
+        const int e = kPerm9.v[row];
+        valid = (e & 0x80) == 0;
+        return e & 0x7F;
+    } else {
+        static_assert(TX == 16, "patch width 16 or the 9x9 table");
+        const int pl = (row & ~31) + tile_row_perm(row & 31);
+        valid = pl < TY * TX;
+        return valid ? pl : 0;
+    }
+}
+
+template <int TY, int TX>
 struct HaloRowMap {
     int img0, n_img, y0, x0, ho, wo;
     __device__ __forceinline__ int64_t operator()(int row) const {
-        constexpr int NPIX = TY * TX, BMG = (NPIX + 31) / 32 * 32;
-        const int g = row / BMG, pl = row - g * BMG;
-        if (pl >= NPIX || img0 + g >= n_img) return -1;
+        bool valid;
+        const int pl = halo_row_pixel<TY, TX>(row, valid);
+        if (!valid) return -1;
         const int y = y0 + pl / TX, x = x0 + pl % TX;
-        return (y < ho && x < wo) ? ((int64_t)(img0 + g) * ho + y) * wo + x : -1;
+        return (y < ho && x < wo) ? ((int64_t)img0 * ho + y) * wo + x : -1;
     }
 };
 
@@ -467,8 +538,9 @@ __global__ __launch_bounds__(256) void conv_halo_bf16_kernel(const woft_conv_par
     const __bf16* a_frag[TM];        // output pixel (ty, tx) reads halo row (ty + ky) * HX + (tx + kx)
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        const int pl = wm * WROWS + i * 32 + r32;
-        a_frag[i] = As + ((pl < NPIX) ? (pl / TX) * HX + (pl % TX) : 0) * LDB + hh * 8;
+        bool valid;
+        const int pl = halo_row_pixel<TY, TX>(wm * WROWS + i * 32 + r32, valid);
+        a_frag[i] = As + ((pl / TX) * HX + (pl % TX)) * LDB + hh * 8;
     }
     const int sw = (r32 >> 2) & 3;
     int b_frag[2];                   // element offset of logical chunk (s*2 + hh) in this lane's B rows
@@ -494,27 +566,39 @@ __global__ __launch_bounds__(256) void conv_halo_bf16_kernel(const woft_conv_par
             if (tap == 0 && more) load_halo(chunk + 1);
             const int ky = tap / KX, kx = tap - ky * KX;
             const __bf16* bst = Bs + stage * B_STAGE;
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                bf16x8 b[NP][TN];
+            // software pipeline over the 2 * TM (k half, row tile) sub-steps: the fragments of sub-step n + 1 are
+            // requested BEFORE the MFMAs of sub-step n, so that their LDS latency hides behind this wave's own MFMAs
+            constexpr int NS = 2 * TM;
+            bf16x8 bq[2][NP][TN], aq[2][NP];
+            auto load_b = [&](int s2) {
 #pragma unroll
                 for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) b[pl][j] = *(const bf16x8*)(bst + b_frag[s2] + pl * B_PLANE + j * 32 * 32);
+                    for (int j = 0; j < TN; ++j)
+                        bq[s2 & 1][pl][j] = *(const bf16x8*)(bst + b_frag[s2] + pl * B_PLANE + j * 32 * 32);
+            };
+            auto load_a = [&](int n) {
+                const int s2 = n / TM, i = n % TM;
 #pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    bf16x8 a[NP];
+                for (int pl = 0; pl < NP; ++pl)
+                    aq[n & 1][pl] = *(const bf16x8*)(a_frag[i] + pl * A_PLANE + (ky * HX + kx) * LDB + s2 * 16);
+            };
+            load_b(0);
+            load_a(0);
 #pragma unroll
-                    for (int pl = 0; pl < NP; ++pl)
-                        a[pl] = *(const bf16x8*)(a_frag[i] + pl * A_PLANE + (ky * HX + kx) * LDB + s2 * 16);
+            for (int n = 0; n < NS; ++n) {
+                const int s2 = n / TM, i = n % TM;
+                if (n + 1 < NS) {
+                    if ((n + 1) % TM == 0) load_b(s2 + 1);
+                    load_a(n + 1);
+                }
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        if (NP == 2) {
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[NP - 1], b[0][j], acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[NP - 1][j], acc[i][j], 0, 0, 0);
-                        }
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0][j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) {
+                    if (NP == 2) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[n & 1][NP - 1], bq[s2 & 1][0][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[n & 1][0], bq[s2 & 1][NP - 1][j], acc[i][j], 0, 0, 0);
                     }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[n & 1][0], bq[s2 & 1][0][j], acc[i][j], 0, 0, 0);
                 }
             }
             if (tap == 0 && more) dma_wait<RH>();
@@ -529,7 +613,7 @@ __global__ __launch_bounds__(256) void conv_halo_bf16_kernel(const woft_conv_par
     };
     for (int chunk = 0; chunk + 1 < nchunk; ++chunk) run_chunk(chunk, std::true_type{});
     run_chunk(nchunk - 1, std::false_type{});
-    const HaloRowMap<TY, TX, 1> rowmap{img0, p.n_img, y0, x0, p.ho, p.wo};
+    const HaloRowMap<TY, TX> rowmap{img0, p.n_img, y0, x0, p.ho, p.wo};
     woft::conv_epilogue_t<TM, TN, WROWS, WCOLS>(p, acc, (float*)smem + wave * woft::STAGE_FLOATS, rowmap, n0, wm, wn,
                                                 lane, m_tile);
 }
@@ -715,17 +799,18 @@ template <int BM, int BN>
 int launch_conv(const woft_conv_params& p, hipStream_t s) {
     const int64_t M = (int64_t)p.n_img * p.ho * p.wo;
     dim3 grid((unsigned)(ceil_div64(M, BM) * (p.cout_pad / BN)));       // 1-D: see woft::tile_of_block
-    const bool deep = g_tuning[0] != 0;
-    if (p.precision == 0)
+    if (p.precision == 0) {
         hipLaunchKernelGGL((conv_mfma_f32_kernel<BM, BN>), grid, dim3(256), 0, s, p);
-    else if (p.precision == 1 && !deep)
-        hipLaunchKernelGGL((conv_mfma_bf16_kernel<BM, BN, 3, false>), grid, dim3(256), 0, s, p);
-    else if (p.precision == 1)
-        hipLaunchKernelGGL((conv_mfma_bf16_kernel<BM, BN, 3, true>), grid, dim3(256), 0, s, p);
-    else if (!deep)
-        hipLaunchKernelGGL((conv_mfma_bf16_kernel<BM, BN, 1, false>), grid, dim3(256), 0, s, p);
+        return woft_launch_status();
+    }
+    // split-bf16 kernels use 32-bit element offsets
+    const int64_t cs_max = (p.in1 != nullptr && p.cs1 > p.cs0) ? p.cs1 : p.cs0;
+    if ((int64_t)p.n_img * p.h * p.w * cs_max >= (1ll << 31)) return WOFT_EINVAL;
+    if ((int64_t)p.taps_y * p.taps_x * p.cin_pad >= (1 << 20)) return WOFT_EINVAL;
+    if (p.precision == 1)
+        hipLaunchKernelGGL((conv_mfma_bf16_kernel<BM, BN, 3>), grid, dim3(256), 0, s, p);
     else
-        hipLaunchKernelGGL((conv_mfma_bf16_kernel<BM, BN, 1, true>), grid, dim3(256), 0, s, p);
+        hipLaunchKernelGGL((conv_mfma_bf16_kernel<BM, BN, 1>), grid, dim3(256), 0, s, p);
     return woft_launch_status();
 }
 

@@ -1,0 +1,120 @@
+// 3x3 stride-1 "same" convolution with one or two output channels, exact fp32 on the vector ALUs.
+//
+// The flow head's second conv (update.py:10-17: 256 -> 2; small model 128 -> 2) has GEMM N = 2: on the matrix
+// cores it pays for a 64-column tile (97 % padding) and, worse, runs one long serial K loop per workgroup.  Here
+// a wave owns a run of 16 output pixels of one image row; lane L holds CPL = cin / 64 consecutive input channels
+// and the 9 x COUT x CPL weights of those channels in registers.  The three input columns of the 3x3 window
+// slide along the run (each new column = 3 loads of CPL floats per lane, one full channel vector per wave
+// instruction), so an input pixel is read three times in total instead of nine.  Each output is the sum of the 64
+// per-lane partial sums (xor butterfly).
+#include "common.h"
+
+namespace {
+
+template <int CPL>
+struct Vec;
+template <>
+struct Vec<4> { typedef float T __attribute__((ext_vector_type(4))); };
+template <>
+struct Vec<2> { typedef float T __attribute__((ext_vector_type(2))); };
+
+constexpr int RUN = 16;
+
+template <int COUT, int CPL>
+__global__ __launch_bounds__(256) void conv3x3_narrow_kernel(const float* __restrict__ in, int cs, int n_img, int h, int w,
+                                                             const float* __restrict__ wgt, int ktot, int cin_pad,
+                                                             const float* __restrict__ bias, float* __restrict__ out,
+                                                             int64_t ldo, int co_off) {
+    typedef typename Vec<CPL>::T vec;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int runs_per_row = (w + RUN - 1) / RUN;
+    const int64_t run = (int64_t)blockIdx.x * 4 + wave;
+    if (run >= (int64_t)n_img * h * runs_per_row) return;
+    const int xr = (int)(run % runs_per_row);
+    const int y = (int)((run / runs_per_row) % h);
+    const int img = (int)(run / ((int64_t)runs_per_row * h));
+    const int x0 = xr * RUN;
+
+    // weights of this lane's channels: wv[o][tap]  (packed weight row o: k = tap * cin_pad + c)
+    vec wv[COUT][9];
+#pragma unroll
+    for (int o = 0; o < COUT; ++o)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wv[o][t] = *(const vec*)(wgt + (int64_t)o * ktot + t * cin_pad + CPL * lane);
+
+    const float* base = in + ((int64_t)img * h * w) * cs + CPL * lane;
+    auto load_col = [&](int x, vec (&col)[3]) {          // rows y-1, y, y+1 of column x (zero outside the image)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int yy = y + ky - 1;
+            const bool ok = x >= 0 && x < w && yy >= 0 && yy < h;
+            const vec val = *(const vec*)(base + (ok ? ((int64_t)yy * w + x) * cs : 0));
+            col[ky] = ok ? val : (vec)(0.f);
+        }
+    };
+
+    // four column buffers used round-robin: step k reads columns (k, k+1, k+2) mod 4 = x-1, x, x+1 and prefetches
+    // x+2 into (k+3) mod 4, so the names come back after four pixels and the run loop stays rolled (few registers:
+    // all waves of a 1/8-resolution 1080p frame are resident at once)
+    vec cb[4][3];
+    load_col(x0 - 1, cb[0]);
+    load_col(x0, cb[1]);
+    load_col(x0 + 1, cb[2]);
+    const float b0 = bias ? bias[0] : 0.f, b1 = (bias && COUT > 1) ? bias[COUT - 1] : 0.f;
+    float* orow = out + (((int64_t)img * h + y) * w) * ldo + co_off;
+#pragma unroll 1
+    for (int i0 = 0; i0 < RUN; i0 += 4) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int x = x0 + i0 + k;
+            load_col(x + 2, cb[(k + 3) & 3]);            // in flight while this pixel is accumulated
+            const vec(&l)[3] = cb[k & 3];
+            const vec(&m)[3] = cb[(k + 1) & 3];
+            const vec(&r)[3] = cb[(k + 2) & 3];
+            float s[COUT];
+#pragma unroll
+            for (int o = 0; o < COUT; ++o) {
+                float t = 0.f;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int e = 0; e < CPL; ++e) {
+                        t = fmaf(wv[o][ky * 3 + 0][e], l[ky][e], t);
+                        t = fmaf(wv[o][ky * 3 + 1][e], m[ky][e], t);
+                        t = fmaf(wv[o][ky * 3 + 2][e], r[ky][e], t);
+                    }
+                s[o] = t;
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1)
+#pragma unroll
+                for (int o = 0; o < COUT; ++o) s[o] += __shfl_xor(s[o], d, 64);
+            if (lane == 0 && x < w) {
+                orow[(int64_t)x * ldo] = s[0] + b0;
+                if (COUT > 1) orow[(int64_t)x * ldo + COUT - 1] = s[COUT - 1] + b1;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int woft_conv3x3_narrow(const float* in, int32_t cs, int32_t n_img, int32_t h, int32_t w, int32_t cin_pad,
+                                   const float* wgt, const float* bias, int32_t cout, float* out, int64_t ldo,
+                                   int32_t co_off, void* stream) {
+    if (!in || !wgt || !out || n_img <= 0 || h <= 0 || w <= 0) return WOFT_EINVAL;
+    if ((cin_pad != 256 && cin_pad != 128) || cs < cin_pad || cs % 4 != 0) return WOFT_EINVAL;
+    if (cout < 1 || cout > 2 || co_off < 0 || ldo < co_off + cout) return WOFT_EINVAL;
+    const int64_t runs = (int64_t)n_img * h * ((w + RUN - 1) / RUN);
+    dim3 grid((unsigned)ceil_div64(runs, 4));
+    const int ktot = 9 * cin_pad;
+    hipStream_t s = (hipStream_t)stream;
+#define NARROW(CO, CPL) \
+    hipLaunchKernelGGL((conv3x3_narrow_kernel<CO, CPL>), grid, dim3(256), 0, s, in, cs, n_img, h, w, wgt, ktot, cin_pad, \
+                       bias, out, ldo, co_off)
+    if (cin_pad == 256) { if (cout == 2) NARROW(2, 4); else NARROW(1, 4); }
+    else { if (cout == 2) NARROW(2, 2); else NARROW(1, 2); }
+#undef NARROW
+    return woft_launch_status();
+}

@@ -319,7 +319,8 @@ class _Plan:
         if len(e.zr) == 1 and not first:
             prog.append(("copy", (self.hA.t, self.hB.t)))
         prog += [("conv", cp(self.hB, e.fh1, self.fh, epi=EPI.EPI_RELU)),
-                 ("conv", cp(self.fh, e.fh2, self.delta)),
+                 (("narrow", (self.fh, e.fh2, self.delta)) if ops.narrow_ok(self.fh, e.fh2)
+                  else ("conv", cp(self.fh, e.fh2, self.delta))),
                  ("coords", None)]
         return prog
 
@@ -342,6 +343,8 @@ class _Plan:
                 ops.tile_rows(a[0], a[1])
             elif kind == "cgemm":
                 ops.corr_gemm_bf16(*a)
+            elif kind == "narrow":
+                ops.conv3x3_narrow(*a)
             elif kind == "lookup":
                 self._lookup(a)
             elif kind == "copy":

@@ -256,6 +256,20 @@ def split_bf16(x, hi, lo=None):
     check(_lib.load().woft_split_bf16(ptr(x), x.numel(), ptr(hi), ptr(lo), stream_ptr()), "woft_split_bf16")
 
 
+def conv3x3_narrow(x, pc, out, co_off=0):
+    """3x3 / stride 1 / pad 1 conv with cout <= 2 in exact fp32 (woft_conv3x3_narrow); x, out: Act."""
+    assert (pc.taps_y, pc.taps_x, pc.stride, pc.pad_y, pc.pad_x, pc.flat) == (3, 3, 1, 1, 1, 0) and pc.cout <= 2
+    assert out.n == x.n and out.h == x.h and out.w == x.w
+    check(_lib.load().woft_conv3x3_narrow(ptr(x.t), x.cs, x.n, x.h, x.w, pc.cin_pad, ptr(pc.wgt), ptr(pc.bias), pc.cout,
+                                          ptr(out.t), out.cs, co_off, stream_ptr()), "woft_conv3x3_narrow")
+
+
+def narrow_ok(x, pc):
+    """True when woft_conv3x3_narrow applies to this layer."""
+    return ((pc.taps_y, pc.taps_x, pc.stride, pc.pad_y, pc.pad_x, pc.flat) == (3, 3, 1, 1, 1, 0) and pc.cout <= 2
+            and pc.cin_pad in (128, 256) and x.cs >= pc.cin_pad)
+
+
 def split_bf16_lines(x, out):
     """x fp32 [rows][k] -> out bf16 [rows][2k]: per 32 values one 128-byte line [hi | lo] (woft_split_bf16_lines)."""
     check(_lib.load().woft_split_bf16_lines(ptr(x), x.numel(), ptr(out), stream_ptr()), "woft_split_bf16_lines")
