@@ -47,7 +47,10 @@ enum woft_epilogue {
                                    n >= split: out1[m][n-split] = sigmoid(y) * e0[m][n-split] (r*h)
                                    update.py:47-50 */
     WOFT_EPI_GRU_Q = 6,         /* out = (1-z)*h + z*tanh(y), h = e0, z = e1   update.py:50-51 */
-    WOFT_EPI_CTX = 7            /* n < split: tanh(y) else relu(y)   weighted_raft.py:217-219   */
+    WOFT_EPI_CTX = 7,           /* n < split: tanh(y) else relu(y)   weighted_raft.py:217-219   */
+    WOFT_EPI_WH_MEAN = 8        /* halo 2 (9x9 patches), one N tile: out[image] = e1[0] + mean over the 81 pixels of
+                                   <e0[0..cout), relu(y)> -- the weight head's last ReLU, 1x1 conv and patch mean
+                                   (weighted_raft.py:341,378-383) without writing the activation               */
 };
 
 typedef struct woft_conv_params {
@@ -164,8 +167,14 @@ int woft_coords_init(float* coords1, int32_t hf, int32_t wf, float* flow4, float
  *   algebraic form) and the head's input patches (weighted_raft.py:267-272, 363-376):
  *   x8[p][hp][wp][0..3] = lookup[p][(hp*nwin + wp)*4 + 0..3], x8[..][4] = mean[p], x8[..][5..7] = 0.
  * woft_wh_reduce: final 1x1 conv + mean over the patch (weighted_raft.py:341,378-383):
- *   out[p] = bias + mean_t <w, act[p][t][:]> */
+ *   out[p] = bias + mean_t <w, act[p][t][:]>
+ * woft_wh_pack with x8 == NULL computes mean[] only.
+ * woft_wh_conv0: the head's first conv + ReLU (weighted_raft.py:336; 5 -> 128 channels, 3x3, zero padding) straight
+ *   from the lookup buffer and mean[] (same input definition as x8), exact fp32:
+ *   out[p][hp][wp][0..127]; wt: fp32 [96][128], wt[(ky*32 + kx*8 + ci)*128 + co]; nwin in {7, 9}. */
 int woft_colsum(const float* f, int64_t n_pix, int32_t c, double* ws, int32_t n_part, double* total, void* stream);
+int woft_wh_conv0(const float* lookup, int32_t ld_lookup, const float* mean, int64_t n_pix, int32_t nwin,
+                  const float* wt, const float* bias, float* out, void* stream);
 int woft_wh_pack(const float* lookup, int32_t ld_lookup, const float* f1, int32_t c, const double* f2_total,
                  float alpha, int64_t n_pix, int32_t nwin, float* mean, float* x8, void* stream);
 int woft_wh_reduce(const float* act, int32_t c, int32_t nwin2, const float* w, float bias,

@@ -64,6 +64,55 @@ def test_conv_plain(ops, cin, cout, k, stride, h, w, tiles, precision, tol):
     assert float(big.t[:, :8].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("precision,tol", [("bf16x3", 2e-5), ("bf16", 2e-2)])
+def test_wh_mean_epilogue(ops, precision, tol):
+    """Last weight-head layer with ReLU + 1x1 conv + patch mean fused into the whole-patch kernel's epilogue
+    (weighted_raft.py:340-341,378-383): one float per patch, the activation is never stored."""
+    n_patch = 53
+    x = F.relu(_rand(n_patch, 128, 9, 9, seed=81))
+    wt = _rand(128, 128, 3, 3, seed=82, scale=1 / math.sqrt(128 * 9))
+    b = _rand(128, seed=83, scale=0.1)
+    w6, b6 = _rand(128, seed=84, scale=0.2), 0.37
+    act = F.relu(F.conv2d(x.double(), wt.double(), b.double(), padding=1))
+    ref = (act * w6.double().view(1, 128, 1, 1)).sum(1).mean(dim=(1, 2)) + b6
+    pc = ops.pack_conv(wt, b)
+    xa = ops.act_from_nchw(x)
+    dummy = ops.new_act(n_patch, 9, 9, 128, zero=True)
+    p = ops.conv_params(xa, pc, dummy, epi=ops._lib.EPI_RELU, precision=precision)
+    assert p.halo == 2
+    out = torch.full((n_patch,), -7.0, device="cuda")
+    w6d, b6d = w6.cuda(), torch.tensor([b6], device="cuda")
+    p.epi = ops._lib.EPI_WH_MEAN
+    p.e0, p.e1 = ops.ptr(w6d), ops.ptr(b6d)
+    p.out, p.ldo, p.co_off = ops.ptr(out), 1, 0
+    ops.run_conv(p)
+    torch.cuda.synchronize()
+    _close(out, ref.float(), tol, what="wh mean epilogue")
+    assert float(dummy.t.abs().max()) == 0.0              # nothing else was written
+
+
+@pytest.mark.parametrize("n", [9, 7])
+def test_wh_conv0(ops, n):
+    """First weight-head conv (weighted_raft.py:336) straight from the lookup buffer: input channels are the
+    (hp wp level) re-read of the level-major lookup row (weighted_raft.py:267-272) + the mean channel."""
+    P = 37
+    lookup = _rand(P, 4 * n * n + 28, seed=71, scale=3.0)
+    mean = _rand(P, seed=72)
+    w0 = _rand(128, 5, 3, 3, seed=73, scale=1 / math.sqrt(45))
+    b0 = _rand(128, seed=74, scale=0.1)
+    x = torch.cat([lookup[:, :4 * n * n].reshape(P, n, n, 4).permute(0, 3, 1, 2), mean.view(P, 1, 1, 1).expand(P, 1, n, n)], 1)
+    ref = F.relu(F.conv2d(x.double(), w0.double(), b0.double(), padding=1)).float()
+    pc = ops.pack_conv(w0, b0, flat_cs=8)
+    wt = pc.wgt[:128].t().contiguous()
+    out = torch.zeros(P, n, n, 128, device="cuda")
+    lib = ops._lib.load()
+    lk, mn = lookup.cuda().contiguous(), mean.cuda().contiguous()
+    ops.check(lib.woft_wh_conv0(ops.ptr(lk), lk.shape[1], ops.ptr(mn), P, n, ops.ptr(wt), ops.ptr(pc.bias), ops.ptr(out),
+                                ops.stream_ptr()), "woft_wh_conv0")
+    torch.cuda.synchronize()
+    _close(out.permute(0, 3, 1, 2), ref, 3e-6, rtol=3e-6, what="wh conv0")
+
+
 @pytest.mark.parametrize("cin,cout,h,w", [(256, 2, 19, 37), (256, 1, 5, 16), (128, 2, 17, 33), (256, 2, 3, 3)])
 def test_conv3x3_narrow(ops, cin, cout, h, w):
     """Flow head conv2 (update.py:10-17) on the vector ALUs: exact fp32 products, written at a channel offset."""

@@ -32,6 +32,16 @@ def main():
              ("iter", plan.prog_iter, 12), ("mask", [("conv", p) for p in plan.prog_mask], 1),
              ("wh", [("conv", p) for p in plan.prog_wh], 1)]
     total = 0.0
+    if getattr(plan, "wh0_direct", False):
+        from woft_amd import _lib
+        lib = _lib.load()
+        n = eng.spec.nwin
+        progs.append(("wh0", [("call", lambda: _lib.check(lib.woft_wh_conv0(
+            _lib.ptr(plan.corr.t), plan.corr.cs, _lib.ptr(plan.wmean), plan.P, n, _lib.ptr(plan.wh0_t),
+            _lib.ptr(eng.wh0.bias), _lib.ptr(plan.a1.t), _lib.stream_ptr()), "wh_conv0"))], 1))
+        progs.append(("whred", [("call", lambda: _lib.check(lib.woft_wh_reduce(
+            _lib.ptr(plan.a1.t), 128, n * n, _lib.ptr(eng.wh6_w), eng.wh6_b, plan.P, _lib.ptr(plan.wlow),
+            _lib.stream_ptr()), "wh_reduce"))], 1))
     for name, prog, mult in progs:
         sub = 0.0
         for idx, (kind, arg) in enumerate(prog):
@@ -39,7 +49,7 @@ def main():
             for _ in range(5):
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 s.record()
-                plan.run([(kind, arg)])
+                arg() if kind == "call" else plan.run([(kind, arg)])
                 e.record()
                 torch.cuda.synchronize()
                 ts.append(s.elapsed_time(e))

@@ -12,7 +12,7 @@ import torch  # noqa: F401  (must precede the CDLL so both share one HIP runtime
 
 LIB_PATH = Path(__file__).resolve().parent / "lib" / "libwoft_hip.so"
 
-EPI_LINEAR, EPI_RELU, EPI_SIGMOID, EPI_TANH, EPI_RELU_RES_RELU, EPI_GRU_ZR, EPI_GRU_Q, EPI_CTX = range(8)
+EPI_LINEAR, EPI_RELU, EPI_SIGMOID, EPI_TANH, EPI_RELU_RES_RELU, EPI_GRU_ZR, EPI_GRU_Q, EPI_CTX, EPI_WH_MEAN = range(9)
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -57,6 +57,7 @@ _SIGS = {
     "woft_coords_init": (i32, [vp, i32, i32, vp, vp, i32, vp]),
     "woft_colsum": (i32, [vp, i64, i32, vp, i32, vp, vp]),
     "woft_wh_pack": (i32, [vp, i32, vp, i32, vp, f32, i64, i32, vp, vp, vp]),
+    "woft_wh_conv0": (i32, [vp, i32, vp, i64, i32, vp, vp, vp, vp]),
     "woft_wh_reduce": (i32, [vp, i32, i32, vp, f32, i64, vp, vp]),
     "woft_convex_upsample": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, i32, vp]),
     "woft_upflow8": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, i32, vp]),

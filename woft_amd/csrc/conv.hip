@@ -383,6 +383,16 @@ constexpr Perm9 make_perm9() {
     return t;
 }
 __device__ const Perm9 kPerm9 = make_perm9();
+struct Perm9Mask {
+    unsigned m[3];                                                       // bit r of m[i]: row r of tile i holds a pixel
+};
+constexpr Perm9Mask make_perm9_mask() {
+    const Perm9 t = make_perm9();
+    Perm9Mask k{};
+    for (int i = 0; i < 96; ++i)
+        if ((t.v[i] & 0x80) == 0) k.m[i / 32] |= 1u << (i % 32);
+    return k;
+}
 
 // tile row (0 .. BM-1) -> pixel of the patch (ty * TX + tx) and whether the row holds a pixel at all
 template <int TY, int TX>
@@ -613,6 +623,38 @@ __global__ __launch_bounds__(256) void conv_halo_bf16_kernel(const woft_conv_par
     };
     for (int chunk = 0; chunk + 1 < nchunk; ++chunk) run_chunk(chunk, std::true_type{});
     run_chunk(nchunk - 1, std::false_type{});
+    if constexpr (TY == 9 && TX == 9) {
+        if (p.epi == WOFT_EPI_WH_MEAN) {
+            // weight-head tail fused (weighted_raft.py:341,378-383): this workgroup holds relu(conv) of one whole
+            // patch, all channels: out[image] = e1[0] + mean_pixels <e0, relu(y)> -- the 1.3 GB activation is never
+            // written.  Accumulator layout: column = r32, row = (r & 3) + 8 (r >> 2) + 4 hh of tile i.
+            constexpr Perm9Mask vm = make_perm9_mask();
+            float part = 0.f;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * WCOLS + j * 32 + r32;
+                const bool nok = n < p.cout;
+                const float wv = nok ? p.e0[n] : 0.f;
+                const float bv = (nok && p.bias != nullptr) ? p.bias[n] : 0.f;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                        const bool valid = (vm.m[wm * TM + i] >> row) & 1u;
+                        const float y = fmaxf(p.alpha * acc[i][j][r] + bv, 0.f);
+                        part += valid ? wv * y : 0.f;
+                    }
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
+            float* red = (float*)smem;                   // (operand stages are dead after the loop's last barrier)
+            if (lane == 0) red[wave] = part;
+            __syncthreads();
+            if (tid == 0) p.out[img0] = p.e1[0] + (red[0] + red[1] + red[2] + red[3]) * (1.f / 81.f);
+            return;
+        }
+    }
     const HaloRowMap<TY, TX> rowmap{img0, p.n_img, y0, x0, p.ho, p.wo};
     woft::conv_epilogue_t<TM, TN, WROWS, WCOLS>(p, acc, (float*)smem + wave * woft::STAGE_FLOATS, rowmap, n0, wm, wn,
                                                 lane, m_tile);
@@ -834,7 +876,10 @@ extern "C" int woft_conv2d(const woft_conv_params* pp, void* stream) {
         return WOFT_EINVAL;
     if ((p.tile_m != 64 && p.tile_m != 128) || (p.tile_n != 64 && p.tile_n != 128)) return WOFT_EINVAL;
     if (p.cout_pad % p.tile_n != 0 || p.cout > p.cout_pad) return WOFT_EINVAL;
-    if (p.epi < 0 || p.epi > WOFT_EPI_CTX) return WOFT_EINVAL;
+    if (p.epi < 0 || p.epi > WOFT_EPI_WH_MEAN) return WOFT_EINVAL;
+    if (p.epi == WOFT_EPI_WH_MEAN && (p.halo != 2 || p.cout_pad != p.tile_n || p.e0 == nullptr || p.e1 == nullptr ||
+                                      p.stat_sum != nullptr))
+        return WOFT_EINVAL;
     if ((p.epi == WOFT_EPI_RELU_RES_RELU || p.epi == WOFT_EPI_GRU_ZR || p.epi == WOFT_EPI_GRU_Q) && p.e0 == nullptr)
         return WOFT_EINVAL;
     if (p.epi == WOFT_EPI_GRU_Q && p.e1 == nullptr) return WOFT_EINVAL;

@@ -73,7 +73,76 @@ __global__ __launch_bounds__(256) void wh_reduce_kernel(const float* __restrict_
     if (lane == 0) out[p] = bias + s / (float)nwin2;
 }
 
+// First conv of the weight head (weighted_raft.py:336: 5 -> 128 channels, 3x3, ReLU) on the NW x NW lookup window
+// of every source pixel, exact fp32 on the vector ALUs, reading the lookup buffer directly (no packed copy):
+//   x[t][0..3] = lookup[p][4 t .. 4 t + 3]   (the reference reads the level-major channels as (hp wp level),
+//   x[t][4]    = mean[p]                       weighted_raft.py:267-272, 363-376)
+// GEMM K is only 45, the output is 1.3 GB at 1080p: the matrix-core kernel is launch/epilogue bound on it.  Here a
+// lane owns ONE output channel (its 45 weights live in registers) and a wave walks over the window; the window
+// values are wave-uniform, so they are fetched by SCALAR loads and enter the FMAs as scalar operands -- no LDS, no
+// vector loads.  Each wave instruction stores 256 contiguous bytes of one pixel's channel vector.
+template <int NW>
+__global__ __launch_bounds__(256) void wh_conv0_kernel(const float* __restrict__ lookup, int ld,
+                                                       const float* __restrict__ mean, int n_pix,
+                                                       const float* __restrict__ wt, const float* __restrict__ b0,
+                                                       float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int co = (wave & 1) * 64 + lane;
+    float w[3][3][5];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int ci = 0; ci < 5; ++ci) w[ky][kx][ci] = wt[(ky * 32 + kx * 8 + ci) * 128 + co];
+    const float bias = b0[co];
+    for (int p = blockIdx.x * 2 + (wave >> 1); p < n_pix; p += gridDim.x * 2) {
+        const float* __restrict__ lk = lookup + (int64_t)p * ld;
+        const float mv = mean[p];
+        float* __restrict__ o = out + (int64_t)p * (NW * NW * 128) + co;
+#pragma unroll 1
+        for (int y = 0; y < NW; ++y) {
+#pragma unroll
+            for (int x = 0; x < NW; ++x) {
+                float acc = bias;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int yy = y + ky - 1;
+                    if (yy < 0 || yy >= NW) continue;                  // (wave-uniform)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int xx = x + kx - 1;
+                        if (xx < 0 || xx >= NW) continue;              // (compile time)
+                        const float* xv = lk + (yy * NW + xx) * 4;
+                        acc = fmaf(w[ky][kx][0], xv[0], acc);
+                        acc = fmaf(w[ky][kx][1], xv[1], acc);
+                        acc = fmaf(w[ky][kx][2], xv[2], acc);
+                        acc = fmaf(w[ky][kx][3], xv[3], acc);
+                        acc = fmaf(w[ky][kx][4], mv, acc);
+                    }
+                }
+                o[(y * NW + x) * 128] = fmaxf(acc, 0.f);
+            }
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int woft_wh_conv0(const float* lookup, int32_t ld_lookup, const float* mean, int64_t n_pix, int32_t nwin,
+                             const float* wt, const float* bias, float* out, void* stream) {
+    if (!lookup || !mean || !wt || !bias || !out || n_pix <= 0 || n_pix >= (1ll << 31)) return WOFT_EINVAL;
+    if (ld_lookup < nwin * nwin * 4 || (nwin != 9 && nwin != 7)) return WOFT_EINVAL;
+    const int64_t pairs = (n_pix + 1) / 2;
+    dim3 grid((unsigned)(pairs < 256 * 8 ? pairs : 256 * 8));
+    hipStream_t s = (hipStream_t)stream;
+    if (nwin == 9)
+        hipLaunchKernelGGL(wh_conv0_kernel<9>, grid, dim3(256), 0, s, lookup, ld_lookup, mean, (int)n_pix, wt, bias, out);
+    else
+        hipLaunchKernelGGL(wh_conv0_kernel<7>, grid, dim3(256), 0, s, lookup, ld_lookup, mean, (int)n_pix, wt, bias, out);
+    return woft_launch_status();
+}
 
 extern "C" int woft_colsum(const float* f, int64_t n_pix, int32_t c, double* ws, int32_t n_part, double* total,
                            void* stream) {
@@ -86,11 +155,12 @@ extern "C" int woft_colsum(const float* f, int64_t n_pix, int32_t c, double* ws,
 
 extern "C" int woft_wh_pack(const float* lookup, int32_t ld_lookup, const float* f1, int32_t c, const double* f2_total,
                             float alpha, int64_t n_pix, int32_t nwin, float* mean, float* x8, void* stream) {
-    if (!lookup || !f1 || !f2_total || !mean || !x8 || n_pix <= 0 || nwin <= 0 || c <= 0) return WOFT_EINVAL;
+    if (!lookup || !f1 || !f2_total || !mean || n_pix <= 0 || nwin <= 0 || c <= 0) return WOFT_EINVAL;
     if (ld_lookup < nwin * nwin * 4 || ld_lookup % 4 != 0) return WOFT_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(wh_mean_kernel, dim3((unsigned)ceil_div64(n_pix, 4)), dim3(256), 0, s, f1, c, f2_total, alpha,
                        n_pix, mean);
+    if (x8 == nullptr) return woft_launch_status();     // mean only (woft_wh_conv0 reads the lookup buffer itself)
     const int64_t n = n_pix * nwin * nwin;
     hipLaunchKernelGGL(wh_pack_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, s, lookup, ld_lookup, mean,
                        n_pix, nwin * nwin, x8);

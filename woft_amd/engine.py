@@ -223,9 +223,21 @@ class _Plan:
             self.wlow = z(P)
             self.cs_ws = torch.zeros(256, sp.fdim, dtype=torch.float64, device=dev)
             self.cs_tot = torch.zeros(sp.fdim, dtype=torch.float64, device=dev)
-            self.prog_wh = [cp(self.x8, eng.wh0, self.a1, epi=EPI.EPI_RELU),
+            # first conv (5 -> 128): scalar-operand VALU kernel straight from the lookup buffer for the 7x7 / 9x9
+            # windows (woft_wh_conv0), the generic conv on the packed x8 patches otherwise
+            self.wh0_direct = n in (7, 9)
+            self.prog_wh = ([] if self.wh0_direct else [cp(self.x8, eng.wh0, self.a1, epi=EPI.EPI_RELU)]) + [
                             cp(self.a1, eng.wh2, self.a2, epi=EPI.EPI_RELU),
                             cp(self.a2, eng.wh4, self.a1, epi=EPI.EPI_RELU)]
+            self.wh0_t = eng.wh0.wgt[:128].t().contiguous()          # [ky*32 + kx*8 + ci][co]
+            # last layer on the whole-patch kernel: ReLU + 1x1 conv + patch mean fused into its epilogue
+            last = self.prog_wh[-1]
+            self.wh_fused = last.halo == 2
+            if self.wh_fused:
+                self.wh6_b = torch.tensor([eng.wh6_b], dtype=torch.float32, device=dev)
+                last.epi = EPI.EPI_WH_MEAN
+                last.e0, last.e1 = _lib.ptr(eng.wh6_w), _lib.ptr(self.wh6_b)
+                last.out, last.ldo, last.co_off = _lib.ptr(self.wlow), 1, 0
 
     def _cp(self, *a, **kw):
         kw.setdefault("precision", self.prec)
@@ -407,11 +419,17 @@ class _Plan:
                                        _lib.ptr(self.cs_tot), _lib.stream_ptr()), "woft_colsum")
             _lib.check(lib.woft_wh_pack(_lib.ptr(self.corr.t), self.corr.cs, _lib.ptr(self.f1.t), sp.fdim,
                                         _lib.ptr(self.cs_tot), 1.0 / (math.sqrt(float(sp.fdim)) * self.P), self.P, n,
-                                        _lib.ptr(self.wmean), _lib.ptr(self.x8.t), _lib.stream_ptr()), "woft_wh_pack")
+                                        _lib.ptr(self.wmean), None if self.wh0_direct else _lib.ptr(self.x8.t),
+                                        _lib.stream_ptr()), "woft_wh_pack")
+            if self.wh0_direct:
+                _lib.check(lib.woft_wh_conv0(_lib.ptr(self.corr.t), self.corr.cs, _lib.ptr(self.wmean), self.P, n,
+                                             _lib.ptr(self.wh0_t), _lib.ptr(e.wh0.bias), _lib.ptr(self.a1.t),
+                                             _lib.stream_ptr()), "woft_wh_conv0")
             for p in self.prog_wh:
                 ops.run_conv(p)
-            _lib.check(lib.woft_wh_reduce(_lib.ptr(self.a1.t), 128, n * n, _lib.ptr(e.wh6_w), e.wh6_b, self.P,
-                                          _lib.ptr(self.wlow), _lib.stream_ptr()), "woft_wh_reduce")
+            if not self.wh_fused:
+                _lib.check(lib.woft_wh_reduce(_lib.ptr(self.a1.t), 128, n * n, _lib.ptr(e.wh6_w), e.wh6_b, self.P,
+                                              _lib.ptr(self.wlow), _lib.stream_ptr()), "woft_wh_reduce")
             wlow = self.wlow
         wout = wout if e.weighted else None
         if sp.small:                                                 # no mask head: bilinear x8 (utils.py:82-84)
