@@ -190,6 +190,11 @@ int woft_wh_reduce(const float* act, int32_t c, int32_t nwin2, const float* w, f
 int woft_convex_upsample(const float* coords1, const float* wlow, const float* mask, int32_t ld_mask,
                          int32_t hf, int32_t wf, int32_t crop_top, int32_t crop_left, int32_t h, int32_t w,
                          float* flow_up, float* dst, float* wout, int32_t do_sigmoid, void* stream);
+/* Pre-computed flow read from the reference's cache files (utils/caching.py:53-59; raft.py:93-106) to the same
+ * outputs: dst[2][h*w] = pixel grid + flow[2][h*w] (may be NULL), wout[h*w] = weights or sigmoid(weights)
+ * (weights / wout may be NULL). */
+int woft_flow_to_tc(const float* flow, const float* weights, int32_t h, int32_t w, float* dst, float* wout,
+                    int32_t do_sigmoid, void* stream);
 /* bilinear x8 upsampling, align_corners=True, times 8 (utils/utils.py:82-84), same outputs. */
 int woft_upflow8(const float* coords1, const float* wlow, int32_t hf, int32_t wf,
                  int32_t crop_top, int32_t crop_left, int32_t h, int32_t w,

@@ -177,3 +177,35 @@ def test_reduced_precision_operating_points(golden_dir, precision, epe_mean, epe
     print(f"{precision}: EPE mean {m:.2e} max {mx:.2e}")
     assert m < epe_mean and mx < epe_max, (m, mx)
     assert float((w.cpu() - torch.sigmoid(torch.from_numpy(g["w_up"])[0])).abs().max()) < wtol
+
+
+@torch.no_grad()
+def test_cached_flow_wire_format(tmp_path):
+    """Pre-computed flow (utils/caching.py:53-59: '<i>-<i+1>.npz' with fp16 'half_flow' / 'half_weights') goes
+    through the same TC / sigmoid post-processing as a computed one (raft.py:92-109,152-195); a missing file falls
+    back to computing the flow."""
+    h, w = 128, 160
+    rng = np.random.RandomState(5)
+    flow = (rng.randn(2, h, w) * 3).astype(np.float16)
+    wts = rng.randn(1, h, w).astype(np.float16)
+    d = tmp_path / "ds" / "seq"
+    d.mkdir(parents=True)
+    np.savez(d / "7-8.npz", half_flow=flow, half_weights=wts)
+    sd = synth.make_state_dict(seed=3)
+    c = _flow_config(sd, 2)
+    c.flow_cache_dir = tmp_path
+    prov = c.of_class(c)
+    img = synth.make_template(h, w, seq_id=1)
+    src, dst, wout = prov.compute_flow(img, img, mode="TC", src_img_identifier=("ds", "seq", 7), do_sigmoid=True,
+                                       numpy_out=True)
+    ys, xs = np.mgrid[0:h, 0:w]
+    grid = np.stack([xs.ravel(), ys.ravel()]).astype(np.float32)
+    assert np.array_equal(src, grid.astype(src.dtype))
+    assert np.array_equal(dst, grid + flow.astype(np.float32).reshape(2, -1))
+    np.testing.assert_allclose(wout, 1 / (1 + np.exp(-wts.astype(np.float32).reshape(1, -1))), rtol=0, atol=1e-6)
+    fl, wl = prov.compute_flow(img, img, mode="flow", src_img_identifier=("ds", "seq", 7), numpy_out=True)
+    assert np.array_equal(fl, flow.astype(np.float32)) and np.array_equal(wl, wts.astype(np.float32))
+    # no file for this pair: the flow is computed, exactly as without an identifier
+    _, dst2, w2 = prov.compute_flow(img, img, mode="TC", src_img_identifier=("ds", "seq", 9), numpy_out=True)
+    _, dst3, w3 = prov.compute_flow(img, img, mode="TC", numpy_out=True)
+    assert dst2.shape == (2, h * w) and np.array_equal(dst2, dst3) and np.array_equal(w2, w3)

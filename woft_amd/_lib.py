@@ -45,6 +45,7 @@ _SIGS = {
     "woft_conv2d": (i32, [C.POINTER(ConvParams), vp]),
     "woft_split_bf16": (i32, [vp, i64, vp, vp, vp]),
     "woft_split_bf16_lines": (i32, [vp, i64, vp, vp]),
+    "woft_flow_to_tc": (i32, [vp, vp, i32, i32, vp, vp, i32, vp]),
     "woft_conv3x3_narrow": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, i64, i32, vp]),
     "woft_corr_gemm_bf16": (i32, [vp, vp, i64, i64, i64, i64, i32, f32, vp, i64, i32, vp]),
     "woft_inorm_finalize": (i32, [vp, vp, i32, i32, i32, i32, i64, f32, vp, vp, vp]),

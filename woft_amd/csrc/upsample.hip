@@ -170,6 +170,21 @@ __global__ void resize_linear_kernel(const uint8_t* __restrict__ img, int h, int
     }
 }
 
+
+// Pre-computed flow (utils/caching.py:53-59 -> raft.py:93-106,159-195) to the provider's outputs:
+// dst[0][i] = x + flow[0][i], dst[1][i] = y + flow[1][i], wout[i] = weights[i] or sigmoid(weights[i])
+__global__ void flow_to_tc_kernel(const float* __restrict__ flow, const float* __restrict__ wts, int h, int w,
+                                  float* __restrict__ dst, float* __restrict__ wout, int do_sigmoid) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n = (int64_t)h * w;
+    if (i >= n) return;
+    if (dst != nullptr) {
+        dst[i] = (float)(i % w) + flow[i];
+        dst[n + i] = (float)(i / w) + flow[n + i];
+    }
+    if (wts != nullptr && wout != nullptr) wout[i] = do_sigmoid ? sigmoidf_(wts[i]) : wts[i];
+}
+
 }  // namespace
 
 extern "C" int woft_resize_linear_u8(const uint8_t* img, int32_t h, int32_t w, int32_t c, uint8_t* out, int32_t ho,
@@ -212,5 +227,14 @@ extern "C" int woft_warp_perspective_u8(const uint8_t* img, int32_t h, int32_t w
     const int64_t n = (int64_t)h * w;
     hipLaunchKernelGGL(warp_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, (hipStream_t)stream, img, h, w,
                        c, hi, out, valid, nearest);
+    return woft_launch_status();
+}
+
+extern "C" int woft_flow_to_tc(const float* flow, const float* weights, int32_t h, int32_t w, float* dst, float* wout,
+                               int32_t do_sigmoid, void* stream) {
+    if (!flow || h <= 0 || w <= 0) return WOFT_EINVAL;
+    const int64_t n = (int64_t)h * w;
+    hipLaunchKernelGGL(flow_to_tc_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, (hipStream_t)stream, flow,
+                       weights, h, w, dst, wout, do_sigmoid);
     return woft_launch_status();
 }

@@ -5,6 +5,7 @@
 """
 import logging
 import os
+from pathlib import Path
 from timeit import default_timer as timer
 
 import numpy as np
@@ -61,6 +62,7 @@ class RAFTWrapper:
         self._pinned = None
         self._pinned_key = None
         self._out = {}
+        self._cache_errors = set()
 
     # ---- template caching (results-identical: InstanceNorm is per sample, extractor.py:171-190) ----
     def pin_source(self, src_img):
@@ -83,6 +85,39 @@ class RAFTWrapper:
                                                    torch.div(torch.arange(h * w, device="cuda"), w, rounding_mode="floor")]))
         return self._out[key]
 
+    def _cached_flow(self, src_img, identifier, mode, numpy_out, do_sigmoid):
+        """utils/caching.py:53-59 wire format: <flow_cache_dir>/<dataset>/<sequence>/<i>-<i+1>.npz holding
+        'half_flow' (2,H,W) and 'half_weights' (1,H,W) (any float dtype, cast to fp32); then the same
+        post-processing as a computed flow (raft.py:152-195)."""
+        dataset_name, seq_name, frame_i = identifier
+        path = Path(self.C.flow_cache_dir) / dataset_name / seq_name / f"{frame_i}-{frame_i + 1}.npz"
+        data = np.load(path, allow_pickle=True)
+        flow = np.ascontiguousarray(data["half_flow"].astype(np.float32))
+        wts = data["half_weights"].astype(np.float32)
+        wts = np.ascontiguousarray(wts) if wts.size > 1 else None
+        h, w = flow.shape[1:]
+        if self.C.weights_postprocessing_fn and wts is not None:
+            raise NotImplementedError("weights_postprocessing_fn is None in every shipped config")
+        o = self._outputs(h, w)
+        o["flow"].copy_(torch.from_numpy(flow), non_blocking=True)
+        wl = None
+        if wts is not None:
+            wl = torch.from_numpy(wts).cuda(non_blocking=True)
+        lib = _lib.load()
+        _lib.check(lib.woft_flow_to_tc(_lib.ptr(o["flow"]), _lib.ptr(wl), h, w, _lib.ptr(o["dst"]),
+                                       _lib.ptr(o["w"]) if wl is not None else None, int(bool(do_sigmoid)),
+                                       _lib.stream_ptr()), "woft_flow_to_tc")
+        weights = o["w"] if wl is not None else None
+        if mode == "flow":
+            wout = weights.reshape(1, h, w) if weights is not None else None
+            if numpy_out:
+                return o["flow"].cpu().numpy(), (wout.cpu().numpy() if wout is not None else None)
+            return o["flow"], wout
+        self.last_flow_shape = {"batch": 1, "delta": 2, "H": h, "W": w}
+        if numpy_out:
+            return (o["src"].cpu().numpy(), o["dst"].cpu().numpy(), weights.cpu().numpy() if weights is not None else None)
+        return o["src"], o["dst"], weights
+
     def compute_flow(self, src_img, dst_img, mode="TC", vis=False, src_img_identifier=None,
                      numpy_out=False, do_sigmoid=False):
         """src_img / dst_img: (H, W, 3) uint8 BGR (numpy, or CUDA tensors already on the device).
@@ -90,8 +125,14 @@ class RAFTWrapper:
         mode 'flow' -> (flow (2,H,W), weights (1,H,W) | None)."""
         assert mode in ["flow", "TC"]
         assert src_img.shape == dst_img.shape
-        if src_img_identifier is not None and self.C.flow_cache_dir:
-            logger.debug("flow cache (utils/caching.py) is not part of the HIP path; computing the flow")
+        if src_img_identifier is not None:                 # pre-computed flow (raft.py:92-109)
+            try:
+                return self._cached_flow(src_img, src_img_identifier, mode, numpy_out, do_sigmoid)
+            except Exception as ex:                        # the reference logs each distinct error once
+                key = (type(ex), str(ex))
+                if key not in self._cache_errors:
+                    self._cache_errors.add(key)
+                    logger.warning(f"no cached flow: {ex}")
         H, W = src_img.shape[:2]
         hp, wp, top, left, oh, ow, lh, lw = _pad_geometry(H, W, self.C.padding_mode)
         plan = self.engine.plan(hp, wp)
