@@ -92,7 +92,7 @@ def main():
                     help="recompute the template's features every frame, as the reference does")
     args = ap.parse_args()
 
-    from woft_amd import dist as wdist, synth
+    from woft_amd import dist as wdist, ops, synth
     from pytracking.utils.config import load_config
     rank, world, local = wdist.init_distributed()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
@@ -166,6 +166,33 @@ def main():
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": lk_avg, "launches_timed": len(lk_ms)},
     }
+    if world == 1 and getattr(plan, "prog_wh", None):
+        # the kernel with the largest share of the frame (profiles/): the weight head's 3x3 128->128 layers on the P
+        # 9x9 lookup windows -- matrix-core bound.  Timed on its own here (untimed region), HIP events on the stream.
+        layer = plan.prog_wh[0]
+        evs = []
+        for _ in range(6):
+            s_ev, e_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s_ev.record()
+            ops.run_conv(layer)
+            e_ev.record()
+            evs.append((s_ev, e_ev))
+        torch.cuda.synchronize()
+        wh_ms = float(np.mean([a.elapsed_time(b) for a, b in evs[1:]]))
+        n = int(layer.h)
+        flops = 2.0 * plan.P * n * n * 9 * 128 * 128                  # the layer's products (algorithmic)
+        terms = {"fp32": 1, "bf16x3": 3, "bf16": 1}[args.precision]
+        rows = 96 if (n == 9 and args.precision != "fp32") else n * n  # 81 pixels occupy 3 MFMA row tiles
+        peak = 157.3 if args.precision == "fp32" else 2500.0
+        out["roofline_mfma"] = {
+            "bound": "mfma", "kernel": "weight head conv 3x3 128->128 on P 9x9 windows (weighted_raft.py:337-340): "
+                                       + ("conv_mfma_f32_kernel" if args.precision == "fp32" else "conv_halo_bf16_kernel<9,9,3,3,128>"),
+            "achieved": flops / (wh_ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
+            "frac": flops / (wh_ms * 1e-3) / 1e12 / peak,
+            "matrix_core_issue_frac": flops * terms * rows / (n * n) / (wh_ms * 1e-3) / 1e12 / peak,
+            "algorithmic_flops_per_launch": flops, "mfma_terms_per_product": terms, "avg_launch_ms": wh_ms,
+            "note": "frac prices the layer's own products against the dense peak of the MFMA type used; the issue "
+                    "fraction also counts the 3 bf16 MFMAs per fp32-emulating product and the 96/81 row padding"}
     tc_gpu = {}
     if world == 1:
         _, dst, _ = tracker.flower.compute_flow(template, frames[0], mode="TC", do_sigmoid=True)

@@ -436,8 +436,12 @@ struct HaloRowMap {
 // was issue bound at a third of the matrix peak): taps are unrolled (A offsets are ds_read immediates), the
 // wave id is made scalar so DMA bases and LDS destinations live in SGPRs, every lane offset is one 32-bit VGPR
 // computed once, halo loads are unconditional (clamped address + select).
-template <int TY, int TX, int KY, int KX, int BN, int TERMS, int WM>
-__global__ __launch_bounds__(256) void conv_halo_bf16_kernel(const woft_conv_params p) {
+// STAGES = 2: weight tile of step k+1 lands while step k computes (one barrier per step).
+// STAGES = 1: one weight stage, two barriers per step, registers capped for 4 workgroups per CU (so that the ~1000
+//             workgroups of a 4x16-tiled layer at 1/8 of 1080p fit on the chip in one round).  Measured SLOWER than
+//             two stages at three workgroups per CU (GRU q conv 72 vs 64 us) and not instantiated.
+template <int TY, int TX, int KY, int KX, int BN, int TERMS, int WM, int STAGES>
+__global__ __launch_bounds__(256, (STAGES == 1 ? 4 : 1)) void conv_halo_bf16_kernel(const woft_conv_params p) {
     constexpr int NWAVES = 4;
     constexpr int NPIX = TY * TX;
     constexpr int BM = (NPIX + 31) / 32 * 32;           // rows (padded to MFMA tiles)
@@ -452,7 +456,7 @@ __global__ __launch_bounds__(256) void conv_halo_bf16_kernel(const woft_conv_par
     constexpr int A_PLANE = HROWS * LDB, A_ELEMS = NP * A_PLANE;
     constexpr int B_PLANE = BN * 32, B_STAGE = NP * B_PLANE;
     constexpr int STAGE_ELEMS = 2 * NWAVES * woft::STAGE_FLOATS;
-    constexpr int SMEM_ELEMS = (A_ELEMS + 2 * B_STAGE > STAGE_ELEMS) ? A_ELEMS + 2 * B_STAGE : STAGE_ELEMS;
+    constexpr int SMEM_ELEMS = (A_ELEMS + STAGES * B_STAGE > STAGE_ELEMS) ? A_ELEMS + STAGES * B_STAGE : STAGE_ELEMS;
     __shared__ __attribute__((aligned(16))) __bf16 smem[SMEM_ELEMS];
     __bf16* As = smem;
     __bf16* Bs = smem + A_ELEMS;
@@ -558,7 +562,7 @@ __global__ __launch_bounds__(256) void conv_halo_bf16_kernel(const woft_conv_par
     for (int s2 = 0; s2 < 2; ++s2) b_frag[s2] = (wn * WCOLS + r32) * 32 + (((s2 * 2 + hh) ^ sw) * 8);
 
     load_halo(0);
-    dma_b(0, 0);
+    if (STAGES == 2) dma_b(0, 0);
     store_halo();
     dma_wait<0>();                                       // this wave's DMA has landed before the others read it
     __syncthreads();
@@ -571,9 +575,18 @@ __global__ __launch_bounds__(256) void conv_halo_bf16_kernel(const woft_conv_par
         for (int tap = 0; tap < TAPS; ++tap) {
             // next step's weights (and, during the first tap, the next chunk's halo: RH loads issued AFTER the DMA,
             // so that "at most RH loads in flight" = DMA complete while the halo loads cross the barrier)
-            if (tap + 1 < TAPS) dma_b((tap + 1) * p.cin_pad + chunk * BK, stage ^ 1);
-            else if (more) dma_b((chunk + 1) * BK, stage ^ 1);
+            if (STAGES == 2) {
+                if (tap + 1 < TAPS) dma_b((tap + 1) * p.cin_pad + chunk * BK, stage ^ 1);
+                else if (more) dma_b((chunk + 1) * BK, stage ^ 1);
+            } else {
+                dma_b(tap * p.cin_pad + chunk * BK, 0);      // this step's weights; the stage is free (barrier below)
+            }
             if (tap == 0 && more) load_halo(chunk + 1);
+            if (STAGES == 1) {
+                if (tap == 0 && more) dma_wait<RH>();
+                else dma_wait<0>();
+                __syncthreads();
+            }
             const int ky = tap / KX, kx = tap - ky * KX;
             const __bf16* bst = Bs + stage * B_STAGE;
             // software pipeline over the 2 * TM (k half, row tile) sub-steps: the fragments of sub-step n + 1 are
@@ -611,10 +624,12 @@ __global__ __launch_bounds__(256) void conv_halo_bf16_kernel(const woft_conv_par
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[n & 1][0], bq[s2 & 1][0][j], acc[i][j], 0, 0, 0);
                 }
             }
-            if (tap == 0 && more) dma_wait<RH>();
-            else dma_wait<0>();
+            if (STAGES == 2) {
+                if (tap == 0 && more) dma_wait<RH>();
+                else dma_wait<0>();
+            }
             __syncthreads();
-            stage ^= 1;
+            if (STAGES == 2) stage ^= 1;
         }
         if (more) {
             store_halo();
@@ -660,13 +675,13 @@ __global__ __launch_bounds__(256) void conv_halo_bf16_kernel(const woft_conv_par
                                                 lane, m_tile);
 }
 
-template <int TY, int TX, int BN, int WM>
+template <int TY, int TX, int BN, int WM, int STAGES>
 int launch_halo(const woft_conv_params& p, hipStream_t s) {
     const int tyn = (p.ho + TY - 1) / TY, txn = (p.wo + TX - 1) / TX;
     const int64_t mt = (int64_t)p.n_img * tyn * txn;
     dim3 grid((unsigned)(mt * (p.cout_pad / BN)));
 #define HALO_LAUNCH(KY, KX, T) \
-    hipLaunchKernelGGL((conv_halo_bf16_kernel<TY, TX, KY, KX, BN, T, WM>), grid, dim3(256), 0, s, p)
+    hipLaunchKernelGGL((conv_halo_bf16_kernel<TY, TX, KY, KX, BN, T, WM, STAGES>), grid, dim3(256), 0, s, p)
 #define HALO_TAPS(T)                                                   \
     if (p.taps_y == 3 && p.taps_x == 3) HALO_LAUNCH(3, 3, T);          \
     else if (p.taps_y == 1 && p.taps_x == 5) HALO_LAUNCH(1, 5, T);     \
@@ -896,10 +911,10 @@ extern "C" int woft_conv2d(const woft_conv_params* pp, void* stream) {
         const int64_t cs_max = (p.in1 != nullptr && p.cs1 > p.cs0) ? p.cs1 : p.cs0;
         if ((int64_t)p.n_img * p.h * p.w * cs_max >= (1ll << 31)) return WOFT_EINVAL;     // 32-bit element offsets
         if ((int64_t)p.taps_y * p.taps_x * p.cin_pad >= (1 << 20)) return WOFT_EINVAL;
-        if (p.halo == 1 && p.tile_n == 128) return launch_halo<8, 16, 128, 2>(p, s);
-        if (p.halo == 1 && p.tile_n == 64) return launch_halo<8, 16, 64, 2>(p, s);
-        if (p.halo == 2 && p.tile_n == 128 && p.ho == 9 && p.wo == 9) return launch_halo<9, 9, 128, 1>(p, s);
-        if (p.halo == 4 && p.tile_n == 128) return launch_halo<4, 16, 128, 2>(p, s);
+        if (p.halo == 1 && p.tile_n == 128) return launch_halo<8, 16, 128, 2, 2>(p, s);
+        if (p.halo == 1 && p.tile_n == 64) return launch_halo<8, 16, 64, 2, 2>(p, s);
+        if (p.halo == 2 && p.tile_n == 128 && p.ho == 9 && p.wo == 9) return launch_halo<9, 9, 128, 1, 2>(p, s);
+        if (p.halo == 4 && p.tile_n == 128) return launch_halo<4, 16, 128, 2, 2>(p, s);
         return WOFT_EINVAL;
     }
     if (p.tile_m == 128 && p.tile_n == 128) return launch_conv<128, 128>(p, s);
