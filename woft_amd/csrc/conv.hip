@@ -715,7 +715,8 @@ __global__ __launch_bounds__(256, 4) void corr_gemm_bf16_kernel(const __bf16* __
     __shared__ __attribute__((aligned(16))) __bf16 smem[SMEM_ELEMS];
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int r32 = lane & 31, hh = lane >> 5;
     const int64_t M = (int64_t)p.n_img * p.ho * p.wo;
@@ -726,22 +727,24 @@ __global__ __launch_bounds__(256, 4) void corr_gemm_bf16_kernel(const __bf16* __
     const int ld = line_elems_per_row;                  // elements per operand row (all its lines)
     const int nk = ld / 64;
 
-    // wave instruction q of a step: operand q / 16, rows (q % 16) * 8 + lane / 8, physical chunk lane % 8
-    const __bf16* src[8];
+    // wave instruction q = wave + 4 t of a step: operand q / 16, rows (q % 16) * 8 + lane / 8, physical chunk
+    // lane % 8 holding logical chunk (lane % 8) ^ ((row >> 1) & 7); (row >> 1) & 7 = (4 (wave & 1) + lane / 16) & 7
+    // for every t, so ONE lane-offset register serves all eight instructions and the bases are scalar
+    const uint32_t dma_lane =
+        (uint32_t)(((lane >> 3) * ld + (((lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7)) * 8)) * 2);
+    const char* srow[8];
+    uint32_t sdst[8];
+    const uint32_t smem_addr = lds_addr_of(smem);
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
         const int q = wave + t * 4;
-        const int row = (q & 15) * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ ((row >> 1) & 7);
-        src[t] = (q < 16 ? a + (m0 + row) * ld : b + (int64_t)(n0 + row) * ld) + c * 8;
+        const int row0 = (q & 15) * 8;
+        srow[t] = (const char*)(q < 16 ? a + (m0 + row0) * ld : b + (int64_t)(n0 + row0) * ld);
+        sdst[t] = smem_addr + (uint32_t)q * 1024u;
     }
     auto dma = [&](int ks) {
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const int q = wave + t * 4;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[t] + ks * 64),
-                                             (__attribute__((address_space(3))) void*)(smem + q * 512), 16, 0, 0);
-        }
+        for (int t = 0; t < 8; ++t) lds_dma16(srow[t] + (int64_t)ks * 128, dma_lane, sdst[t]);
     };
 
     f32x16 acc[TM][TN];
@@ -757,6 +760,7 @@ __global__ __launch_bounds__(256, 4) void corr_gemm_bf16_kernel(const __bf16* __
     const __bf16* b_rows = smem + PL + (wn * 64 + r32) * 64;
     for (int ks = 0; ks < nk; ++ks) {
         if (!(abl & 4) || ks == 0) dma(ks);
+        dma_wait<0>();                                   // this wave's pieces have landed before the others read
         __syncthreads();
         if (!(abl & 8)) {
             if (TERMS == 3) {
@@ -915,6 +919,7 @@ extern "C" int woft_conv2d(const woft_conv_params* pp, void* stream) {
         if (p.halo == 1 && p.tile_n == 64) return launch_halo<8, 16, 64, 2, 2>(p, s);
         if (p.halo == 2 && p.tile_n == 128 && p.ho == 9 && p.wo == 9) return launch_halo<9, 9, 128, 1, 2>(p, s);
         if (p.halo == 4 && p.tile_n == 128) return launch_halo<4, 16, 128, 2, 2>(p, s);
+        if (p.halo == 4 && p.tile_n == 64) return launch_halo<4, 16, 64, 2, 2>(p, s);
         return WOFT_EINVAL;
     }
     if (p.tile_m == 128 && p.tile_n == 128) return launch_conv<128, 128>(p, s);

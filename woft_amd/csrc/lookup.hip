@@ -60,7 +60,9 @@ __global__ __launch_bounds__(256) void corr_lookup_kernel(const woft_lookup_para
     }
 #pragma unroll
     for (int l = 0; l < 4; ++l) *(f32x4*)(&patch[wave][l][(4 * a + r) * 16 + 4 * b]) = v[l];
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // the patch is private to this wave: no block barrier
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
     // ---- interpolate + write (dword stores, 256 B per wave instruction) ---------------------------
     if (!active) return;
