@@ -18,7 +18,7 @@ def main():
     P = hf * wf
     n = ops.tiled_dims(hf, wf)[2]
     terms = int(os.environ.get("TERMS", "3"))
-    mk = lambda rows: (torch.randn(ops._round_up(rows, 128), 256, device="cuda") * 0.1)
+    mk = lambda rows: (torch.randn(ops._round_up(rows, 256), 256, device="cuda") * 0.1)
     a, b = mk(P), mk(n)
     if terms == 3:
         sa, sb = (torch.zeros(x.shape[0], 512, dtype=torch.bfloat16, device="cuda") for x in (a, b))

@@ -706,18 +706,21 @@ int launch_halo(const woft_conv_params& p, hipStream_t s) {
 // service group holds 8 even and 8 odd rows whose (r >> 1) & 7 are all different).
 // One stage only (32 KiB): four workgroups per CU overlap each other's load, MFMA and store-drain phases,
 // which measured faster than two stages with two workgroups (tools/bench_cgemm.py).
-template <int TERMS>
-__global__ __launch_bounds__(256, 4) void corr_gemm_bf16_kernel(const __bf16* __restrict__ a, const __bf16* __restrict__ b,
-                                                                int line_elems_per_row, const woft_conv_params p, int abl) {
-    constexpr int BM = 128, BN = 128, TM = 2, TN = 2;
-    constexpr int PL = 128 * 64;                        // elements of one operand tile stage (128 rows x 128 B)
-    constexpr int SMEM_ELEMS = (2 * PL > 8 * woft::STAGE_FLOATS) ? 2 * PL : 8 * woft::STAGE_FLOATS;
+template <int TERMS, int WM, int WN, int STAGES>
+__global__ __launch_bounds__(WM * WN * 64, 4)
+void corr_gemm_bf16_kernel(const __bf16* __restrict__ a, const __bf16* __restrict__ b, int line_elems_per_row,
+                           const woft_conv_params p, int abl) {
+    // workgroup = WM x WN waves, each owning a 64 x 64 block of the (64 WM) x (64 WN) tile
+    constexpr int NWV = WM * WN;
+    constexpr int BM = WM * 64, BN = WN * 64, TM = 2, TN = 2;
+    constexpr int STG = (BM + BN) * 64;                 // elements of one stage: BM + BN rows of 128 B
+    constexpr int SMEM_ELEMS = (STAGES * STG > 2 * NWV * woft::STAGE_FLOATS) ? STAGES * STG : 2 * NWV * woft::STAGE_FLOATS;
     __shared__ __attribute__((aligned(16))) __bf16 smem[SMEM_ELEMS];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int r32 = lane & 31, hh = lane >> 5;
     const int64_t M = (int64_t)p.n_img * p.ho * p.wo;
     int m_tile, n_tile;
@@ -727,24 +730,26 @@ __global__ __launch_bounds__(256, 4) void corr_gemm_bf16_kernel(const __bf16* __
     const int ld = line_elems_per_row;                  // elements per operand row (all its lines)
     const int nk = ld / 64;
 
-    // wave instruction q = wave + 4 t of a step: operand q / 16, rows (q % 16) * 8 + lane / 8, physical chunk
-    // lane % 8 holding logical chunk (lane % 8) ^ ((row >> 1) & 7); (row >> 1) & 7 = (4 (wave & 1) + lane / 16) & 7
-    // for every t, so ONE lane-offset register serves all eight instructions and the bases are scalar
+    // DMA piece q = wave + NWV t of a step: rows 8 q .. 8 q + 7 of the stage image [A rows | B rows], lane ->
+    // (row lane / 8, physical chunk lane % 8) holding logical chunk (lane % 8) ^ ((row >> 1) & 7);
+    // (row >> 1) & 7 = (4 (wave & 1) + lane / 16) & 7 for every t (NWV is even), so ONE lane-offset register serves
+    // all pieces of the wave and the bases are scalar
+    constexpr int NQ = (BM + BN) / 8, QPW = NQ / NWV;
+    static_assert(NQ % NWV == 0 && NWV % 2 == 0, "DMA pieces must divide over an even number of waves");
     const uint32_t dma_lane =
         (uint32_t)(((lane >> 3) * ld + (((lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7)) * 8)) * 2);
-    const char* srow[8];
-    uint32_t sdst[8];
+    const char* srow[QPW];
+    uint32_t sdst[QPW];
     const uint32_t smem_addr = lds_addr_of(smem);
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        const int q = wave + t * 4;
-        const int row0 = (q & 15) * 8;
-        srow[t] = (const char*)(q < 16 ? a + (m0 + row0) * ld : b + (int64_t)(n0 + row0) * ld);
+    for (int t = 0; t < QPW; ++t) {
+        const int q = wave + t * NWV;
+        srow[t] = (const char*)(q < BM / 8 ? a + (m0 + q * 8) * ld : b + (int64_t)(n0 + (q - BM / 8) * 8) * ld);
         sdst[t] = smem_addr + (uint32_t)q * 1024u;
     }
-    auto dma = [&](int ks) {
+    auto dma = [&](int ks, int stage) {
 #pragma unroll
-        for (int t = 0; t < 8; ++t) lds_dma16(srow[t] + (int64_t)ks * 128, dma_lane, sdst[t]);
+        for (int t = 0; t < QPW; ++t) lds_dma16(srow[t] + (int64_t)ks * 128, dma_lane, sdst[t] + (uint32_t)(stage * STG * 2));
     };
 
     f32x16 acc[TM][TN];
@@ -756,12 +761,23 @@ __global__ __launch_bounds__(256, 4) void corr_gemm_bf16_kernel(const __bf16* __
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int sw = (r32 >> 1) & 7;
-    const __bf16* a_rows = smem + (wm * 64 + r32) * 64;
-    const __bf16* b_rows = smem + PL + (wn * 64 + r32) * 64;
-    for (int ks = 0; ks < nk; ++ks) {
-        if (!(abl & 4) || ks == 0) dma(ks);
-        dma_wait<0>();                                   // this wave's pieces have landed before the others read
+    const __bf16* a_rows0 = smem + (wm * 64 + r32) * 64;
+    const __bf16* b_rows0 = smem + BM * 64 + (wn * 64 + r32) * 64;
+    if (STAGES == 2) {
+        dma(0, 0);
+        dma_wait<0>();
         __syncthreads();
+    }
+    for (int ks = 0; ks < nk; ++ks) {
+        if (STAGES == 2) {
+            if (ks + 1 < nk && !(abl & 4)) dma(ks + 1, (ks + 1) & 1);     // lands while this step computes
+        } else {
+            if (!(abl & 4) || ks == 0) dma(ks, 0);
+            dma_wait<0>();                               // this wave's pieces have landed before the others read
+            __syncthreads();
+        }
+        const __bf16* a_rows = a_rows0 + (STAGES == 2 ? (ks & 1) * STG : 0);
+        const __bf16* b_rows = b_rows0 + (STAGES == 2 ? (ks & 1) * STG : 0);
         if (!(abl & 8)) {
             if (TERMS == 3) {
 #pragma unroll
@@ -804,6 +820,7 @@ __global__ __launch_bounds__(256, 4) void corr_gemm_bf16_kernel(const __bf16* __
                 }
             }
         }
+        if (STAGES == 2) dma_wait<0>();
         __syncthreads();
     }
     if (abl & 2) {          // ablation: no epilogue at all (keep the accumulators live)
@@ -941,13 +958,17 @@ extern "C" int woft_corr_gemm_bf16(const void* a, const void* b, int64_t m, int6
     p.out = out; p.ldo = ldo;
     p.epi = WOFT_EPI_LINEAR;
     const int abl = g_tuning[2];                         // ablation bits (tools/bench_cgemm.py); 0 in production
+    hipStream_t s = (hipStream_t)stream;
+    // workgroup shape: 2 x 2 waves (128 x 128 tile), one stage.  256 x 128 / one stage and 256 x 256 / two stages
+    // (half the operand traffic) were measured at the same 2.05-2.17 ms for level 0: see DESIGN.md section 4.
+    if (rows_a % 128 != 0 || rows_b % 128 != 0) return WOFT_EINVAL;
     dim3 grid((unsigned)(ceil_div64(m, 128) * (rows_b / 128)));
     if (terms == 3)
-        hipLaunchKernelGGL((corr_gemm_bf16_kernel<3>), grid, dim3(256), 0, (hipStream_t)stream, (const __bf16*)a,
-                           (const __bf16*)b, 2 * k, p, abl);
+        hipLaunchKernelGGL((corr_gemm_bf16_kernel<3, 2, 2, 1>), grid, dim3(256), 0, s, (const __bf16*)a, (const __bf16*)b,
+                           2 * k, p, abl);
     else
-        hipLaunchKernelGGL((corr_gemm_bf16_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, (const __bf16*)a,
-                           (const __bf16*)b, k, p, abl);
+        hipLaunchKernelGGL((corr_gemm_bf16_kernel<1, 2, 2, 1>), grid, dim3(256), 0, s, (const __bf16*)a, (const __bf16*)b,
+                           k, p, abl);
     return woft_launch_status();
 }
 
