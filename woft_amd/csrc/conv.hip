@@ -45,10 +45,11 @@ int g_tuning[4] = {0, 1, 0, 0};
 // outstanding global load (vmcnt(0)) at the next barrier, including prefetches that are meant to stay in flight.
 // The caller orders it explicitly with dma_wait<N>() before the barrier that publishes the data.
 __device__ __forceinline__ void lds_dma16(const void* gbase, uint32_t lane_off, uint32_t lds_addr) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
-                 :
+    uint32_t saved_m0;                                   // m0 is a reserved register: hand it back as found
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(saved_m0)
                  : "s"(lds_addr), "v"(lane_off), "s"(gbase)
-                 : "memory", "m0");
+                 : "memory");
 }
 template <int N>
 __device__ __forceinline__ void dma_wait() {             // at most N vector-memory loads still in flight
