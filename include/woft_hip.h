@@ -91,6 +91,11 @@ typedef struct woft_conv_params {
                               1 = 8x16 px, 4 = 4x16 px, 2 = one 9x9 image per workgroup (weight-head patches;
                               ho = wo = 9).  (Larger tiles / several patches per workgroup were measured
                               1.5-3x slower: one workgroup per CU cannot hide its own latencies.) */
+    int32_t in_norm;       /* halo != 0 only: 0 = use in0 as is; 1 / 2 = in0 holds a RAW conv output whose
+                              InstanceNorm is applied while loading (extractor.py:44-47: x = (x - in_mean[c]) *
+                              in_rstd[c], 2: followed by ReLU), zero padding applied after it; in1 must be NULL */
+    const float* in_mean;  /* [cin] per-channel statistics of in0 (woft_inorm_finalize)          */
+    const float* in_rstd;
 } woft_conv_params;
 
 int woft_conv2d(const woft_conv_params* p, void* stream);

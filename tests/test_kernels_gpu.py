@@ -64,6 +64,31 @@ def test_conv_plain(ops, cin, cout, k, stride, h, w, tiles, precision, tol):
     assert float(big.t[:, :8].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("mode", [1, 2])
+def test_conv_halo_norm_on_load(ops, mode):
+    """InstanceNorm (+ ReLU) of the producer applied inside the consumer's LDS-halo loader (extractor.py:44-47):
+    identical to normalising first (same fp32 operations), zero padding applied after the normalisation."""
+    x = _rand(1, 96, 21, 37, seed=91, scale=2.0) + 0.3
+    wt = _rand(96, 96, 3, 3, seed=92, scale=1 / math.sqrt(96 * 9))
+    b = _rand(96, seed=93, scale=0.1)
+    mean, rstd = _rand(96, seed=94, scale=0.5).cuda(), (_rand(96, seed=95).abs() + 0.5).cuda()
+    pc = ops.pack_conv(wt, b)
+    xa = ops.act_from_nchw(x)
+    xn = ops.new_act(1, 21, 37, 96, zero=True)
+    ops.inorm_apply(xa, mean, rstd, xn, mode - 1)
+    o1, o2 = ops.new_act(1, 21, 37, 96, zero=True), ops.new_act(1, 21, 37, 96, zero=True)
+    p1 = ops.conv_params(xa, pc, o1, precision="bf16x3", in_norm=mode, in_stats=(mean, rstd))
+    p2 = ops.conv_params(xn, pc, o2, precision="bf16x3")
+    assert p1.halo != 0 and p1.in_norm == mode
+    ops.run_conv(p1)
+    ops.run_conv(p2)
+    torch.cuda.synchronize()
+    assert torch.equal(o1.t, o2.t)
+    ref = F.conv2d(F.relu((x - mean.cpu().view(1, -1, 1, 1)) * rstd.cpu().view(1, -1, 1, 1)) if mode == 2 else
+                   (x - mean.cpu().view(1, -1, 1, 1)) * rstd.cpu().view(1, -1, 1, 1), wt, b, padding=1)
+    _close(o1.nchw(), ref, 2e-4, what="norm-on-load conv")
+
+
 @pytest.mark.parametrize("precision,tol", [("bf16x3", 2e-5), ("bf16", 2e-2)])
 def test_wh_mean_epilogue(ops, precision, tol):
     """Last weight-head layer with ReLU + 1x1 conv + patch mean fused into the whole-patch kernel's epilogue

@@ -491,26 +491,41 @@ __global__ __launch_bounds__(256, (STAGES == 1 ? 4 : 1)) void conv_halo_bf16_ker
         hok[j] = ht < HROWS && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w;
         hpix[j] = hok[j] ? (img0 * p.h + iy) * p.w + ix : 0;
     }
-    f32x4 rh[RH];
-    auto load_halo = [&](int chunk) {                    // RH unconditional 16-byte loads (counted by vmcnt below)
+    f32x4 rh[RH], nmu, nrs;
+    constexpr int NLOAD = RH + 2;                        // vector loads per load_halo (counted by vmcnt below)
+    const float* nmean = p.in_norm ? p.in_mean : p.in0;  // (always loaded: keeps the load count fixed)
+    const float* nrstd = p.in_norm ? p.in_rstd : p.in0;
+    auto load_halo = [&](int chunk) {                    // NLOAD unconditional 16-byte loads
         const int c0 = chunk * BK;
         const bool second = (p.in1 != nullptr) && (c0 >= p.c_split);
         const float* src = (second ? p.in1 + (c0 - p.c_split) : p.in0 + c0) + 4 * v;
         const int cs = second ? p.cs1 : p.cs0;
 #pragma unroll
         for (int j = 0; j < RH; ++j) rh[j] = *(const f32x4*)(src + (uint32_t)(hpix[j] * cs));
+        nmu = *(const f32x4*)(nmean + (p.in_norm ? c0 : 0) + 4 * v);
+        nrs = *(const f32x4*)(nrstd + (p.in_norm ? c0 : 0) + 4 * v);
     };
     auto store_halo = [&]() {
         // (pins the use of the prefetched registers HERE: the conversions must not be scheduled up into the taps,
         //  where their wait would drain the weight DMA queue early)
 #pragma unroll
         for (int j = 0; j < RH; ++j) asm volatile("" : "+v"(rh[j]));
+        asm volatile("" : "+v"(nmu), "+v"(nrs));
 #pragma unroll
         for (int j = 0; j < RH; ++j) {
             const int ht = r0 + 32 * j;
             if (RH * 32 > HROWS && ht >= HROWS) continue;
             const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-            const f32x4 val = hok[j] ? rh[j] : zero;
+            f32x4 x = rh[j];
+            if (p.in_norm) {                             // InstanceNorm (+ ReLU) of the producer, applied on load
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float y = (x[e] - nmu[e]) * nrs[e];
+                    if (p.in_norm == 2) y = fmaxf(y, 0.f);
+                    x[e] = y;
+                }
+            }
+            const f32x4 val = hok[j] ? x : zero;
             const bf16x4 hi = __builtin_convertvector(val, bf16x4);
             *(bf16x4*)(As + ht * LDB + 4 * v) = hi;
             if (NP == 2) {
@@ -584,7 +599,7 @@ __global__ __launch_bounds__(256, (STAGES == 1 ? 4 : 1)) void conv_halo_bf16_ker
             }
             if (tap == 0 && more) load_halo(chunk + 1);
             if (STAGES == 1) {
-                if (tap == 0 && more) dma_wait<RH>();
+                if (tap == 0 && more) dma_wait<NLOAD>();
                 else dma_wait<0>();
                 __syncthreads();
             }
@@ -626,7 +641,7 @@ __global__ __launch_bounds__(256, (STAGES == 1 ? 4 : 1)) void conv_halo_bf16_ker
                 }
             }
             if (STAGES == 2) {
-                if (tap == 0 && more) dma_wait<RH>();
+                if (tap == 0 && more) dma_wait<NLOAD>();
                 else dma_wait<0>();
             }
             __syncthreads();
@@ -925,6 +940,8 @@ extern "C" int woft_conv2d(const woft_conv_params* pp, void* stream) {
     if (p.e1 != nullptr && p.lde1 % 4 != 0) return WOFT_EINVAL;
     if (p.out1 != nullptr && (p.ldo1 % 4 != 0 || p.split % 4 != 0)) return WOFT_EINVAL;
     if ((p.stat_sum == nullptr) != (p.stat_sq == nullptr)) return WOFT_EINVAL;
+    if (p.in_norm < 0 || p.in_norm > 2) return WOFT_EINVAL;
+    if (p.in_norm != 0 && (p.halo == 0 || p.in1 != nullptr || p.in_mean == nullptr || p.in_rstd == nullptr)) return WOFT_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     if (p.halo != 0) {
         // LDS-halo kernels: split-bf16 precisions, stride 1, 3x3 / 1x5 / 5x1 taps, non-flat, same-size output

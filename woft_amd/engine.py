@@ -258,28 +258,46 @@ class _Plan:
         inorm = e.norm == "instance"
         tag = "i" if inorm else "c"
 
-        def layer(x, pc, name, relu, res=None):
-            """-> relu?(norm(conv(x)))  or, with res,  relu(res + relu(norm(conv(x))))"""
-            ho, wo = pc.out_hw(x.h, x.w)
+        def layer(x, pc, name, relu, res=None, defer=False):
+            """-> relu?(norm(conv(x)))  or, with res,  relu(res + relu(norm(conv(x)))).
+            x may be a pending activation ("raw", act, mode): a raw conv output whose InstanceNorm (+ ReLU) was
+            deferred to its consumer -- fused into this conv's LDS-halo loader when this conv runs on that kernel,
+            materialised by the apply kernel otherwise.  defer=True returns such a pending activation."""
+            xin, in_norm = x, 0
+            if isinstance(x, tuple):
+                _, raw_x, mode = x
+                probe = self._cp(raw_x, pc, raw_x, in_norm=mode, in_stats=(self.mean, self.rstd))
+                if probe.in_norm:
+                    xin, in_norm = raw_x, mode
+                else:
+                    xin = self._scratch(f"{tag}_{name}_in", 1, raw_x.h, raw_x.w, raw_x.c)
+                    prog.append(("apply", (raw_x, xin, mode - 1, None)))        # apply modes: 0 norm, 1 norm + relu
+            ho, wo = pc.out_hw(xin.h, xin.w)
             out = self._scratch(f"{tag}_{name}", 1, ho, wo, pc.cout)
+            kw = dict(in_norm=in_norm, in_stats=(self.mean, self.rstd)) if in_norm else {}
             if not inorm:
                 epi = EPI.EPI_RELU_RES_RELU if res is not None else (EPI.EPI_RELU if relu else EPI.EPI_LINEAR)
-                prog.append(("conv", self._cp(x, pc, out, epi=epi, e0=res)))
+                prog.append(("conv", self._cp(xin, pc, out, epi=epi, e0=res, **kw)))
                 return out
             raw = self._scratch(f"{tag}_raw_{name}", 1, ho, wo, pc.cout)
-            p = self._cp(x, pc, raw, stats=self.stats)
+            p = self._cp(xin, pc, raw, stats=self.stats, **kw)
             rows = 2 * p._m_tiles
             prog.append(("conv", p))
             prog.append(("fin", (rows, pc.cout_pad, pc.cout, raw.cs, p._m)))
+            if defer and res is None:
+                return ("raw", raw, 2 if relu else 1)
             prog.append(("apply", (raw, out, 2 if res is not None else (1 if relu else 0), res)))
             return out
 
         x = layer(img, e.conv1, "c1", True)
         for i, blk in enumerate(e.blocks):
+            # (the shortcut first: a deferred normalisation reads mean / rstd of the LAST finalize)
+            res = x if blk["stride"] == 1 else layer(x, blk["down"], f"b{i}_d", False)
             y = x
             for k, pc in enumerate(blk["convs"][:-1]):
-                y = layer(y, pc, f"b{i}_{k}", True)
-            res = x if blk["stride"] == 1 else layer(x, blk["down"], f"b{i}_d", False)
+                # the block-internal activations have exactly one consumer (the next conv of the block): their
+                # normalisation is deferred to it (the residual input x and the block output are materialised)
+                y = layer(y, pc, f"b{i}_{k}", True, defer=inorm)
             x = layer(y, blk["convs"][-1], f"b{i}_o", True, res=res)
         for pc, out, co_off, epi in outputs:
             prog.append(("conv", self._cp(x, pc, out, co_off=co_off, epi=epi)))

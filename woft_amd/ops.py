@@ -162,8 +162,11 @@ def pick_tiles(m, cout_pad):
 # kernels
 # ------------------------------------------------------------------------------------------
 def conv_params(x, pc, out, co_off=0, epi=_lib.EPI_LINEAR, x2=None, c_split=0, e0=None, e1=None, out1=None,
-                split=0, alpha=1.0, stats=None, ho=None, wo=None, tiles=None, cout=None, precision=0, halo=None):
-    """Build (and keep alive) a woft_conv_params for `out[:, co_off:co_off+cout] = epi(conv(x))`."""
+                split=0, alpha=1.0, stats=None, ho=None, wo=None, tiles=None, cout=None, precision=0, halo=None,
+                in_norm=0, in_stats=None):
+    """Build (and keep alive) a woft_conv_params for `out[:, co_off:co_off+cout] = epi(conv(x))`.
+    in_norm = 1 / 2 with in_stats = (mean, rstd): x is a RAW conv output, InstanceNorm (2: + ReLU) applied while
+    loading -- LDS-halo kernel only (check p.halo on the result; the caller falls back to woft_inorm_apply)."""
     if ho is None or wo is None:
         ho, wo = pc.out_hw(x.h, x.w)
     p = ConvParams()
@@ -203,6 +206,9 @@ def conv_params(x, pc, out, co_off=0, epi=_lib.EPI_LINEAR, x2=None, c_split=0, e
                 if tn == 128 and x.n * math.ceil(ho / 8) * math.ceil(wo / 16) * nt < HALO_MIN_BLOCKS:
                     halo = 4
     p.halo = halo
+    p.in_norm, p.in_mean, p.in_rstd = 0, None, None
+    if in_norm and halo:
+        p.in_norm, p.in_mean, p.in_rstd = int(in_norm), ptr(in_stats[0]), ptr(in_stats[1])
     p._m_tiles = math.ceil(m / tm)
     if halo in HALO_TILES:
         ty, tx, g = HALO_TILES[halo]
@@ -213,7 +219,7 @@ def conv_params(x, pc, out, co_off=0, epi=_lib.EPI_LINEAR, x2=None, c_split=0, e
         p.stat_sum, p.stat_sq = ptr(stats[0]), ptr(stats[1])
     else:
         p.stat_sum, p.stat_sq = None, None
-    p._keep = (x, x2, pc, out, e0, e1, out1, stats)
+    p._keep = (x, x2, pc, out, e0, e1, out1, stats, in_stats)
     p._m = m
     return p
 
