@@ -78,26 +78,27 @@ __global__ __launch_bounds__(256) void wh_reduce_kernel(const float* __restrict_
 //   x[t][0..3] = lookup[p][4 t .. 4 t + 3]   (the reference reads the level-major channels as (hp wp level),
 //   x[t][4]    = mean[p]                       weighted_raft.py:267-272, 363-376)
 // GEMM K is only 45, the output is 1.3 GB at 1080p: the matrix-core kernel is launch/epilogue bound on it.  Here a
-// lane owns ONE output channel (its 45 weights live in registers) and a wave walks over the window; the window
+// lane owns TWO output channels (their 90 weights live in registers, packed FMAs) and a wave walks over the window; the window
 // values are wave-uniform, so they are fetched by SCALAR loads and enter the FMAs as scalar operands -- no LDS, no
-// vector loads.  Each wave instruction stores 256 contiguous bytes of one pixel's channel vector.
+// vector loads.  Each wave instruction stores the 512 contiguous bytes of one pixel's channel vector.
 template <int NW>
 __global__ __launch_bounds__(256) void wh_conv0_kernel(const float* __restrict__ lookup, int ld,
                                                        const float* __restrict__ mean, int n_pix,
                                                        const float* __restrict__ wt, const float* __restrict__ b0,
                                                        float* __restrict__ out) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int co = (wave & 1) * 64 + lane;
-    float w[3][3][5];
+    const int co = 2 * lane;                             // this lane's two output channels (packed FMAs)
+    f32x2 w[3][3][5];
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-            for (int ci = 0; ci < 5; ++ci) w[ky][kx][ci] = wt[(ky * 32 + kx * 8 + ci) * 128 + co];
-    const float bias = b0[co];
-    for (int p = blockIdx.x * 2 + (wave >> 1); p < n_pix; p += gridDim.x * 2) {
+            for (int ci = 0; ci < 5; ++ci) w[ky][kx][ci] = *(const f32x2*)(wt + (ky * 32 + kx * 8 + ci) * 128 + co);
+    const f32x2 bias = *(const f32x2*)(b0 + co);
+    for (int p = blockIdx.x * 4 + wave; p < n_pix; p += gridDim.x * 4) {
         const float* __restrict__ lk = lookup + (int64_t)p * ld;
         const float mv = mean[p];
         float* __restrict__ o = out + (int64_t)p * (NW * NW * 128) + co;
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(256) void wh_conv0_kernel(const float* __restrict__
         for (int y = 0; y < NW; ++y) {
 #pragma unroll
             for (int x = 0; x < NW; ++x) {
-                float acc = bias;
+                f32x2 acc = bias;
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky) {
                     const int yy = y + ky - 1;
@@ -115,14 +116,17 @@ __global__ __launch_bounds__(256) void wh_conv0_kernel(const float* __restrict__
                         const int xx = x + kx - 1;
                         if (xx < 0 || xx >= NW) continue;              // (compile time)
                         const float* xv = lk + (yy * NW + xx) * 4;
-                        acc = fmaf(w[ky][kx][0], xv[0], acc);
-                        acc = fmaf(w[ky][kx][1], xv[1], acc);
-                        acc = fmaf(w[ky][kx][2], xv[2], acc);
-                        acc = fmaf(w[ky][kx][3], xv[3], acc);
-                        acc = fmaf(w[ky][kx][4], mv, acc);
+#pragma unroll
+                        for (int ci = 0; ci < 4; ++ci) {
+                            const f32x2 xs = {xv[ci], xv[ci]};
+                            acc = __builtin_elementwise_fma(w[ky][kx][ci], xs, acc);
+                        }
+                        const f32x2 ms = {mv, mv};
+                        acc = __builtin_elementwise_fma(w[ky][kx][4], ms, acc);
                     }
                 }
-                o[(y * NW + x) * 128] = fmaxf(acc, 0.f);
+                const f32x2 r = {fmaxf(acc[0], 0.f), fmaxf(acc[1], 0.f)};
+                *(f32x2*)(o + (y * NW + x) * 128) = r;
             }
         }
     }
@@ -134,8 +138,8 @@ extern "C" int woft_wh_conv0(const float* lookup, int32_t ld_lookup, const float
                              const float* wt, const float* bias, float* out, void* stream) {
     if (!lookup || !mean || !wt || !bias || !out || n_pix <= 0 || n_pix >= (1ll << 31)) return WOFT_EINVAL;
     if (ld_lookup < nwin * nwin * 4 || (nwin != 9 && nwin != 7)) return WOFT_EINVAL;
-    const int64_t pairs = (n_pix + 1) / 2;
-    dim3 grid((unsigned)(pairs < 256 * 8 ? pairs : 256 * 8));
+    const int64_t quads = (n_pix + 3) / 4;                // one wave per window, four per workgroup
+    dim3 grid((unsigned)(quads < 256 * 8 ? quads : 256 * 8));
     hipStream_t s = (hipStream_t)stream;
     if (nwin == 9)
         hipLaunchKernelGGL(wh_conv0_kernel<9>, grid, dim3(256), 0, s, lookup, ld_lookup, mean, (int)n_pix, wt, bias, out);
