@@ -441,7 +441,9 @@ struct HaloRowMap {
 // STAGES = 1: one weight stage, two barriers per step, registers capped for 4 workgroups per CU (so that the ~1000
 //             workgroups of a 4x16-tiled layer at 1/8 of 1080p fit on the chip in one round).  Measured SLOWER than
 //             two stages at three workgroups per CU (GRU q conv 72 vs 64 us) and not instantiated.
-template <int TY, int TX, int KY, int KX, int BN, int TERMS, int WM, int STAGES>
+// NORM (compile time, so that the other layers do not pay for it): p.in_norm != 0, the producer's InstanceNorm (+ ReLU)
+// is applied while the halo is staged.
+template <int TY, int TX, int KY, int KX, int BN, int TERMS, int WM, int STAGES, bool NORM>
 __global__ __launch_bounds__(256, (STAGES == 1 ? 4 : 1)) void conv_halo_bf16_kernel(const woft_conv_params p) {
     constexpr int NWAVES = 4;
     constexpr int NPIX = TY * TX;
@@ -492,9 +494,7 @@ __global__ __launch_bounds__(256, (STAGES == 1 ? 4 : 1)) void conv_halo_bf16_ker
         hpix[j] = hok[j] ? (img0 * p.h + iy) * p.w + ix : 0;
     }
     f32x4 rh[RH], nmu, nrs;
-    constexpr int NLOAD = RH + 2;                        // vector loads per load_halo (counted by vmcnt below)
-    const float* nmean = p.in_norm ? p.in_mean : p.in0;  // (always loaded: keeps the load count fixed)
-    const float* nrstd = p.in_norm ? p.in_rstd : p.in0;
+    constexpr int NLOAD = RH + (NORM ? 2 : 0);           // vector loads per load_halo (counted by vmcnt below)
     auto load_halo = [&](int chunk) {                    // NLOAD unconditional 16-byte loads
         const int c0 = chunk * BK;
         const bool second = (p.in1 != nullptr) && (c0 >= p.c_split);
@@ -502,22 +502,24 @@ __global__ __launch_bounds__(256, (STAGES == 1 ? 4 : 1)) void conv_halo_bf16_ker
         const int cs = second ? p.cs1 : p.cs0;
 #pragma unroll
         for (int j = 0; j < RH; ++j) rh[j] = *(const f32x4*)(src + (uint32_t)(hpix[j] * cs));
-        nmu = *(const f32x4*)(nmean + (p.in_norm ? c0 : 0) + 4 * v);
-        nrs = *(const f32x4*)(nrstd + (p.in_norm ? c0 : 0) + 4 * v);
+        if (NORM) {
+            nmu = *(const f32x4*)(p.in_mean + c0 + 4 * v);
+            nrs = *(const f32x4*)(p.in_rstd + c0 + 4 * v);
+        }
     };
     auto store_halo = [&]() {
         // (pins the use of the prefetched registers HERE: the conversions must not be scheduled up into the taps,
         //  where their wait would drain the weight DMA queue early)
 #pragma unroll
         for (int j = 0; j < RH; ++j) asm volatile("" : "+v"(rh[j]));
-        asm volatile("" : "+v"(nmu), "+v"(nrs));
+        if (NORM) asm volatile("" : "+v"(nmu), "+v"(nrs));
 #pragma unroll
         for (int j = 0; j < RH; ++j) {
             const int ht = r0 + 32 * j;
             if (RH * 32 > HROWS && ht >= HROWS) continue;
             const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
             f32x4 x = rh[j];
-            if (p.in_norm) {                             // InstanceNorm (+ ReLU) of the producer, applied on load
+            if (NORM) {                                  // InstanceNorm (+ ReLU) of the producer, applied on load
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float y = (x[e] - nmu[e]) * nrs[e];
@@ -696,12 +698,15 @@ int launch_halo(const woft_conv_params& p, hipStream_t s) {
     const int tyn = (p.ho + TY - 1) / TY, txn = (p.wo + TX - 1) / TX;
     const int64_t mt = (int64_t)p.n_img * tyn * txn;
     dim3 grid((unsigned)(mt * (p.cout_pad / BN)));
-#define HALO_LAUNCH(KY, KX, T) \
-    hipLaunchKernelGGL((conv_halo_bf16_kernel<TY, TX, KY, KX, BN, T, WM, STAGES>), grid, dim3(256), 0, s, p)
-#define HALO_TAPS(T)                                                   \
-    if (p.taps_y == 3 && p.taps_x == 3) HALO_LAUNCH(3, 3, T);          \
-    else if (p.taps_y == 1 && p.taps_x == 5) HALO_LAUNCH(1, 5, T);     \
-    else if (p.taps_y == 5 && p.taps_x == 1) HALO_LAUNCH(5, 1, T);     \
+#define HALO_LAUNCH(KY, KX, T, N) \
+    hipLaunchKernelGGL((conv_halo_bf16_kernel<TY, TX, KY, KX, BN, T, WM, STAGES, N>), grid, dim3(256), 0, s, p)
+#define HALO_TAPS(T)                                                                            \
+    if (p.in_norm != 0) {                 /* encoder residual blocks: 3x3 only */                \
+        if (p.taps_y == 3 && p.taps_x == 3 && TY != 9) HALO_LAUNCH(3, 3, T, (TY != 9));         \
+        else return WOFT_EINVAL;                                                                \
+    } else if (p.taps_y == 3 && p.taps_x == 3) HALO_LAUNCH(3, 3, T, false);                     \
+    else if (p.taps_y == 1 && p.taps_x == 5) HALO_LAUNCH(1, 5, T, false);                       \
+    else if (p.taps_y == 5 && p.taps_x == 1) HALO_LAUNCH(5, 1, T, false);                       \
     else return WOFT_EINVAL
     if (p.precision == 1) { HALO_TAPS(3); } else { HALO_TAPS(1); }
 #undef HALO_TAPS

@@ -207,7 +207,7 @@ def conv_params(x, pc, out, co_off=0, epi=_lib.EPI_LINEAR, x2=None, c_split=0, e
                     halo = 4
     p.halo = halo
     p.in_norm, p.in_mean, p.in_rstd = 0, None, None
-    if in_norm and halo:
+    if in_norm and halo in (1, 4) and (pc.taps_y, pc.taps_x) == (3, 3):      # (instantiated for the 3x3 pixel tiles)
         p.in_norm, p.in_mean, p.in_rstd = int(in_norm), ptr(in_stats[0]), ptr(in_stats[1])
     p._m_tiles = math.ceil(m / tm)
     if halo in HALO_TILES:
