@@ -85,6 +85,9 @@ def main():
     ap.add_argument("--iters", type=int, default=12)
     ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16x3", "bf16"],
                     help="conv / correlation-GEMM arithmetic: exact fp32 MFMA, split-bf16 (fp32-emulating, default), bf16")
+    ap.add_argument("--corr", default="volume", choices=["volume", "otf"],
+                    help="correlation: all-pairs volume in HBM (default; the lookup is the HBM-roofline kernel) or the "
+                         "volume-free on-the-fly lookup (same results)")
     ap.add_argument("--no-alt-precisions", action="store_true",
                     help="skip the short extra runs at the other two precisions (reported under 'alt_precisions')")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -108,6 +111,7 @@ def main():
         conf.flow_config.model = sd
         conf.flow_config.iters = args.iters
         conf.flow_config.precision = precision
+        conf.flow_config.corr = args.corr if precision != "fp32" else "volume"
         trk = conf.tracker_class(conf)
         trk.init(template, mask)
         if args.no_template_cache:

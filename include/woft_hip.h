@@ -26,7 +26,7 @@ extern "C" {
 
 /* ABI / build identification: returns 10000*major + 100*minor + patch. */
 int woft_abi_version(void);
-/* sizeof(woft_conv_params) (which = 0) / sizeof(woft_lookup_params) (which = 1): layout check for FFI mirrors. */
+/* sizeof(woft_conv_params) (which = 0) / woft_lookup_params (1) / woft_lookup_otf_params (2): layout check for FFI mirrors. */
 int woft_sizeof(int which);
 /* developer tuning knob (A/B experiments; call before any launch): key 0 = conv mainloop variant. */
 int woft_set_tuning(int key, int value);
@@ -154,6 +154,25 @@ typedef struct woft_lookup_params {
     int32_t ldo;
 } woft_lookup_params;
 int woft_corr_lookup(const woft_lookup_params* p, void* stream);
+/* Volume-free correlation lookup (the reference's alternate_corr path: corr.py:72-100 and its alt_cuda_corr
+ * extension): the same samples as woft_corr_lookup computed directly from the feature maps,
+ * corr_l(p, q) = alpha * <f1[p], f2_l[q]>, f2_l = fmap2 average-pooled l times -- no P x P volume in memory.
+ * f1 / f2[l]: row-major split operands in the format of woft_corr_gemm_bf16 (terms = 3: woft_split_bf16_lines,
+ * terms = 1: the bf16 plane), one row of k features per pixel; every correlation value is the one that GEMM
+ * would have produced (same products, same order).  Cost grows with the spread of the flow inside each 8 x 8
+ * block of source pixels (bounding box of their windows); results do not depend on it. */
+typedef struct woft_lookup_otf_params {
+    const void* f1;         /* [hf*wf][k] source features (split)                                  */
+    const void* f2[4];      /* [h[l]*w[l]][k] target features of level l (split)                    */
+    int32_t h[4], w[4];
+    int32_t levels, radius, terms;
+    int32_t hf, wf, k;
+    float alpha;            /* 1 / sqrt(k)  (corr.py:68)                                            */
+    const float* coords;    /* [hf*wf][2]                                                           */
+    float* out;             /* [hf*wf][ldo], channel order of woft_corr_lookup                      */
+    int32_t ldo;
+} woft_lookup_otf_params;
+int woft_corr_lookup_otf(const woft_lookup_otf_params* p, void* stream);
 /* NHWC map [h][w][c] -> its rows in 4x4-tile order [(ceil(h/4)*ceil(w/4)*16)][c], zero rows outside the map:
  * the B operand of the correlation GEMM that yields the tiled volume layout above. */
 int woft_tile_rows(const float* in, int32_t h, int32_t w, int32_t c, float* out, void* stream);

@@ -209,3 +209,31 @@ def test_cached_flow_wire_format(tmp_path):
     _, dst2, w2 = prov.compute_flow(img, img, mode="TC", src_img_identifier=("ds", "seq", 9), numpy_out=True)
     _, dst3, w3 = prov.compute_flow(img, img, mode="TC", numpy_out=True)
     assert dst2.shape == (2, h * w) and np.array_equal(dst2, dst3) and np.array_equal(w2, w3)
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("precision,small", [("bf16x3", False), ("bf16", False), ("bf16x3", True)])
+def test_volume_free_correlation_matches_volume(precision, small):
+    """corr='otf' (the lookup computed from the feature maps, no P x P volume; what the reference's alternate_corr
+    selects, corr.py:72-100) gives the same flow and weights as the volume path of the same precision."""
+    sd = synth.make_state_dict(seed=11, small=small, weighted=not small)
+    rt = "orig" if small else "weighted"
+    h, w = 136, 200
+    a, b = synth.make_template(h, w, seq_id=2), synth.make_template(h, w, seq_id=3)
+    outs = {}
+    for corr in ("volume", "otf"):
+        c = _flow_config(sd, 5, raft_type=rt, padding_mode="RAFT", small=small, precision=precision)
+        c.corr = corr
+        prov = c.of_class(c)
+        assert prov.engine.corr == corr
+        fl, wt = prov.compute_flow(a, b, mode="flow", numpy_out=True)
+        outs[corr] = (fl, wt)
+    # identical correlation values and identical interpolation arithmetic: the whole flow is bit-identical
+    assert np.array_equal(outs["otf"][0], outs["volume"][0])
+    if not small:
+        assert np.array_equal(outs["otf"][1], outs["volume"][1])
+    # it is the default in these precisions; fp32 keeps the volume
+    c = _flow_config(sd, 5, raft_type=rt, padding_mode="RAFT", small=small, precision=precision)
+    assert c.of_class(c).engine.corr == "otf"
+    c = _flow_config(sd, 5, raft_type=rt, padding_mode="RAFT", small=small, precision="fp32")
+    assert c.of_class(c).engine.corr == "volume"

@@ -160,3 +160,51 @@ def test_flow_of_identical_frames_is_deterministic_fullsize():
     idx = torch.arange(H * W, device="cuda")
     assert torch.equal(s2[0], idx % W) and torch.equal(s2[1], idx // W) and s2.dtype == torch.int64
     assert bool(torch.isfinite(d2).all()) and float(w2.min()) >= 0.0 and float(w2.max()) <= 1.0
+
+
+def test_volume_free_lookup_equals_volume_lookup_fullsize(ops):
+    """1080p feature size, split-bf16: the on-the-fly lookup (no volume) returns bit for bit what the lookup in the
+    5.6 GB volume built by the correlation GEMM returns -- for a smooth field, for independent per-pixel offsets and
+    for windows hanging over every border."""
+    g = torch.Generator(device="cuda").manual_seed(3)
+    f1 = torch.randn(HF * WF, C, device="cuda", generator=g) * 0.3
+    f2 = ops.new_act(1, HF, WF, C)
+    f2.t.copy_(torch.randn(HF * WF, C, device="cuda", generator=g) * 0.3)
+
+    def split(t):
+        o = torch.zeros(t.shape[0], 2 * C, dtype=torch.bfloat16, device="cuda")
+        ops.split_bf16_lines(t.contiguous(), o)
+        return o
+    a = torch.zeros(ops._round_up(HF * WF, 128), C, device="cuda")
+    a[:HF * WF] = f1
+    sa = split(a)
+    vols, dims, f2s, cur = [], [], [], f2
+    for l in range(4):
+        h, w = cur.h, cur.w
+        n = ops.tiled_dims(h, w)[2]
+        rows = torch.zeros(ops._round_up(n, 128), C, device="cuda")
+        ops.tile_rows(cur, rows)
+        vol = torch.zeros(HF * WF, n, device="cuda")
+        ops.corr_gemm_bf16(sa, split(rows), HF * WF, n, 1.0 / math.sqrt(C), vol, 3)
+        vols.append(vol)
+        dims.append((h, w))
+        f2s.append(split(cur.t))
+        if l < 3:
+            nxt = ops.new_act(1, h // 2, w // 2, C)
+            ops.avgpool2(cur, nxt)
+            cur = nxt
+    idx = torch.arange(HF * WF, device="cuda")
+    grid = torch.stack([idx % WF, idx // WF], 1).float()
+    fields = {
+        "smooth": grid * 1.01 + torch.tensor([2.3, -1.7], device="cuda"),
+        "scattered": grid + (torch.rand(HF * WF, 2, device="cuda", generator=g) * 2 - 1) * 12.0,
+        "borders": grid * 1.2 - torch.tensor([20.0, 12.0], device="cuda"),
+    }
+    for name, coords in fields.items():
+        coords = coords.contiguous()
+        ref = torch.zeros(HF * WF, 352, device="cuda")
+        out = torch.zeros(HF * WF, 352, device="cuda")
+        ops.run_lookup(ops.make_lookup_params(vols, dims, coords, ref, 4))
+        ops.run_lookup_otf(ops.make_lookup_otf_params(sa, f2s, dims, HF, WF, C, coords, out, 4, 3))
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref), f"{name}: volume-free lookup differs from the lookup in the volume"

@@ -406,6 +406,43 @@ def test_corr_gemm_presplit(ops, h, w, precision, tol):
         _close(vols[l], ref[l], tol * 0.1, what=f"level {l}: pre-split GEMM vs the conv kernel")
 
 
+@pytest.mark.parametrize("h,w,precision,spread", [(17, 25, "bf16x3", 2.0), (24, 40, "bf16x3", 30.0), (16, 20, "bf16", 3.0),
+                                                  (9, 11, "bf16x3", 200.0)])
+def test_lookup_on_the_fly(ops, h, w, precision, spread):
+    """Volume-free lookup (woft_corr_lookup_otf) == lookup in the volume built by the correlation GEMM in the same
+    arithmetic, bit for bit (identical correlation values, identical interpolation), for smooth, scattered and
+    far-out-of-map coordinates."""
+    c = 256
+    f1, f2 = _rand(1, c, h, w, seed=51), _rand(1, c, h, w, seed=52)
+    vols, dims = _build_pyramid_gpu(ops, f1, f2, precision, presplit=True)
+    coords = raft_ref.coords_grid(1, h, w) + _rand(1, 2, h, w, seed=53, scale=spread)
+    coords[0, :, 0, 0] = torch.tensor([-7.3, 2.2])
+    coords[0, :, h - 1, w - 1] = torch.tensor([w + 9.5, h + 3.0])
+    cg = coords[0].permute(1, 2, 0).reshape(h * w, 2).contiguous().cuda()
+    ref = torch.zeros(h * w, 352, device="cuda")
+    ops.run_lookup(ops.make_lookup_params(vols, dims, cg, ref, 4))
+    # the same operands, row-major and split
+    x3 = precision == "bf16x3"
+    a1, a2 = ops.act_from_nchw(f1), ops.act_from_nchw(f2)
+
+    def split(t):
+        o = torch.zeros(t.shape[0], c * (2 if x3 else 1), dtype=torch.bfloat16, device="cuda")
+        ops.split_bf16_lines(t, o) if x3 else ops.split_bf16(t, o, None)
+        return o
+    f2s, cur = [], a2
+    for l in range(4):
+        f2s.append(split(cur.t.contiguous()))
+        if l < 3:
+            nxt = ops.new_act(1, cur.h // 2, cur.w // 2, c)
+            ops.avgpool2(cur, nxt)
+            cur = nxt
+    out = torch.full((h * w, 352), 7.0, device="cuda")
+    ops.run_lookup_otf(ops.make_lookup_otf_params(split(a1.t.contiguous()), f2s, dims, h, w, c, cg, out, 4, 3 if x3 else 1))
+    torch.cuda.synchronize()
+    assert torch.equal(out[:, :324], ref[:, :324]), "on-the-fly lookup differs from the lookup in the volume"
+    assert float((out[:, 324:] - 7.0).abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("radius", [4, 3])
 def test_lookup_golden_handmade(ops, golden_dir, radius):
     g = np.load(golden_dir / "lookup_handmade.npz")

@@ -39,6 +39,14 @@ class LookupParams(C.Structure):
     ]
 
 
+class LookupOtfParams(C.Structure):
+    _fields_ = [
+        ("f1", vp), ("f2", vp * 4), ("h", i32 * 4), ("w", i32 * 4),
+        ("levels", i32), ("radius", i32), ("terms", i32), ("hf", i32), ("wf", i32), ("k", i32),
+        ("alpha", f32), ("coords", vp), ("out", vp), ("ldo", i32),
+    ]
+
+
 _SIGS = {
     "woft_abi_version": (i32, []),
     "woft_sizeof": (i32, [i32]),
@@ -47,6 +55,7 @@ _SIGS = {
     "woft_split_bf16": (i32, [vp, i64, vp, vp, vp]),
     "woft_split_bf16_lines": (i32, [vp, i64, vp, vp]),
     "woft_flow_to_tc": (i32, [vp, vp, i32, i32, vp, vp, i32, vp]),
+    "woft_corr_lookup_otf": (i32, [C.POINTER(LookupOtfParams), vp]),
     "woft_conv3x3_narrow": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, i64, i32, vp]),
     "woft_corr_gemm_bf16": (i32, [vp, vp, i64, i64, i64, i64, i32, f32, vp, i64, i32, vp]),
     "woft_inorm_finalize": (i32, [vp, vp, i32, i32, i32, i32, i64, f32, vp, vp, vp]),
@@ -91,7 +100,8 @@ def load():
     for name, (res, args) in _SIGS.items():
         fn = getattr(lib, name)           # AttributeError if a declared symbol is not exported
         fn.restype, fn.argtypes = res, args
-    if lib.woft_sizeof(0) != C.sizeof(ConvParams) or lib.woft_sizeof(1) != C.sizeof(LookupParams):
+    if lib.woft_sizeof(0) != C.sizeof(ConvParams) or lib.woft_sizeof(1) != C.sizeof(LookupParams) \
+            or lib.woft_sizeof(2) != C.sizeof(LookupOtfParams):
         raise WoftHipError("ctypes mirror of woft_conv_params / woft_lookup_params is out of sync with the library")
     if os.environ.get("WOFT_CONV_DEEP"):
         lib.woft_set_tuning(0, int(os.environ["WOFT_CONV_DEEP"]))

@@ -28,6 +28,7 @@
 #include <type_traits>
 
 #include "conv_common.h"
+#include "dma.h"
 
 namespace {
 
@@ -38,26 +39,6 @@ using woft::BK;
 //   [0] gather kernel: 0 = register-staged operands, one LDS stage; 1 = B by LDS-DMA, two stages, one barrier per step
 //   [1] unused (was: halo kernel weight path);  [2] corr GEMM ablation bits
 int g_tuning[4] = {0, 1, 0, 0};
-
-// One LDS-DMA wave instruction: lane L copies 16 bytes from (gbase + lane_off) to LDS byte address lds_addr + 16 L.
-// gbase and lds_addr are wave-uniform (SGPRs).  Written as inline assembly so that (1) the address is the
-// scalar-base + 32-bit-lane-offset form and (2) the compiler does not count it: it would otherwise drain EVERY
-// outstanding global load (vmcnt(0)) at the next barrier, including prefetches that are meant to stay in flight.
-// The caller orders it explicitly with dma_wait<N>() before the barrier that publishes the data.
-__device__ __forceinline__ void lds_dma16(const void* gbase, uint32_t lane_off, uint32_t lds_addr) {
-    uint32_t saved_m0;                                   // m0 is a reserved register: hand it back as found
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
-                 : "=&s"(saved_m0)
-                 : "s"(lds_addr), "v"(lane_off), "s"(gbase)
-                 : "memory");
-}
-template <int N>
-__device__ __forceinline__ void dma_wait() {             // at most N vector-memory loads still in flight
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-__device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
-    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
-}
 
 constexpr int LDS_LD = 36;   // fp32 tiles: floats per row (144 B: 16-B aligned, conflict-free b128 reads)
 

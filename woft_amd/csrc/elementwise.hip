@@ -139,5 +139,6 @@ extern "C" int woft_avgpool2_nhwc(const float* in, int32_t h, int32_t w, int32_t
 extern "C" int woft_sizeof(int which) {
     if (which == 0) return (int)sizeof(woft_conv_params);
     if (which == 1) return (int)sizeof(woft_lookup_params);
+    if (which == 2) return (int)sizeof(woft_lookup_otf_params);
     return -1;
 }

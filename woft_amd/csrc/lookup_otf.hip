@@ -1,0 +1,252 @@
+// Volume-free correlation lookup (the reference's alt_cuda_corr idea, corr.py:72-100 + the CUDA
+// extension it binds): the (2r+1)^2 x L bilinear samples of corr.py:29-59 computed straight from the feature maps,
+//   corr_l(p, q) = alpha * <fmap1[p], pool_l(fmap2)[q]>         (pooling commutes with the dot product)
+// without ever materialising the P x P volume (5.6 GB at 1080p, 89 GB at 4K).
+//
+// A workgroup owns an 8 x 8 block of source pixels.  Per pyramid level it finds the bounding box of the 64 lookup
+// windows (for a smooth flow field: (8 / 2^l + 2r + 1)^2 target pixels), and computes the 64 x |box| block of
+// correlations as a split-bf16 MFMA GEMM -- 64 box positions at a time, both operand tiles copied global -> LDS by
+// LDS-DMA exactly as in corr_gemm_bf16_kernel (same operand format, same product order: every correlation value is
+// bit-identical to the one the volume GEMM would have stored).  After each 64-column chunk every lane drops its 16
+// correlations into the (2r+2)^2 windows (LDS) of the pixels whose window contains that box position; when the box
+// is done the samples are interpolated from the pixel's own window with the arithmetic of corr_lookup_kernel, so the
+// output equals the volume path's bit for bit.  A window of an outlier pixel only enlarges its block's box (more
+// chunks): always correct, fast when the flow is locally smooth.
+//
+// Sampling rule, channel order and zero padding: as corr_lookup_kernel (lookup.hip).
+#include "common.h"
+#include "dma.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+template <int TERMS, int R, int K>
+__global__ __launch_bounds__(256, 2) void corr_lookup_otf_kernel(const woft_lookup_otf_params p) {
+    constexpr int NW = 2 * R + 1, N2 = NW * NW;
+    constexpr int NS = (N2 + 3) / 4;                    // samples per thread (4 threads per pixel)
+    constexpr int LD = (TERMS == 3) ? 2 * K : K;        // elements per operand row
+    constexpr int NK = LD / 64;                         // K steps (one 128-byte line each)
+    constexpr int NSUB = (TERMS == 3) ? 2 : 4;          // MFMA k sub-steps per line
+    constexpr int NST = 6, DEPTH = 5;                   // LDS ring: DEPTH steps of B rows in flight (latency from beyond L2)
+    __shared__ __attribute__((aligned(16))) __bf16 stage[NST * 64 * 64];    // NST stages of 64 B rows, 128 B each
+    constexpr int WS = NW + 1, WLD = WS * WS + 1;       // (2r+2)^2 window of a pixel (+1: spreads the LDS banks)
+    __shared__ float Wn[64 * WLD];                      // the windows of the 64 source pixels at the current level
+    __shared__ int s_wx0[64], s_wy0[64];
+    __shared__ float s_fx[64], s_fy[64];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r32 = lane & 31, hh = lane >> 5;
+    constexpr int ld = LD, nk = NK;
+    // workgroup -> 8 x 8 tile: consecutive workgroup ids land on consecutive XCDs (private L2 each), so the ids are
+    // re-dealt to give every XCD a contiguous band of tiles -- neighbouring tiles' boxes overlap ~5x and then hit in L2
+    const int tiles_x = (p.wf + 7) / 8, ntiles = tiles_x * ((p.hf + 7) / 8);
+    int tile;
+    {
+        const int q = ntiles / 8, rr = ntiles % 8, xcd = blockIdx.x % 8, idx = blockIdx.x / 8;
+        tile = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
+    }
+    const int px0 = (tile % tiles_x) * 8, py0 = (tile / tiles_x) * 8;
+
+    // The block's source features stay in REGISTERS for the whole kernel, as the MFMA A fragments of this wave's
+    // 32 rows (lane (r32, hh): row r32, k = 8 (2 s + hh) .. + 7 of every line; hi and lo halves of the line) -- the
+    // first version re-fetched the A tile with every 64-column chunk and was bound by that L2 -> LDS traffic.
+    bf16x8 afr[NK][NSUB][TERMS == 3 ? 2 : 1];
+    {
+        const int m = wm * 32 + r32;
+        int y = py0 + (m >> 3), x = px0 + (m & 7);
+        y = y < p.hf ? y : p.hf - 1;                    // rows outside the grid repeat a valid pixel (never written)
+        x = x < p.wf ? x : p.wf - 1;
+        const char* row = (const char*)p.f1 + (int64_t)(y * p.wf + x) * (ld * 2);
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks)
+#pragma unroll
+            for (int s2 = 0; s2 < NSUB; ++s2) {
+                afr[ks][s2][0] = *(const bf16x8*)(row + ks * 128 + (s2 * 2 + hh) * 16);
+                if (TERMS == 3) afr[ks][s2][TERMS == 3 ? 1 : 0] = *(const bf16x8*)(row + ks * 128 + 64 + (s2 * 2 + hh) * 16);
+            }
+    }
+    // B stream: DMA pieces q = wave + 4 t (t = 0, 1) of a step = rows 8 q .. 8 q + 7 of the 64 box positions;
+    // lane -> (row lane / 8, physical chunk lane % 8) holding logical chunk (lane % 8) ^ ((row >> 1) & 7)
+    const int swz = (4 * (wave & 1) + (lane >> 4)) & 7;
+    const uint32_t chunk_off = (uint32_t)(((lane & 7) ^ swz) * 16);
+    const uint32_t st_addr = lds_addr_of(stage);
+    const int sw = (r32 >> 1) & 7;
+    const __bf16* b_rows = stage + (wn * 32 + r32) * 64;
+
+    const int mypix = tid >> 2, part = tid & 3;         // gather: 4 threads per source pixel
+    const int gy = py0 + (mypix >> 3), gx = px0 + (mypix & 7);
+    const bool pvalid = gy < p.hf && gx < p.wf;
+
+    for (int l = 0; l < p.levels; ++l) {
+        const int W = p.w[l], H = p.h[l];
+        if (tid < 64) {
+            const int y = py0 + (tid >> 3), x = px0 + (tid & 7);
+            int wx0 = 0x3fffffff, wy0 = 0x3fffffff;     // (outside the grid: excluded from the box)
+            float fx = 0.f, fy = 0.f;
+            if (y < p.hf && x < p.wf) {
+                const float sc = 1.0f / (float)(1 << l);
+                const float xs = p.coords[((int64_t)y * p.wf + x) * 2] * sc, ys = p.coords[((int64_t)y * p.wf + x) * 2 + 1] * sc;
+                float flx = floorf(xs), fly = floorf(ys);
+                fx = xs - flx;
+                fy = ys - fly;
+                flx = fminf(fmaxf(flx, -1.0e6f), 1.0e6f);
+                fly = fminf(fmaxf(fly, -1.0e6f), 1.0e6f);
+                wx0 = (int)flx - R;
+                wy0 = (int)fly - R;
+            }
+            s_wx0[tid] = wx0; s_wy0[tid] = wy0; s_fx[tid] = fx; s_fy[tid] = fy;
+        }
+        __syncthreads();
+        // bounding box of the valid windows: butterfly over the 64 lanes of every wave (all waves hold the result)
+        int bx0, bx1, by0, by1;
+        {
+            const int vx = s_wx0[lane], vy = s_wy0[lane];
+            const bool ok = vx != 0x3fffffff;
+            bx0 = ok ? vx : 0x3fffffff; bx1 = ok ? vx : -0x3fffffff;
+            by0 = ok ? vy : 0x3fffffff; by1 = ok ? vy : -0x3fffffff;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                const int a0 = __shfl_xor(bx0, d, 64), a1 = __shfl_xor(bx1, d, 64);
+                const int c0 = __shfl_xor(by0, d, 64), c1 = __shfl_xor(by1, d, 64);
+                bx0 = a0 < bx0 ? a0 : bx0; bx1 = a1 > bx1 ? a1 : bx1;
+                by0 = c0 < by0 ? c0 : by0; by1 = c1 > by1 ? c1 : by1;
+            }
+            bx0 = __builtin_amdgcn_readfirstlane(bx0); bx1 = __builtin_amdgcn_readfirstlane(bx1);
+            by0 = __builtin_amdgcn_readfirstlane(by0); by1 = __builtin_amdgcn_readfirstlane(by1);
+        }
+        bx0 = bx0 > 0 ? bx0 : 0;
+        by0 = by0 > 0 ? by0 : 0;
+        bx1 = (bx1 + NW < W - 1) ? bx1 + NW : W - 1;     // windows span wx0 .. wx0 + 2R + 1
+        by1 = (by1 + NW < H - 1) ? by1 + NW : H - 1;
+        const int bw = bx1 - bx0 + 1, bh = by1 - by0 + 1;
+        const int N = (bw > 0 && bh > 0) ? bw * bh : 0;
+
+        for (int i = tid; i < 64 * WLD; i += 256) Wn[i] = 0.f;      // cells outside the map stay zero
+        // (visible to all waves after the first step barrier below; S == 0: the barrier before the interpolation)
+
+        const char* f2 = (const char*)p.f2[l];
+        // ---- K steps of all 64-column chunks of the box as ONE stream through an LDS ring: the B rows of step
+        //      s + DEPTH are requested while step s computes (one workgroup barrier per step) ----
+        const int nchunk = (N + 63) / 64;
+        const int S = nchunk * nk;
+        uint32_t b_off[2] = {0u, 0u};
+        int is_c = 0, is_k = 0;                          // (chunk, k step) of the next step to request
+        auto issue = [&](int s_idx) {
+            if (is_k == 0) {                             // new chunk: rows of the box positions c0 .. c0 + 63
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    int pos = is_c * 64 + (wave + 4 * t) * 8 + (lane >> 3);
+                    pos = pos < N ? pos : N - 1;        // (columns past the box repeat its last position; never read)
+                    const int by = pos / bw, bx = pos - by * bw;
+                    b_off[t] = (uint32_t)((by0 + by) * W + bx0 + bx) * (uint32_t)(ld * 2) + chunk_off;
+                }
+            }
+            const uint32_t st = st_addr + (uint32_t)(s_idx % NST) * 8192u;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) lds_dma16(f2 + is_k * 128, b_off[t], st + (uint32_t)(wave + 4 * t) * 1024u);
+            if (++is_k == nk) { is_k = 0; ++is_c; }
+        };
+        for (int s_idx = 0; s_idx < DEPTH && s_idx < S; ++s_idx) issue(s_idx);
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        int c0 = 0;
+        for (int s0 = 0; s0 < S; s0 += NK) {             // one 64-column chunk per iteration, K steps unrolled
+#pragma unroll
+            for (int ks = 0; ks < NK; ++ks) {
+                const int s_idx = s0 + ks;
+                // this step's two pieces have landed; those of the following (up to DEPTH - 1) steps may still fly
+                const int rem = S - 1 - s_idx;
+                if (rem >= 4) dma_wait<8>();
+                else if (rem == 3) dma_wait<6>();
+                else if (rem == 2) dma_wait<4>();
+                else if (rem == 1) dma_wait<2>();
+                else dma_wait<0>();
+                __syncthreads();                         // ... for every wave; and step s - 1 is fully consumed
+                if (s_idx + DEPTH < S) issue(s_idx + DEPTH);     // into the stage of step s - 1
+                const __bf16* br = b_rows + (s_idx % NST) * 4096;
+                if (TERMS == 3) {
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        const int ch = ((s2 * 2 + hh) ^ sw) * 8, cl = ((4 + s2 * 2 + hh) ^ sw) * 8;
+                        const bf16x8 bh = *(const bf16x8*)(br + ch), bl = *(const bf16x8*)(br + cl);
+                        const bf16x8 ah = afr[ks][s2][0], al = afr[ks][s2][TERMS == 3 ? 1 : 0];
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);   // (order of corr_gemm_bf16_kernel)
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int s2 = 0; s2 < 4; ++s2) {
+                        const int ch = ((s2 * 2 + hh) ^ sw) * 8;
+                        const bf16x8 bh = *(const bf16x8*)(br + ch);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks][s2][0], bh, acc, 0, 0, 0);
+                    }
+                }
+            }
+            // ---- chunk complete: every lane drops its 16 correlations (one box position, 16 source pixels) into
+            //      the windows that contain that position (zero outside the map = never written) ----
+            {
+                const int pos = c0 + wn * 32 + r32;
+                const int by = pos / bw, bx = pos - by * bw;
+                const int tx = bx0 + bx, ty = by0 + by;  // target pixel of this column
+                const bool col_ok = pos < N;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    const int cx = tx - s_wx0[m], cy = ty - s_wy0[m];
+                    if (col_ok && cx >= 0 && cx < WS && cy >= 0 && cy < WS) Wn[m * WLD + cy * WS + cx] = acc[r] * p.alpha;
+                    acc[r] = 0.f;
+                }
+            }
+            c0 += 64;
+        }
+        __syncthreads();
+        // ---- bilinear samples from the pixel's own window: the arithmetic of corr_lookup_kernel ----
+        if (pvalid) {
+            const float fx = s_fx[mypix], fy = s_fy[mypix];
+            const float* wq = Wn + mypix * WLD;
+            float* o = p.out + ((int64_t)gy * p.wf + gx) * p.ldo + l * N2;
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                const int s = part + 4 * k;
+                if (s >= N2) break;
+                const int i = (NW == 9) ? (s * 57) >> 9 : (s * 37) >> 8;   // = s / NW for s < NW^2 (NW = 9 / 7)
+                const int j = s - i * NW;                           // i: x offset, j: y offset (x-major window)
+                const float* q = wq + j * WS + i;
+                const float top = q[0] * (1.f - fx) + q[1] * fx;
+                const float bot = q[WS] * (1.f - fx) + q[WS + 1] * fx;
+                o[s] = top * (1.f - fy) + bot * fy;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+extern "C" int woft_corr_lookup_otf(const woft_lookup_otf_params* pp, void* stream) {
+    if (!pp) return WOFT_EINVAL;
+    const woft_lookup_otf_params& p = *pp;
+    if (p.levels < 1 || p.levels > 4 || !p.f1 || !p.coords || !p.out || p.hf <= 0 || p.wf <= 0) return WOFT_EINVAL;
+    if (p.terms != 1 && p.terms != 3) return WOFT_EINVAL;
+    if (p.k <= 0 || p.k % (p.terms == 3 ? 32 : 64) != 0) return WOFT_EINVAL;
+    const int64_t row_bytes = (int64_t)p.k * (p.terms == 3 ? 4 : 2);
+    if ((int64_t)p.hf * p.wf * row_bytes >= (1ll << 32)) return WOFT_EINVAL;        // 32-bit lane offsets
+    for (int l = 0; l < p.levels; ++l)
+        if (!p.f2[l] || p.h[l] <= 0 || p.w[l] <= 0 || (int64_t)p.h[l] * p.w[l] * row_bytes >= (1ll << 32)) return WOFT_EINVAL;
+    const int nout = p.levels * (2 * p.radius + 1) * (2 * p.radius + 1);
+    if (p.ldo < nout) return WOFT_EINVAL;
+    dim3 grid((unsigned)(((p.wf + 7) / 8) * ((p.hf + 7) / 8)));
+    hipStream_t s = (hipStream_t)stream;
+#define OTF(T, RR, KK) hipLaunchKernelGGL((corr_lookup_otf_kernel<T, RR, KK>), grid, dim3(256), 0, s, p)
+    if (p.k == 256 && p.radius == 4) { if (p.terms == 3) OTF(3, 4, 256); else OTF(1, 4, 256); }       /* full model  */
+    else if (p.k == 128 && p.radius == 3) { if (p.terms == 3) OTF(3, 3, 128); else OTF(1, 3, 128); }  /* small model */
+    else return WOFT_EINVAL;
+#undef OTF
+    return woft_launch_status();
+}

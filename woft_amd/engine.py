@@ -86,11 +86,18 @@ class _Enc:
 
 
 class RaftEngine:
-    def __init__(self, state_dict, small=False, weighted=True, precision="fp32"):
-        """precision: "fp32" (exact fp32 MFMA), "bf16x3" (split-bf16, fp32-emulating) or "bf16"."""
+    def __init__(self, state_dict, small=False, weighted=True, precision="fp32", corr="volume"):
+        """precision: "fp32" (exact fp32 MFMA), "bf16x3" (split-bf16, fp32-emulating) or "bf16".
+        corr: "volume" (all-pairs volume + pyramid in HBM, corr.py:13-69) or "otf" (volume-free lookup from the
+        feature maps, the reference's alternate_corr idea, corr.py:72-100; split-bf16 precisions only)."""
         if precision not in ops.PRECISION:
             raise ValueError(f"precision must be one of {sorted(ops.PRECISION)}")
+        if corr not in ("volume", "otf"):
+            raise ValueError("corr must be 'volume' or 'otf'")
+        if corr == "otf" and precision == "fp32":
+            raise ValueError("corr='otf' runs on the split-bf16 matrix-core path: precision 'bf16x3' or 'bf16'")
         self.precision = precision
+        self.corr = corr
         _lib.load()
         if not torch.cuda.is_available():
             raise _lib.WoftHipError("woft_amd needs a HIP device: there is no CPU fallback")
@@ -166,17 +173,22 @@ class _Plan:
         self.f1s = bf(self.f1rows)
         # target feature pyramid: linear NHWC maps (f2act) and their rows in 4x4-tile order (f2rows, the B
         # operand of the correlation GEMM, zero padded to the N tile) -> volumes in the tiled layout
+        # (corr = "otf": no volume; the lookup reads the row-major split maps f2s directly)
+        self.otf = eng.corr == "otf"
         self.dims, self.f2rows, self.f2act, self.vol = [], [], [], []
         self.f2s = []
         h, w = hf, wf
         for _ in range(sp.levels):
             self.dims.append((h, w))
-            n = ops.tiled_dims(h, w)[2]
-            rows = z(_ru(n, 128), sp.fdim)
-            self.f2rows.append(rows)
-            self.f2s.append(bf(rows))
             self.f2act.append(new_act(1, h, w, sp.fdim, zero=True))
-            self.vol.append(z(P, n))
+            if self.otf:
+                self.f2s.append(bf(self.f2act[-1].t))
+            else:
+                n = ops.tiled_dims(h, w)[2]
+                rows = z(_ru(n, 128), sp.fdim)
+                self.f2rows.append(rows)
+                self.f2s.append(bf(rows))
+                self.vol.append(z(P, n))
             h, w = h // 2, w // 2
         # context: GRU state and the GRU input buffer [inp | motion | flow | pad]
         self.net0 = new_act(1, hf, wf, sp.hdim, zero=True)
@@ -206,7 +218,11 @@ class _Plan:
         self.hB = new_act(1, hf, wf, sp.hdim, zero=True)
         self.fh = new_act(1, hf, wf, 128 if sp.small else 256, zero=True)
         self.delta = new_act(1, hf, wf, 2, cs=4, zero=True)
-        self.lookup = ops.make_lookup_params(self.vol, self.dims, self.coords, self.corr.t, sp.radius)
+        if self.otf:
+            self.lookup = ops.make_lookup_otf_params(self.f1s, self.f2s, self.dims, hf, wf, sp.fdim, self.coords,
+                                                     self.corr.t, sp.radius, 3 if x3 else 1)
+        else:
+            self.lookup = ops.make_lookup_params(self.vol, self.dims, self.coords, self.corr.t, sp.radius)
         self.prog_iter_first = self._iter_program(first=True)
         self.prog_iter = self._iter_program(first=False)
         self.prog_mask = []
@@ -311,6 +327,9 @@ class _Plan:
         for l in range(sp.levels):
             if l > 0:
                 prog.append(("pool", (self.f2act[l - 1], self.f2act[l])))
+            if self.otf:        # only the operands: pooled maps, split once
+                prog.append(("split", (self.f2act[l].t, self.f2s[l])))
+                continue
             prog.append(("tile", (self.f2act[l], self.f2rows[l])))
             if self.prec == "fp32":
                 prog.append(("conv", ops.corr_volume(self.f1, self.f2rows[l], self.vol[l].shape[1], self.vol[l], alpha)))
@@ -387,12 +406,13 @@ class _Plan:
                 raise ValueError(kind)
 
     def _lookup(self, params):
+        run = ops.run_lookup_otf if self.otf else ops.run_lookup
         if self.lookup_events is None:
-            ops.run_lookup(params)
+            run(params)
             return
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
-        ops.run_lookup(params)
+        run(params)
         e.record()
         self.lookup_events.append((s, e))
 

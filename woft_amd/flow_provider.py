@@ -42,8 +42,6 @@ class RAFTWrapper:
     def __init__(self, config):
         self.C = config
         cp = config.class_params
-        if cp.alternate_corr:
-            raise NotImplementedError("alternate_corr is never enabled by the reference configs (corr.py:72-100)")
         if cp.mask_estimation:
             raise NotImplementedError("mask_estimation (MaskHead) is unset in every shipped config")
         if self.C.raft_type not in ("orig", "weighted"):
@@ -58,7 +56,15 @@ class RAFTWrapper:
         # `mixed_precision=True` (autocast in the reference, weighted_raft.py:204,215,233) selects "bf16".
         self.precision = os.environ.get("WOFT_PRECISION") or self.C.precision or \
             ("bf16" if cp.mixed_precision else "fp32")
-        self.engine = RaftEngine(state_dict, small=small, weighted=weighted, precision=self.precision)
+        # correlation: "volume" (all-pairs volume + pyramid in HBM, corr.py:13-69) or "otf" (volume-free lookup, what
+        # the reference's `alternate_corr` switch selects, corr.py:72-100).  Bit-identical results in the split-bf16
+        # precisions, where "otf" is faster and needs no P x P buffer: it is the default there.
+        self.corr = os.environ.get("WOFT_CORR") or getattr(self.C, "corr", None) or \
+            ("volume" if self.precision == "fp32" else "otf")
+        if self.corr == "otf" and self.precision == "fp32":
+            raise ValueError("alternate_corr / corr='otf' runs on the split-bf16 matrix-core path: set precision "
+                             "'bf16x3' (fp32-emulating) or 'bf16'")
+        self.engine = RaftEngine(state_dict, small=small, weighted=weighted, precision=self.precision, corr=self.corr)
         self._pinned = None
         self._pinned_key = None
         self._out = {}

@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import ConvParams, LookupParams, check, ptr, stream_ptr
+from ._lib import ConvParams, LookupOtfParams, LookupParams, check, ptr, stream_ptr
 
 DEV = "cuda"
 
@@ -274,6 +274,24 @@ def narrow_ok(x, pc):
     """True when woft_conv3x3_narrow applies to this layer."""
     return ((pc.taps_y, pc.taps_x, pc.stride, pc.pad_y, pc.pad_x, pc.flat) == (3, 3, 1, 1, 1, 0) and pc.cout <= 2
             and pc.cin_pad in (128, 256) and x.cs >= pc.cin_pad)
+
+
+def make_lookup_otf_params(f1s, f2s, dims, hf, wf, k, coords, out, radius, terms):
+    """Volume-free lookup (woft_corr_lookup_otf): f1s / f2s[l] split feature rows (row-major), dims[l] = (h, w)."""
+    p = LookupOtfParams()
+    p.f1 = ptr(f1s)
+    for l, (t, (h, w)) in enumerate(zip(f2s, dims)):
+        p.f2[l], p.h[l], p.w[l] = ptr(t), h, w
+    p.levels, p.radius, p.terms = len(f2s), radius, terms
+    p.hf, p.wf, p.k = hf, wf, k
+    p.alpha = 1.0 / math.sqrt(float(k))
+    p.coords, p.out, p.ldo = ptr(coords), ptr(out), out.shape[1]
+    p._keep = (f1s, f2s, coords, out)
+    return p
+
+
+def run_lookup_otf(p):
+    check(_lib.load().woft_corr_lookup_otf(C.byref(p), stream_ptr()), "woft_corr_lookup_otf")
 
 
 def split_bf16_lines(x, out):
