@@ -85,9 +85,13 @@ def main():
     ap.add_argument("--iters", type=int, default=12)
     ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16x3", "bf16"],
                     help="conv / correlation-GEMM arithmetic: exact fp32 MFMA, split-bf16 (fp32-emulating, default), bf16")
-    ap.add_argument("--corr", default="volume", choices=["volume", "otf"],
-                    help="correlation: all-pairs volume in HBM (default; the lookup is the HBM-roofline kernel) or the "
-                         "volume-free on-the-fly lookup (same results)")
+    ap.add_argument("--corr", default="otf", choices=["volume", "otf"],
+                    help="correlation: volume-free on-the-fly lookup (default in the split-bf16 precisions) or the "
+                         "all-pairs volume in HBM whose lookup is the HBM-roofline kernel (bit-identical results; "
+                         "fp32 precision always uses the volume)")
+    ap.add_argument("--no-alt-corr", action="store_true",
+                    help="skip the short extra run in the other correlation mode (reported under 'alt_corr'; in the "
+                         "default mode it also measures the volume lookup for 'roofline_lookup')")
     ap.add_argument("--no-alt-precisions", action="store_true",
                     help="skip the short extra runs at the other two precisions (reported under 'alt_precisions')")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -106,12 +110,12 @@ def main():
     template, frames = make_sequence(H, W, rank, Wm + K)
     mask = synth.make_init_mask(H, W)
 
-    def make_tracker(precision):
+    def make_tracker(precision, corr=None):
         conf = load_config(ROOT / "pytracking" / "configs" / "WOFT.py")
         conf.flow_config.model = sd
         conf.flow_config.iters = args.iters
         conf.flow_config.precision = precision
-        conf.flow_config.corr = args.corr if precision != "fp32" else "volume"
+        conf.flow_config.corr = (corr or args.corr) if precision != "fp32" else "volume"
         trk = conf.tracker_class(conf)
         trk.init(template, mask)
         if args.no_template_cache:
@@ -120,13 +124,14 @@ def main():
 
     tracker = make_tracker(args.precision)
     plan = tracker.flower.engine.plan(H, W)
+    corr_mode = tracker.flower.engine.corr
 
     results = []
     for f in frames[:Wm]:
         results.append(tracker.track(f))
     wdist.gather_tracks(results[:1])        # untimed: creates the RCCL communicator / warms the collective
     torch.cuda.synchronize()
-    plan.lookup_events = []
+    plan.lookup_events, plan.wh_events = [], []
     wdist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -137,23 +142,50 @@ def main():
     wdist.barrier()
     elapsed = time.perf_counter() - t0
     elapsed = wdist.max_over_ranks(elapsed)
-    events = plan.lookup_events
-    plan.lookup_events = None
+    events, wh_events = plan.lookup_events, plan.wh_events
+    plan.lookup_events = plan.wh_events = None
 
     if rank != 0:
         return
     n_lost = int(tracks[:, :, 9].sum().item())
-    lk_ms = [s.elapsed_time(e) for s, e in events]
-    lk_avg = float(np.mean(lk_ms)) if lk_ms else float("nan")
-    algo_bytes = LOOKUP_ALGO_BYTES_PER_PIXEL * plan.P
-    traffic = None            # HBM bytes per launch from the committed PMC passes (separate rocprofv3 runs)
-    try:
-        pmc = json.loads((ROOT / "profiles" / "r01_lookup_pmc.json").read_text())
-        if pmc["resolution"] == [H, W]:
-            traffic = pmc["traffic_bytes_per_launch"]
-    except Exception:
-        pass
-    achieved = algo_bytes / (lk_avg * 1e-3) / 1e9 if lk_ms else float("nan")
+
+    def lookup_roofline(evs, P):
+        """Correlation lookup in the volume (the named HBM-roofline kernel): algorithmic bytes / live time."""
+        lk_ms = [s.elapsed_time(e) for s, e in evs]
+        lk_avg = float(np.mean(lk_ms)) if lk_ms else float("nan")
+        algo_bytes = LOOKUP_ALGO_BYTES_PER_PIXEL * P
+        traffic = None            # HBM bytes per launch from the committed PMC passes (separate rocprofv3 runs)
+        try:
+            pmc = json.loads((ROOT / "profiles" / "r01_lookup_pmc.json").read_text())
+            if pmc["resolution"] == [H, W]:
+                traffic = pmc["traffic_bytes_per_launch"]
+        except Exception:
+            pass
+        achieved = algo_bytes / (lk_avg * 1e-3) / 1e9 if lk_ms else float("nan")
+        return {"bound": "hbm", "kernel": "corr_lookup_kernel<4>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": lk_avg, "launches_timed": len(lk_ms)}
+
+    def mfma_roofline(evs, layer, P):
+        """The kernel with the largest share of a frame (profiles/): a weight-head 3x3 128->128 layer on the P lookup
+        windows (weighted_raft.py:337-340), matrix-core bound; HIP events around its launches in the timed region."""
+        ms = [s.elapsed_time(e) for s, e in evs]
+        wh_ms = float(np.mean(ms)) if ms else float("nan")
+        n = int(layer.h)
+        flops = 2.0 * P * n * n * 9 * 128 * 128                       # the layer's products (algorithmic)
+        terms = {"fp32": 1, "bf16x3": 3, "bf16": 1}[args.precision]
+        rows = 96 if (n == 9 and args.precision != "fp32") else n * n  # 81 pixels occupy 3 MFMA row tiles
+        peak = 157.3 if args.precision == "fp32" else 2500.0
+        return {"bound": "mfma", "kernel": "weight head conv 3x3 128->128 on P 9x9 windows: "
+                + ("conv_mfma_f32_kernel" if args.precision == "fp32" else "conv_halo_bf16_kernel<9,9,3,3,128>"),
+                "achieved": flops / (wh_ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
+                "frac": flops / (wh_ms * 1e-3) / 1e12 / peak, "traffic": None,
+                "matrix_core_issue_frac": flops * terms * rows / (n * n) / (wh_ms * 1e-3) / 1e12 / peak,
+                "algorithmic_flops_per_launch": flops, "mfma_terms_per_product": terms, "avg_launch_ms": wh_ms,
+                "launches_timed": len(ms),
+                "note": "frac prices the layer's own products against the dense peak of the MFMA type used; the issue "
+                        "fraction also counts the 3 bf16 MFMAs per fp32-emulating product and the 96/81 row padding"}
+
     out = {
         "metric": "tracked frames/sec at 1080p, 12 RAFT iters; flow EPE vs reference",
         "value": world * K / elapsed, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
@@ -162,50 +194,30 @@ def main():
                   "bf16": "bf16 (fp32 accumulate)"}[args.precision], "data": "synthetic",
         "config": {"workload": f"{H}x{W} synthetic sequence per GPU: WeightedRAFT-full {args.iters} iters + "
                                "weighted LSq homography on Sobol-500 correspondences (reference default config WOFT.py)",
-                   "resolution": [H, W], "iters": args.iters, "sequences": world,
+                   "resolution": [H, W], "iters": args.iters, "sequences": world, "correlation": corr_mode,
                    "template_cache": not args.no_template_cache, "weights": "synthetic seed 7 (reference key set)",
                    "frames_resident_in_hbm": True},
         "lost_frames": n_lost,
-        "roofline": {"bound": "hbm", "kernel": "corr_lookup_kernel<4>", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": lk_avg, "launches_timed": len(lk_ms)},
     }
-    if world == 1 and getattr(plan, "prog_wh", None):
-        # the kernel with the largest share of the frame (profiles/): the weight head's 3x3 128->128 layers on the P
-        # 9x9 lookup windows -- matrix-core bound.  Timed on its own here (untimed region), HIP events on the stream.
-        layer = plan.prog_wh[0]
-        evs = []
-        for _ in range(6):
-            s_ev, e_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s_ev.record()
-            ops.run_conv(layer)
-            e_ev.record()
-            evs.append((s_ev, e_ev))
-        torch.cuda.synchronize()
-        wh_ms = float(np.mean([a.elapsed_time(b) for a, b in evs[1:]]))
-        n = int(layer.h)
-        flops = 2.0 * plan.P * n * n * 9 * 128 * 128                  # the layer's products (algorithmic)
-        terms = {"fp32": 1, "bf16x3": 3, "bf16": 1}[args.precision]
-        rows = 96 if (n == 9 and args.precision != "fp32") else n * n  # 81 pixels occupy 3 MFMA row tiles
-        peak = 157.3 if args.precision == "fp32" else 2500.0
-        out["roofline_mfma"] = {
-            "bound": "mfma", "kernel": "weight head conv 3x3 128->128 on P 9x9 windows (weighted_raft.py:337-340): "
-                                       + ("conv_mfma_f32_kernel" if args.precision == "fp32" else "conv_halo_bf16_kernel<9,9,3,3,128>"),
-            "achieved": flops / (wh_ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
-            "frac": flops / (wh_ms * 1e-3) / 1e12 / peak,
-            "matrix_core_issue_frac": flops * terms * rows / (n * n) / (wh_ms * 1e-3) / 1e12 / peak,
-            "algorithmic_flops_per_launch": flops, "mfma_terms_per_product": terms, "avg_launch_ms": wh_ms,
-            "note": "frac prices the layer's own products against the dense peak of the MFMA type used; the issue "
-                    "fraction also counts the 3 bf16 MFMAs per fp32-emulating product and the 96/81 row padding"}
+    have_wh = bool(getattr(plan, "prog_wh", None)) and wh_events
+    if corr_mode == "volume":
+        # the lookup reads the volume: the named HBM-roofline kernel, measured live in the timed region
+        out["roofline"] = lookup_roofline(events, plan.P)
+        if have_wh:
+            out["roofline_mfma"] = mfma_roofline(wh_events, plan.prog_wh[0], plan.P)
+    elif have_wh:
+        # volume-free correlation: no HBM-bound lookup on the path; the dominant kernel is the matrix-core conv
+        # (the volume lookup's HBM roofline is measured in the 'alt_corr' pass below -> 'roofline_lookup')
+        out["roofline"] = mfma_roofline(wh_events, plan.prog_wh[0], plan.P)
     tc_gpu = {}
     if world == 1:
         _, dst, _ = tracker.flower.compute_flow(template, frames[0], mode="TC", do_sigmoid=True)
         tc_gpu[args.precision] = dst.cpu()
+    tracker = plan = None                 # (frees the main engine's buffers before the short extra runs)
+    torch.cuda.empty_cache()
     if world == 1 and not args.no_alt_precisions:
         # the other two arithmetic modes, same sequence, short runs (each its own engine + buffers)
         alt = {}
-        del tracker, plan
-        torch.cuda.empty_cache()
         for prec in ("fp32", "bf16x3", "bf16"):
             if prec == args.precision:
                 continue
@@ -225,6 +237,28 @@ def main():
             del trk
             torch.cuda.empty_cache()
         out["alt_precisions"] = alt
+    if world == 1 and not args.no_alt_corr and args.precision != "fp32":
+        # the other correlation mode, same sequence, short run; in the default (volume-free) mode this is also where
+        # the volume lookup -- the named HBM-roofline kernel -- is measured live
+        other = "volume" if corr_mode == "otf" else "otf"
+        trk = make_tracker(args.precision, corr=other)
+        pl = trk.flower.engine.plan(H, W)
+        for f in frames[:2]:
+            trk.track(f)
+        torch.cuda.synchronize()
+        pl.lookup_events = []
+        t1 = time.perf_counter()
+        n_alt = min(K, 8)
+        for f in frames[Wm:Wm + n_alt]:
+            trk.track(f)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        evs, pl.lookup_events = pl.lookup_events, None
+        out["alt_corr"] = {other: {"frames_per_s": n_alt / dt, "ms_per_step": 1000.0 * dt / n_alt, "steps": n_alt}}
+        if other == "volume":
+            out["roofline_lookup"] = lookup_roofline(evs, pl.P)
+        del trk, pl
+        torch.cuda.empty_cache()
     if world == 1 and not args.no_cpu_baseline:
         torch.set_num_threads(usable_cores())
         f0 = frames[0].cpu().numpy()

@@ -153,7 +153,8 @@ class _Plan:
         self.eng, self.hp, self.wp = eng, hp, wp
         self.prec = eng.precision
         self.source_tag = None
-        self.lookup_events = None      # bench hook: list collecting (start, end) HIP events per lookup launch
+        self.lookup_events = None
+        self.wh_events = None      # bench hook: list collecting (start, end) HIP events per lookup launch
         sp = eng.spec
         hf, wf = hp // 8, wp // 8
         self.hf, self.wf, self.P = hf, wf, hf * wf
@@ -463,8 +464,15 @@ class _Plan:
                 _lib.check(lib.woft_wh_conv0(_lib.ptr(self.corr.t), self.corr.cs, _lib.ptr(self.wmean), self.P, n,
                                              _lib.ptr(self.wh0_t), _lib.ptr(e.wh0.bias), _lib.ptr(self.a1.t),
                                              _lib.stream_ptr()), "woft_wh_conv0")
-            for p in self.prog_wh:
-                ops.run_conv(p)
+            for k, p in enumerate(self.prog_wh):
+                if k == 0 and self.wh_events is not None:            # bench.py: HIP events around the first 128->128 layer
+                    s, t = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    s.record()
+                    ops.run_conv(p)
+                    t.record()
+                    self.wh_events.append((s, t))
+                else:
+                    ops.run_conv(p)
             if not self.wh_fused:
                 _lib.check(lib.woft_wh_reduce(_lib.ptr(self.a1.t), 128, n * n, _lib.ptr(e.wh6_w), e.wh6_b, self.P,
                                               _lib.ptr(self.wlow), _lib.stream_ptr()), "woft_wh_reduce")
