@@ -15,9 +15,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--precision", default="bf16x3")
     ap.add_argument("--hw", default="1080,1920")
+    ap.add_argument("--corr", default=None, help="volume | otf (default: otf in the split-bf16 precisions)")
     a = ap.parse_args()
     h, w = (int(v) for v in a.hw.split(","))
-    eng = RaftEngine(synth.make_state_dict(seed=7), small=False, weighted=True, precision=a.precision)
+    corr = a.corr or ("volume" if a.precision == "fp32" else "otf")
+    eng = RaftEngine(synth.make_state_dict(seed=7), small=False, weighted=True, precision=a.precision, corr=corr)
     plan = eng.plan(h, w) if hasattr(eng, "plan") else None
     if plan is None:
         raise SystemExit("engine has no plan()")
