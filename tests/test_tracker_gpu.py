@@ -21,8 +21,11 @@ def _corners_err(Ha, Hb, H, W):
     return np.abs(pa[:2] / pa[2] - pb[:2] / pb[2]).max()
 
 
-@pytest.mark.parametrize("cfg,estimator", [("WOFT.py", "qr"), ("WOFT_IRLS.py", "irls_huber2")])
-def test_tracker_matches_oracle(cfg, estimator):
+@pytest.mark.parametrize("cfg,estimator,precision", [("WOFT.py", "qr", None), ("WOFT_IRLS.py", "irls_huber2", None),
+                                                     ("WOFT.py", "qr", "bf16x3")])
+def test_tracker_matches_oracle(cfg, estimator, precision):
+    """precision None: the config's default (exact fp32 MFMA, all-pairs volume); "bf16x3": the bench's default path
+    (split-bf16 MFMA emulating fp32, volume-free correlation lookup)."""
     from pytracking.utils.config import load_config
     H, W, iters, nframes = 128, 160, 4, 4
     sd = synth.make_state_dict(seed=7)
@@ -33,7 +36,10 @@ def test_tracker_matches_oracle(cfg, estimator):
     conf = load_config(ROOT / "pytracking" / "configs" / cfg)
     conf.flow_config.model = sd
     conf.flow_config.iters = iters
+    if precision:
+        conf.flow_config.precision = precision
     tracker = conf.tracker_class(conf)
+    assert tracker.flower.engine.corr == ("otf" if precision else "volume")
     tracker.init(template, mask)
     ref = tracker_ref.TrackerRef(sd, iters=iters, estimator=estimator)
     ref.init(template, mask)
