@@ -89,6 +89,10 @@ def main():
                     help="correlation: volume-free on-the-fly lookup (default in the split-bf16 precisions) or the "
                          "all-pairs volume in HBM whose lookup is the HBM-roofline kernel (bit-identical results; "
                          "fp32 precision always uses the volume)")
+    ap.add_argument("--mask-weight-head", action="store_true",
+                    help="evaluate the weight head only on the template pixels whose weights the tracker reads (its "
+                         "template mask) instead of every pixel as the reference's network does; identical tracks "
+                         "(the default run reports this variant under 'alt_weight_head')")
     ap.add_argument("--no-alt-corr", action="store_true",
                     help="skip the short extra run in the other correlation mode (reported under 'alt_corr'; in the "
                          "default mode it also measures the volume lookup for 'roofline_lookup')")
@@ -110,8 +114,9 @@ def main():
     template, frames = make_sequence(H, W, rank, Wm + K)
     mask = synth.make_init_mask(H, W)
 
-    def make_tracker(precision, corr=None):
+    def make_tracker(precision, corr=None, mask_wh=None):
         conf = load_config(ROOT / "pytracking" / "configs" / "WOFT.py")
+        conf.mask_weight_head = args.mask_weight_head if mask_wh is None else mask_wh
         conf.flow_config.model = sd
         conf.flow_config.iters = args.iters
         conf.flow_config.precision = precision
@@ -169,10 +174,11 @@ def main():
     def mfma_roofline(evs, layer, P):
         """The kernel with the largest share of a frame (profiles/): a weight-head 3x3 128->128 layer on the P lookup
         windows (weighted_raft.py:337-340), matrix-core bound; HIP events around its launches in the timed region."""
-        ms = [s.elapsed_time(e) for s, e in evs]
+        ms = [s.elapsed_time(e) for s, e, _ in evs]
         wh_ms = float(np.mean(ms)) if ms else float("nan")
         n = int(layer.h)
-        flops = 2.0 * P * n * n * 9 * 128 * 128                       # the layer's products (algorithmic)
+        n_win = float(np.mean([k for _, _, k in evs])) if evs else float(P)   # windows per launch (P, or the mask region)
+        flops = 2.0 * n_win * n * n * 9 * 128 * 128                   # the layer's products (algorithmic)
         terms = {"fp32": 1, "bf16x3": 3, "bf16": 1}[args.precision]
         rows = 96 if (n == 9 and args.precision != "fp32") else n * n  # 81 pixels occupy 3 MFMA row tiles
         peak = 157.3 if args.precision == "fp32" else 2500.0
@@ -181,8 +187,8 @@ def main():
                 "achieved": flops / (wh_ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
                 "frac": flops / (wh_ms * 1e-3) / 1e12 / peak, "traffic": None,
                 "matrix_core_issue_frac": flops * terms * rows / (n * n) / (wh_ms * 1e-3) / 1e12 / peak,
-                "algorithmic_flops_per_launch": flops, "mfma_terms_per_product": terms, "avg_launch_ms": wh_ms,
-                "launches_timed": len(ms),
+                "algorithmic_flops_per_launch": flops, "windows_per_launch": n_win, "mfma_terms_per_product": terms,
+                "avg_launch_ms": wh_ms, "launches_timed": len(ms),
                 "note": "frac prices the layer's own products against the dense peak of the MFMA type used; the issue "
                         "fraction also counts the 3 bf16 MFMAs per fp32-emulating product and the 96/81 row padding"}
 
@@ -195,6 +201,9 @@ def main():
         "config": {"workload": f"{H}x{W} synthetic sequence per GPU: WeightedRAFT-full {args.iters} iters + "
                                "weighted LSq homography on Sobol-500 correspondences (reference default config WOFT.py)",
                    "resolution": [H, W], "iters": args.iters, "sequences": world, "correlation": corr_mode,
+                   "weight_head": "every template pixel (as the reference's network)" if not args.mask_weight_head else
+                                  "1/8-res pixels of the template mask (N_in = HW/4, SURVEY 8d) + upsampling support: "
+                                  "the weights the tracker reads (TRK:287-312); identical tracks",
                    "template_cache": not args.no_template_cache, "weights": "synthetic seed 7 (reference key set)",
                    "frames_resident_in_hbm": True},
         "lost_frames": n_lost,
@@ -258,6 +267,24 @@ def main():
         if other == "volume":
             out["roofline_lookup"] = lookup_roofline(evs, pl.P)
         del trk, pl
+        torch.cuda.empty_cache()
+    if world == 1 and not args.no_alt_corr:
+        # the weight head restricted to the template-mask region (the weights the tracker reads) -- or, with
+        # --mask-weight-head, on every pixel: same tracks, short run
+        trk = make_tracker(args.precision, mask_wh=not args.mask_weight_head)
+        for f in frames[:Wm]:                        # (same history as the timed run: the tracks must coincide)
+            trk.track(f)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        n_alt = min(K, 8)
+        res_alt = [trk.track(f) for f in frames[Wm:Wm + n_alt]]
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        same = all(np.array_equal(a[0], b_[0]) for a, b_ in zip(res_alt, results[Wm:Wm + n_alt]))
+        out["alt_weight_head"] = {("full" if args.mask_weight_head else "mask_region"): {
+            "frames_per_s": n_alt / dt, "ms_per_step": 1000.0 * dt / n_alt, "steps": n_alt,
+            "tracks_identical_to_timed_run": bool(same)}}
+        del trk
         torch.cuda.empty_cache()
     if world == 1 and not args.no_cpu_baseline:
         torch.set_num_threads(usable_cores())

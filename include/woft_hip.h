@@ -96,6 +96,8 @@ typedef struct woft_conv_params {
                               in_rstd[c], 2: followed by ReLU), zero padding applied after it; in1 must be NULL */
     const float* in_mean;  /* [cin] per-channel statistics of in0 (woft_inorm_finalize)          */
     const float* in_rstd;
+    const int32_t* out_index; /* WOFT_EPI_WH_MEAN only, optional: image i writes out[out_index[i]] (the weight head
+                              evaluated on a subset of the source pixels)                        */
 } woft_conv_params;
 
 int woft_conv2d(const woft_conv_params* p, void* stream);
@@ -195,10 +197,12 @@ int woft_coords_init(float* coords1, int32_t hf, int32_t wf, float* flow4, float
  * woft_wh_pack with x8 == NULL computes mean[] only.
  * woft_wh_conv0: the head's first conv + ReLU (weighted_raft.py:336; 5 -> 128 channels, 3x3, zero padding) straight
  *   from the lookup buffer and mean[] (same input definition as x8), exact fp32:
- *   out[p][hp][wp][0..127]; wt: fp32 [96][128], wt[(ky*32 + kx*8 + ci)*128 + co]; nwin in {7, 9}. */
+ *   out[p][hp][wp][0..127]; wt: fp32 [96][128], wt[(ky*32 + kx*8 + ci)*128 + co]; nwin in {7, 9}.
+ *   index (optional): window p of the output is source pixel index[p] (n_pix = number of windows): the head
+ *   evaluated on a subset of the source pixels, e.g. the tracker's template-mask region. */
 int woft_colsum(const float* f, int64_t n_pix, int32_t c, double* ws, int32_t n_part, double* total, void* stream);
 int woft_wh_conv0(const float* lookup, int32_t ld_lookup, const float* mean, int64_t n_pix, int32_t nwin,
-                  const float* wt, const float* bias, float* out, void* stream);
+                  const float* wt, const float* bias, float* out, const int32_t* index, void* stream);
 int woft_wh_pack(const float* lookup, int32_t ld_lookup, const float* f1, int32_t c, const double* f2_total,
                  float alpha, int64_t n_pix, int32_t nwin, float* mean, float* x8, void* stream);
 int woft_wh_reduce(const float* act, int32_t c, int32_t nwin2, const float* w, float bias,

@@ -133,7 +133,7 @@ def test_wh_conv0(ops, n):
     lib = ops._lib.load()
     lk, mn = lookup.cuda().contiguous(), mean.cuda().contiguous()
     ops.check(lib.woft_wh_conv0(ops.ptr(lk), lk.shape[1], ops.ptr(mn), P, n, ops.ptr(wt), ops.ptr(pc.bias), ops.ptr(out),
-                                ops.stream_ptr()), "woft_wh_conv0")
+                                None, ops.stream_ptr()), "woft_wh_conv0")
     torch.cuda.synchronize()
     _close(out.permute(0, 3, 1, 2), ref, 3e-6, rtol=3e-6, what="wh conv0")
 

@@ -186,3 +186,39 @@ def test_tc_select_kernel_semantics(golden_dir):
         assert np.array_equal(pb[:m].cpu().numpy(), np.stack([chosen % w, chosen // w], 1).astype(np.float32))
         assert np.array_equal(pa[:m].cpu().numpy(), d[:, chosen].T)
         assert np.array_equal(wo[:m].cpu().numpy(), wts.cpu().numpy()[chosen])
+
+
+def test_weight_head_on_mask_region_only():
+    """The tracker reads flow weights only inside its template mask (TRK:287-312): evaluating the weight head on
+    those 1/8-res pixels (+ the upsampling support) instead of everywhere gives the same weights there, bit for bit,
+    and therefore identical homographies -- on both tracker paths and for a mask touching the border."""
+    from pytracking.utils.config import load_config
+    H, W, iters = 136, 200, 3
+    sd = synth.make_state_dict(seed=5)
+    template = synth.make_template(H, W, seq_id=7)
+    frames = [synth.make_frame(template, t) for t in (1, 2, 3)]
+    mask = np.zeros((H, W), np.uint8)
+    mask[0:70, 30:120] = 255
+    outs = {}
+    for full in (True, False):
+        conf = load_config(ROOT / "pytracking" / "configs" / "WOFT.py")
+        conf.flow_config.model = sd
+        conf.flow_config.iters = iters
+        conf.flow_config.precision = "bf16x3"
+        conf.flow_config.padding_mode = "RAFT"
+        conf.mask_weight_head = not full
+        trk = conf.tracker_class(conf)
+        trk.init(template, mask)
+        outs[full] = [trk.track(f)[0] for f in frames]
+        plan = trk.flower.engine.plan(*[(d + 7) // 8 * 8 for d in (H, W)])
+        assert (plan.wh_region is None) == full
+        if not full:
+            n_sel = int(plan.wh_region[0].numel())
+            assert 0 < n_sel < plan.P // 2
+            _, _, w_reg = trk.flower.compute_flow(template, frames[0], mode="TC", do_sigmoid=True, numpy_out=True)
+            trk.flower.pin_weight_region(None)
+            _, _, w_full = trk.flower.compute_flow(template, frames[0], mode="TC", do_sigmoid=True, numpy_out=True)
+            sel = (mask > 0).reshape(-1)
+            assert np.array_equal(w_reg[0, sel], w_full[0, sel])
+    for a, b in zip(outs[True], outs[False]):
+        assert np.array_equal(a, b)

@@ -40,7 +40,7 @@ def main():
         n = eng.spec.nwin
         progs.append(("wh0", [("call", lambda: _lib.check(lib.woft_wh_conv0(
             _lib.ptr(plan.corr.t), plan.corr.cs, _lib.ptr(plan.wmean), plan.P, n, _lib.ptr(plan.wh0_t),
-            _lib.ptr(eng.wh0.bias), _lib.ptr(plan.a1.t), _lib.stream_ptr()), "wh_conv0"))], 1))
+            _lib.ptr(eng.wh0.bias), _lib.ptr(plan.a1.t), None, _lib.stream_ptr()), "wh_conv0"))], 1))
         progs.append(("whred", [("call", lambda: _lib.check(lib.woft_wh_reduce(
             _lib.ptr(plan.a1.t), 128, n * n, _lib.ptr(eng.wh6_w), eng.wh6_b, plan.P, _lib.ptr(plan.wlow),
             _lib.stream_ptr()), "wh_reduce"))], 1))

@@ -28,7 +28,7 @@ class ConvParams(C.Structure):
         ("out_w", i32), ("out_pitch", i32), ("epi", i32), ("split", i32),
         ("e0", vp), ("e1", vp), ("lde0", i32), ("lde1", i32), ("out1", vp), ("ldo1", i32),
         ("stat_sum", vp), ("stat_sq", vp), ("tile_m", i32), ("tile_n", i32), ("halo", i32),
-        ("in_norm", i32), ("in_mean", vp), ("in_rstd", vp),
+        ("in_norm", i32), ("in_mean", vp), ("in_rstd", vp), ("out_index", vp),
     ]
 
 
@@ -68,7 +68,7 @@ _SIGS = {
     "woft_coords_init": (i32, [vp, i32, i32, vp, vp, i32, vp]),
     "woft_colsum": (i32, [vp, i64, i32, vp, i32, vp, vp]),
     "woft_wh_pack": (i32, [vp, i32, vp, i32, vp, f32, i64, i32, vp, vp, vp]),
-    "woft_wh_conv0": (i32, [vp, i32, vp, i64, i32, vp, vp, vp, vp]),
+    "woft_wh_conv0": (i32, [vp, i32, vp, i64, i32, vp, vp, vp, vp, vp]),
     "woft_wh_reduce": (i32, [vp, i32, i32, vp, f32, i64, vp, vp]),
     "woft_convex_upsample": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, i32, vp]),
     "woft_upflow8": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, i32, vp]),

@@ -665,7 +665,8 @@ __global__ __launch_bounds__(256, (STAGES == 1 ? 4 : 1)) void conv_halo_bf16_ker
             float* red = (float*)smem;                   // (operand stages are dead after the loop's last barrier)
             if (lane == 0) red[wave] = part;
             __syncthreads();
-            if (tid == 0) p.out[img0] = p.e1[0] + (red[0] + red[1] + red[2] + red[3]) * (1.f / 81.f);
+            if (tid == 0)
+                p.out[p.out_index ? p.out_index[img0] : img0] = p.e1[0] + (red[0] + red[1] + red[2] + red[3]) * (1.f / 81.f);
             return;
         }
     }

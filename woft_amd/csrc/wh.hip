@@ -85,7 +85,7 @@ template <int NW>
 __global__ __launch_bounds__(256) void wh_conv0_kernel(const float* __restrict__ lookup, int ld,
                                                        const float* __restrict__ mean, int n_pix,
                                                        const float* __restrict__ wt, const float* __restrict__ b0,
-                                                       float* __restrict__ out) {
+                                                       float* __restrict__ out, const int* __restrict__ index) {
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -99,8 +99,9 @@ __global__ __launch_bounds__(256) void wh_conv0_kernel(const float* __restrict__
             for (int ci = 0; ci < 5; ++ci) w[ky][kx][ci] = *(const f32x2*)(wt + (ky * 32 + kx * 8 + ci) * 128 + co);
     const f32x2 bias = *(const f32x2*)(b0 + co);
     for (int p = blockIdx.x * 4 + wave; p < n_pix; p += gridDim.x * 4) {
-        const float* __restrict__ lk = lookup + (int64_t)p * ld;
-        const float mv = mean[p];
+        const int src = index ? index[p] : p;           // window p of the output = source pixel index[p]
+        const float* __restrict__ lk = lookup + (int64_t)src * ld;
+        const float mv = mean[src];
         float* __restrict__ o = out + (int64_t)p * (NW * NW * 128) + co;
 #pragma unroll 1
         for (int y = 0; y < NW; ++y) {
@@ -135,16 +136,16 @@ __global__ __launch_bounds__(256) void wh_conv0_kernel(const float* __restrict__
 }  // namespace
 
 extern "C" int woft_wh_conv0(const float* lookup, int32_t ld_lookup, const float* mean, int64_t n_pix, int32_t nwin,
-                             const float* wt, const float* bias, float* out, void* stream) {
+                             const float* wt, const float* bias, float* out, const int32_t* index, void* stream) {
     if (!lookup || !mean || !wt || !bias || !out || n_pix <= 0 || n_pix >= (1ll << 31)) return WOFT_EINVAL;
     if (ld_lookup < nwin * nwin * 4 || (nwin != 9 && nwin != 7)) return WOFT_EINVAL;
     const int64_t quads = (n_pix + 3) / 4;                // one wave per window, four per workgroup
     dim3 grid((unsigned)(quads < 256 * 8 ? quads : 256 * 8));
     hipStream_t s = (hipStream_t)stream;
     if (nwin == 9)
-        hipLaunchKernelGGL(wh_conv0_kernel<9>, grid, dim3(256), 0, s, lookup, ld_lookup, mean, (int)n_pix, wt, bias, out);
+        hipLaunchKernelGGL(wh_conv0_kernel<9>, grid, dim3(256), 0, s, lookup, ld_lookup, mean, (int)n_pix, wt, bias, out, index);
     else
-        hipLaunchKernelGGL(wh_conv0_kernel<7>, grid, dim3(256), 0, s, lookup, ld_lookup, mean, (int)n_pix, wt, bias, out);
+        hipLaunchKernelGGL(wh_conv0_kernel<7>, grid, dim3(256), 0, s, lookup, ld_lookup, mean, (int)n_pix, wt, bias, out, index);
     return woft_launch_status();
 }
 

@@ -243,18 +243,45 @@ class _Plan:
             # first conv (5 -> 128): scalar-operand VALU kernel straight from the lookup buffer for the 7x7 / 9x9
             # windows (woft_wh_conv0), the generic conv on the packed x8 patches otherwise
             self.wh0_direct = n in (7, 9)
-            self.prog_wh = ([] if self.wh0_direct else [cp(self.x8, eng.wh0, self.a1, epi=EPI.EPI_RELU)]) + [
-                            cp(self.a1, eng.wh2, self.a2, epi=EPI.EPI_RELU),
-                            cp(self.a2, eng.wh4, self.a1, epi=EPI.EPI_RELU)]
             self.wh0_t = eng.wh0.wgt[:128].t().contiguous()          # [ky*32 + kx*8 + ci][co]
-            # last layer on the whole-patch kernel: ReLU + 1x1 conv + patch mean fused into its epilogue
-            last = self.prog_wh[-1]
-            self.wh_fused = last.halo == 2
-            if self.wh_fused:
-                self.wh6_b = torch.tensor([eng.wh6_b], dtype=torch.float32, device=dev)
-                last.epi = EPI.EPI_WH_MEAN
-                last.e0, last.e1 = _lib.ptr(eng.wh6_w), _lib.ptr(self.wh6_b)
-                last.out, last.ldo, last.co_off = _lib.ptr(self.wlow), 1, 0
+            self.wh6_b = torch.tensor([eng.wh6_b], dtype=torch.float32, device=dev)
+            self.prog_wh, self.wh_fused = self._wh_program(P, None)
+            # the head restricted to a subset of the source pixels (set_weight_region): programs per region
+            self.wh_region = None                        # None = every source pixel
+            self._wh_regions = {}
+
+    def _wh_program(self, n_win, index):
+        """Launch list of the head's 128->128 layers on n_win windows (all source pixels, or those listed in the
+        int32 tensor `index`) -> (program, fused): fused = the last layer runs on the whole-window kernel with
+        ReLU + 1x1 conv + window mean in its epilogue."""
+        eng, cp, n = self.eng, self._cp, self.eng.spec.nwin
+        a1 = Act(self.a1.t[:n_win * n * n], n_win, n, n, 128)
+        a2 = Act(self.a2.t[:n_win * n * n], n_win, n, n, 128)
+        prog = ([] if self.wh0_direct else [cp(self.x8, eng.wh0, a1, epi=EPI.EPI_RELU)]) + [
+            cp(a1, eng.wh2, a2, epi=EPI.EPI_RELU), cp(a2, eng.wh4, a1, epi=EPI.EPI_RELU)]
+        last = prog[-1]
+        fused = last.halo == 2
+        if fused:
+            last.epi = EPI.EPI_WH_MEAN
+            last.e0, last.e1 = _lib.ptr(eng.wh6_w), _lib.ptr(self.wh6_b)
+            last.out, last.ldo, last.co_off = _lib.ptr(self.wlow), 1, 0
+            last.out_index = _lib.ptr(index) if index is not None else None
+        return prog, fused
+
+    def set_weight_region(self, index):
+        """Evaluate the weight head only on the source pixels listed in `index` (int32 device tensor of 1/8-res
+        pixel ids, or None for all): the other entries of the low-res weight map are zero.  Per-pixel results
+        are unchanged (the head has no cross-pixel terms, weighted_raft.py:363-383); callers pass the pixels whose
+        weights they consume (the tracker: its template mask, TRK:287-312, dilated by the upsampling support)."""
+        if index is None or not (self.eng.weighted and self.wh0_direct and self.wh_fused):
+            self.wh_region = None
+            return
+        key = index.data_ptr()
+        if key not in self._wh_regions:
+            prog, fused = self._wh_program(int(index.numel()), index)
+            assert fused
+            self._wh_regions[key] = (index, prog)
+        self.wh_region = self._wh_regions[key]
 
     def _cp(self, *a, **kw):
         kw.setdefault("precision", self.prec)
@@ -460,17 +487,23 @@ class _Plan:
                                         _lib.ptr(self.cs_tot), 1.0 / (math.sqrt(float(sp.fdim)) * self.P), self.P, n,
                                         _lib.ptr(self.wmean), None if self.wh0_direct else _lib.ptr(self.x8.t),
                                         _lib.stream_ptr()), "woft_wh_pack")
+            region = self.wh_region
+            prog_wh = region[1] if region is not None else self.prog_wh
+            n_win = int(region[0].numel()) if region is not None else self.P
+            if region is not None:
+                self.wlow.zero_()                                    # pixels outside the region
             if self.wh0_direct:
-                _lib.check(lib.woft_wh_conv0(_lib.ptr(self.corr.t), self.corr.cs, _lib.ptr(self.wmean), self.P, n,
+                _lib.check(lib.woft_wh_conv0(_lib.ptr(self.corr.t), self.corr.cs, _lib.ptr(self.wmean), n_win, n,
                                              _lib.ptr(self.wh0_t), _lib.ptr(e.wh0.bias), _lib.ptr(self.a1.t),
+                                             _lib.ptr(region[0]) if region is not None else None,
                                              _lib.stream_ptr()), "woft_wh_conv0")
-            for k, p in enumerate(self.prog_wh):
+            for k, p in enumerate(prog_wh):
                 if k == 0 and self.wh_events is not None:            # bench.py: HIP events around the first 128->128 layer
                     s, t = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     s.record()
                     ops.run_conv(p)
                     t.record()
-                    self.wh_events.append((s, t))
+                    self.wh_events.append((s, t, n_win))
                 else:
                     ops.run_conv(p)
             if not self.wh_fused:

@@ -67,6 +67,7 @@ class RAFTWrapper:
         self.engine = RaftEngine(state_dict, small=small, weighted=weighted, precision=self.precision, corr=self.corr)
         self._pinned = None
         self._pinned_key = None
+        self._wmask, self._wregion = None, {}
         self._out = {}
         self._cache_errors = set()
 
@@ -76,6 +77,33 @@ class RAFTWrapper:
         its feature/context tensors are computed once and reused by compute_flow(src_img, ...)."""
         self._pinned = src_img
         self._pinned_key = None
+        self._wmask, self._wregion = None, {}
+
+    def pin_weight_region(self, mask):
+        """Declare that, for flows FROM the pinned source image, the caller consumes the flow weights only at the
+        pixels where `mask` (bool ndarray, source-image size; None = everywhere) is set: the weight head is then
+        evaluated on those 1/8-resolution pixels only (+ the 3x3 support of the x8 upsampling), the other weights
+        are unspecified.  The weights at the masked pixels are unchanged (the head is per source pixel,
+        weighted_raft.py:363-383).  Flows from other sources always get the full weight map."""
+        self._wmask = None if mask is None else np.ascontiguousarray(np.asarray(mask) > 0)
+        self._wregion = {}
+
+    def _weight_region(self, key, hp, wp, top, left, oh, ow):
+        if self._wmask is None:
+            return None
+        if key not in self._wregion:
+            m = self._wmask[:oh, :ow]
+            coarse = np.zeros((hp // 8, wp // 8), bool)
+            ys, xs = np.nonzero(m)
+            coarse[(ys + top) >> 3, (xs + left) >> 3] = True
+            pad = np.pad(coarse, 1)
+            dil = np.zeros_like(coarse)
+            for dy in range(3):                            # convex / bilinear x8 upsampling reads the 3x3 neighbours
+                for dx in range(3):
+                    dil |= pad[dy:dy + coarse.shape[0], dx:dx + coarse.shape[1]]
+            idx = np.flatnonzero(dil).astype(np.int32)
+            self._wregion[key] = torch.from_numpy(idx).cuda() if idx.size and idx.size < dil.size else None
+        return self._wregion[key]
 
     def postprocess_weights(self, flat_weights, fn):
         s = self.last_flow_shape
@@ -162,6 +190,7 @@ class RAFTWrapper:
             plan.encode_source()
             plan.source_tag = self if src_img is self._pinned else None
             self._pinned_key = key if src_img is self._pinned else None
+        plan.set_weight_region(self._weight_region(key, hp, wp, top, left, oh, ow) if src_img is self._pinned else None)
         d = up(dst_img)
         plan.load_image(1, d, top, left)
         o = self._outputs(oh, ow)
