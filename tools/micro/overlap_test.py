@@ -1,5 +1,5 @@
 import sys, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, str(__import__("pathlib").Path(__file__).resolve().parents[2]))
 from woft_amd import _lib, ops
 hf, wf = 135, 240
 P = hf * wf
