@@ -28,7 +28,7 @@ extern "C" {
 int woft_abi_version(void);
 /* sizeof(woft_conv_params) (which = 0) / woft_lookup_params (1) / woft_lookup_otf_params (2): layout check for FFI mirrors. */
 int woft_sizeof(int which);
-/* developer tuning knob (A/B experiments; call before any launch): key 0 = conv mainloop variant. */
+/* developer knob for the micro-benchmarks in tools/ (ablation bits of the correlation GEMM, key 2); 0 in production. */
 int woft_set_tuning(int key, int value);
 
 /* ---------------------------------------------------------------------------------------

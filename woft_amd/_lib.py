@@ -103,10 +103,6 @@ def load():
     if lib.woft_sizeof(0) != C.sizeof(ConvParams) or lib.woft_sizeof(1) != C.sizeof(LookupParams) \
             or lib.woft_sizeof(2) != C.sizeof(LookupOtfParams):
         raise WoftHipError("ctypes mirror of woft_conv_params / woft_lookup_params is out of sync with the library")
-    if os.environ.get("WOFT_CONV_DEEP"):
-        lib.woft_set_tuning(0, int(os.environ["WOFT_CONV_DEEP"]))
-    if os.environ.get("WOFT_CONV_DMA"):
-        lib.woft_set_tuning(1, int(os.environ["WOFT_CONV_DMA"]))
     _lib = lib
     return lib
 

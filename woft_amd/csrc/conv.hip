@@ -35,10 +35,9 @@ namespace {
 using woft::ARows;
 using woft::BK;
 
-// developer tuning knobs (A/B experiments only; set once at start-up, never from the hot path):
-//   [0] gather kernel: 0 = register-staged operands, one LDS stage; 1 = B by LDS-DMA, two stages, one barrier per step
-//   [1] unused (was: halo kernel weight path);  [2] corr GEMM ablation bits
-int g_tuning[4] = {0, 1, 0, 0};
+// developer knob (woft_set_tuning; never set on the hot path): [2] = ablation bits of corr_gemm_bf16_kernel for
+// tools/bench_cgemm.py (1 no stores, 2 no epilogue, 4 no operand DMA after the first step, 8 no MFMAs, 16 non-temporal stores)
+int g_tuning[4] = {0, 0, 0, 0};
 
 constexpr int LDS_LD = 36;   // fp32 tiles: floats per row (144 B: 16-B aligned, conflict-free b128 reads)
 
