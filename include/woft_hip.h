@@ -96,6 +96,11 @@ typedef struct woft_conv_params {
                               in_rstd[c], 2: followed by ReLU), zero padding applied after it; in1 must be NULL */
     const float* in_mean;  /* [cin] per-channel statistics of in0 (woft_inorm_finalize)          */
     const float* in_rstd;
+    const float* bias_map; /* optional per-pixel bias [M][ld_bias_map] used instead of bias[] (cout % 4 == 0): the
+                              contribution of input channels that do not change between launches, computed once
+                              (the GRU's context features `inp`, update.py:45-60: conv(W,[h,inp,motion]) =
+                              conv(W_h,m, [h,motion]) + conv(W_inp, inp))                              */
+    int32_t ld_bias_map;
     const int32_t* out_index; /* WOFT_EPI_WH_MEAN only, optional: image i writes out[out_index[i]] (the weight head
                               evaluated on a subset of the source pixels)                        */
 } woft_conv_params;

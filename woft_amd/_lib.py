@@ -28,7 +28,8 @@ class ConvParams(C.Structure):
         ("out_w", i32), ("out_pitch", i32), ("epi", i32), ("split", i32),
         ("e0", vp), ("e1", vp), ("lde0", i32), ("lde1", i32), ("out1", vp), ("ldo1", i32),
         ("stat_sum", vp), ("stat_sq", vp), ("tile_m", i32), ("tile_n", i32), ("halo", i32),
-        ("in_norm", i32), ("in_mean", vp), ("in_rstd", vp), ("out_index", vp),
+        ("in_norm", i32), ("in_mean", vp), ("in_rstd", vp), ("bias_map", vp), ("ld_bias_map", i32),
+        ("out_index", vp),
     ]
 
 

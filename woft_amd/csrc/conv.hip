@@ -927,6 +927,9 @@ extern "C" int woft_conv2d(const woft_conv_params* pp, void* stream) {
     if (p.out1 != nullptr && (p.ldo1 % 4 != 0 || p.split % 4 != 0)) return WOFT_EINVAL;
     if ((p.stat_sum == nullptr) != (p.stat_sq == nullptr)) return WOFT_EINVAL;
     if (p.in_norm < 0 || p.in_norm > 2) return WOFT_EINVAL;
+    if (p.bias_map != nullptr && (p.cout % 4 != 0 || p.ld_bias_map < p.cout || p.ld_bias_map % 4 != 0 ||
+                                  p.epi == WOFT_EPI_CTX || p.epi == WOFT_EPI_WH_MEAN || p.out_pitch != 0))
+        return WOFT_EINVAL;
     if (p.in_norm != 0 && (p.halo == 0 || p.in1 != nullptr || p.in_mean == nullptr || p.in_rstd == nullptr)) return WOFT_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     if (p.halo != 0) {

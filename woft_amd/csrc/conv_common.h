@@ -150,9 +150,11 @@ __device__ __forceinline__ void conv_epilogue_t(const woft_conv_params& p, f32x1
                 const int64_t m = rowmap(wm * WROWS + i * 32 + row);
                 const f32x4 v = *(const f32x4*)(stage + row * STAGE_LD + c4);
                 if (m < 0 || n >= p.cout) continue;
-                f32x4 y;
+                f32x4 y, b4 = bias4;
+                if (p.bias_map != nullptr && n + 3 < p.cout)        // per-pixel bias (a precomputed partial conv)
+                    b4 = *(const f32x4*)(p.bias_map + m * p.ld_bias_map + n);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) y[e] = p.alpha * v[e] + bias4[e];
+                for (int e = 0; e < 4; ++e) y[e] = p.alpha * v[e] + b4[e];
                 if (do_stats) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)

@@ -163,7 +163,7 @@ def pick_tiles(m, cout_pad):
 # ------------------------------------------------------------------------------------------
 def conv_params(x, pc, out, co_off=0, epi=_lib.EPI_LINEAR, x2=None, c_split=0, e0=None, e1=None, out1=None,
                 split=0, alpha=1.0, stats=None, ho=None, wo=None, tiles=None, cout=None, precision=0, halo=None,
-                in_norm=0, in_stats=None):
+                in_norm=0, in_stats=None, bias_map=None, x2_off=0):
     """Build (and keep alive) a woft_conv_params for `out[:, co_off:co_off+cout] = epi(conv(x))`.
     in_norm = 1 / 2 with in_stats = (mean, rstd): x is a RAW conv output, InstanceNorm (2: + ReLU) applied while
     loading -- LDS-halo kernel only (check p.halo on the result; the caller falls back to woft_inorm_apply)."""
@@ -171,8 +171,8 @@ def conv_params(x, pc, out, co_off=0, epi=_lib.EPI_LINEAR, x2=None, c_split=0, e
         ho, wo = pc.out_hw(x.h, x.w)
     p = ConvParams()
     p.in0, p.cs0 = ptr(x.t), x.cs
-    if x2 is not None:
-        p.in1, p.cs1, p.c_split = ptr(x2.t), x2.cs, c_split
+    if x2 is not None:                  # (x2_off: first channel of x2 used as the second source)
+        p.in1, p.cs1, p.c_split = x2.t.data_ptr() + 4 * x2_off, x2.cs, c_split
     else:
         p.in1, p.cs1, p.c_split = None, 0, pc.cin_pad
     p.n_img, p.h, p.w, p.ho, p.wo = x.n, x.h, x.w, ho, wo
@@ -206,6 +206,7 @@ def conv_params(x, pc, out, co_off=0, epi=_lib.EPI_LINEAR, x2=None, c_split=0, e
                 if tn == 128 and x.n * math.ceil(ho / 8) * math.ceil(wo / 16) * nt < HALO_MIN_BLOCKS:
                     halo = 4
     p.halo = halo
+    p.bias_map, p.ld_bias_map = (ptr(bias_map.t), bias_map.cs) if bias_map is not None else (None, 0)
     p.in_norm, p.in_mean, p.in_rstd = 0, None, None
     if in_norm and halo in (1, 4) and (pc.taps_y, pc.taps_x) == (3, 3):      # (instantiated for the 3x3 pixel tiles)
         p.in_norm, p.in_mean, p.in_rstd = int(in_norm), ptr(in_stats[0]), ptr(in_stats[1])
@@ -219,7 +220,7 @@ def conv_params(x, pc, out, co_off=0, epi=_lib.EPI_LINEAR, x2=None, c_split=0, e
         p.stat_sum, p.stat_sq = ptr(stats[0]), ptr(stats[1])
     else:
         p.stat_sum, p.stat_sq = None, None
-    p._keep = (x, x2, pc, out, e0, e1, out1, stats, in_stats)
+    p._keep = (x, x2, pc, out, e0, e1, out1, stats, in_stats, bias_map)
     p._m = m
     return p
 
