@@ -127,23 +127,27 @@ class RaftEngine:
                        ops.pack_conv(cat("gru.convz2", "gru.convr2", ".weight"),
                                      cat("gru.convz2", "gru.convr2", ".bias"), padding=(2, 0))]
             self.q = [g("gru.convq1", padding=(0, 2)), g("gru.convq2", padding=(2, 0))]
-            # The GRU convs see [h | inp | motion] (update.py:45-60, 127-131) and `inp` (the context features) is
-            # the same in every iteration: conv(W, [h, inp, motion]) = conv(W_[h,motion], [h, motion]) + conv(W_inp, inp).
-            # The second term (+ bias) is computed once per source image (gate_inp) and enters the iterations as a
-            # per-pixel bias; the per-iteration convs (gate_dyn) run on 2/3 of the input channels.
-            hd_, cd_ = sp.hdim, sp.cdim
-            dyn = [(0, hd_, 0), (hd_ + cd_, hd_ + cd_ + 128, hd_)]           # h -> 0.., motion(+flow) -> hd..
-            ctx = [(hd_, hd_ + cd_, 0)]
+            self.mk1 = g("mask.0")
+            self.mk2 = g("mask.2", scale=0.25)         # ".25 * self.mask(net)"  update.py:135
+        # The GRU convs see [h | inp | motion] (update.py:22-31, 45-60, 127-131) and `inp` (the context features) is the
+        # same in every iteration: conv(W, [h, inp, motion]) = conv(W_[h,motion], [h, motion]) + conv(W_inp, inp).
+        # The second term (+ bias) is computed once per source image (gate_inp) and enters the iterations as a
+        # per-pixel bias; the per-iteration convs (gate_dyn) run without the context channels.
+        hd_, cd_, mot = sp.hdim, sp.cdim, (82 if small else 128)
+        dyn = [(0, hd_, 0), (hd_ + cd_, hd_ + cd_ + mot, hd_)]              # h -> 0.., motion(+flow) -> hd..
+        ctx = [(hd_, hd_ + cd_, 0)]
+        if small:
+            zr_w = [(cat("gru.convz", "gru.convr", ".weight"), cat("gru.convz", "gru.convr", ".bias"), None)]
+            q_w = [(sd[u + "gru.convq.weight"], sd[u + "gru.convq.bias"], None)]
+        else:
             zr_w = [(cat("gru.convz1", "gru.convr1", ".weight"), cat("gru.convz1", "gru.convr1", ".bias"), (0, 2)),
                     (cat("gru.convz2", "gru.convr2", ".weight"), cat("gru.convz2", "gru.convr2", ".bias"), (2, 0))]
             q_w = [(sd[u + "gru.convq1.weight"], sd[u + "gru.convq1.bias"], (0, 2)),
                    (sd[u + "gru.convq2.weight"], sd[u + "gru.convq2.bias"], (2, 0))]
-            self.zr_dyn = [ops.pack_conv(w_, None, padding=pd, cin_layout=dyn) for w_, _, pd in zr_w]
-            self.zr_inp = [ops.pack_conv(w_, b_, padding=pd, cin_layout=ctx) for w_, b_, pd in zr_w]
-            self.q_dyn = [ops.pack_conv(w_, None, padding=pd, cin_layout=dyn) for w_, _, pd in q_w]
-            self.q_inp = [ops.pack_conv(w_, b_, padding=pd, cin_layout=ctx) for w_, b_, pd in q_w]
-            self.mk1 = g("mask.0")
-            self.mk2 = g("mask.2", scale=0.25)         # ".25 * self.mask(net)"  update.py:135
+        self.zr_dyn = [ops.pack_conv(w_, None, padding=pd, cin_layout=dyn) for w_, _, pd in zr_w]
+        self.zr_inp = [ops.pack_conv(w_, b_, padding=pd, cin_layout=ctx) for w_, b_, pd in zr_w]
+        self.q_dyn = [ops.pack_conv(w_, None, padding=pd, cin_layout=dyn) for w_, _, pd in q_w]
+        self.q_inp = [ops.pack_conv(w_, b_, padding=pd, cin_layout=ctx) for w_, b_, pd in q_w]
         if weighted:
             w = "weight_head.net."
             self.wh0 = ops.pack_conv(sd[w + "0.weight"], sd[w + "0.bias"], flat_cs=8)
@@ -228,15 +232,14 @@ class _Plan:
         self.cf = new_act(1, hf, wf, 128 if sp.small else 256, zero=True)     # [cor | flo]
         self.fl1 = new_act(1, hf, wf, 64 if sp.small else 128, zero=True)
         self.flow4 = new_act(1, hf, wf, 2, cs=4, zero=True)
-        self.gate_bias = None
-        if not sp.small:            # per-pixel gate biases conv(W_inp, inp) + b: z|r and q of the two GRU half steps
-            self.inp_c = new_act(1, hf, wf, sp.cdim, zero=True)
-            self.gate_bias = [(new_act(1, hf, wf, 2 * sp.hdim, zero=True), new_act(1, hf, wf, sp.hdim, zero=True))
-                              for _ in range(2)]
-            self.prog_gate_bias = []
-            for k in range(2):
-                self.prog_gate_bias += [("conv", cp(self.inp_c, eng.zr_inp[k], self.gate_bias[k][0])),
-                                        ("conv", cp(self.inp_c, eng.q_inp[k], self.gate_bias[k][1]))]
+        # per-pixel gate biases conv(W_inp, inp) + b: z|r and q of every GRU (half) step
+        self.inp_c = new_act(1, hf, wf, sp.cdim, zero=True)
+        self.gate_bias = [(new_act(1, hf, wf, 2 * sp.hdim, zero=True), new_act(1, hf, wf, sp.hdim, zero=True))
+                          for _ in eng.zr_inp]
+        self.prog_gate_bias = []
+        for k in range(len(eng.zr_inp)):
+            self.prog_gate_bias += [("conv", cp(self.inp_c, eng.zr_inp[k], self.gate_bias[k][0])),
+                                    ("conv", cp(self.inp_c, eng.q_inp[k], self.gate_bias[k][1]))]
         self.zbuf = new_act(1, hf, wf, sp.hdim, zero=True)
         self.rh = new_act(1, hf, wf, sp.hdim, zero=True)
         self.hA = new_act(1, hf, wf, sp.hdim, zero=True)
