@@ -85,10 +85,16 @@ def main():
     only = os.environ.get("ONLY")
     if only:
         cases = [c for c in cases if only in c[0]]
+    tune = os.environ.get("TUNE1")                       # A/B of a developer knob (woft_set_tuning key 1)
     for name, fn, flops, t in cases:
         ms = bench(fn)
         tot += ms
-        print(f"{name:44s} tiles {t}  {ms*1e3:9.1f} us   {flops/ms/1e9:8.1f} TFLOP/s (useful)")
+        extra = ""
+        if tune:
+            ops._lib.load().woft_set_tuning(1, int(tune))
+            extra = f"   tuned({tune}) {bench(fn)*1e3:9.1f} us"
+            ops._lib.load().woft_set_tuning(1, 0)
+        print(f"{name:44s} tiles {t}  {ms*1e3:9.1f} us   {flops/ms/1e9:8.1f} TFLOP/s (useful){extra}")
     print(f"sum {tot:.3f} ms  [{a.precision}]")
 
 
