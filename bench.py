@@ -13,6 +13,7 @@ Each rank tracks its own sequence; the finished tracks are all-gathered (RCCL) a
 Prints ONE JSON line on rank 0 (see README/DESIGN for the fields).
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -153,6 +154,7 @@ def main():
     if rank != 0:
         return
     n_lost = int(tracks[:, :, 9].sum().item())
+    peak_gb = torch.cuda.max_memory_allocated() / 2 ** 30        # every device buffer of the path is a torch tensor
 
     def lookup_roofline(evs, P):
         """Correlation lookup in the volume (the named HBM-roofline kernel): algorithmic bytes / live time."""
@@ -181,15 +183,22 @@ def main():
         flops = 2.0 * n_win * n * n * 9 * 128 * 128                   # the layer's products (algorithmic)
         terms = {"fp32": 1, "bf16x3": 3, "bf16": 1}[args.precision]
         rows = 96 if (n == 9 and args.precision != "fp32") else n * n  # 81 pixels occupy 3 MFMA row tiles
+        issued = flops * terms * rows / (n * n)
+        fused0 = bool(getattr(plan, "wh0_fused", False))             # the 5->128 first layer runs inside this launch
+        if fused0:
+            flops += 2.0 * n_win * n * n * 45 * 128
+            issued += 2.0 * n_win * 96 * 48 * 128 * terms            # K 45 -> 48
         peak = 157.3 if args.precision == "fp32" else 2500.0
-        return {"bound": "mfma", "kernel": "weight head conv 3x3 128->128 on P 9x9 windows: "
-                + ("conv_mfma_f32_kernel" if args.precision == "fp32" else "conv_halo_bf16_kernel<9,9,3,3,128>"),
+        kname = ("conv_mfma_f32_kernel" if args.precision == "fp32" else
+                 "conv_halo_bf16_kernel<9,9,3,3,128" + (",C0>: the 5->128 first layer is computed in the same launch"
+                                                        if fused0 else ">"))
+        return {"bound": "mfma", "kernel": "weight head conv 3x3 128->128 on P 9x9 windows: " + kname,
                 "achieved": flops / (wh_ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
                 "frac": flops / (wh_ms * 1e-3) / 1e12 / peak, "traffic": None,
-                "matrix_core_issue_frac": flops * terms * rows / (n * n) / (wh_ms * 1e-3) / 1e12 / peak,
+                "matrix_core_issue_frac": issued / (wh_ms * 1e-3) / 1e12 / peak,
                 "algorithmic_flops_per_launch": flops, "windows_per_launch": n_win, "mfma_terms_per_product": terms,
                 "avg_launch_ms": wh_ms, "launches_timed": len(ms),
-                "note": "frac prices the layer's own products against the dense peak of the MFMA type used; the issue "
+                "note": "frac prices the launch's own products against the dense peak of the MFMA type used; the issue "
                         "fraction also counts the 3 bf16 MFMAs per fp32-emulating product and the 96/81 row padding"}
 
     out = {
@@ -206,7 +215,7 @@ def main():
                                   "the weights the tracker reads (TRK:287-312); identical tracks",
                    "template_cache": not args.no_template_cache, "weights": "synthetic seed 7 (reference key set)",
                    "frames_resident_in_hbm": True},
-        "lost_frames": n_lost,
+        "lost_frames": n_lost, "hbm_allocated_peak_gb": peak_gb,
     }
     have_wh = bool(getattr(plan, "prog_wh", None)) and wh_events
     if corr_mode == "volume":
@@ -223,6 +232,7 @@ def main():
         _, dst, _ = tracker.flower.compute_flow(template, frames[0], mode="TC", do_sigmoid=True)
         tc_gpu[args.precision] = dst.cpu()
     tracker = plan = None                 # (frees the main engine's buffers before the short extra runs)
+    gc.collect()
     torch.cuda.empty_cache()
     if world == 1 and not args.no_alt_precisions:
         # the other two arithmetic modes, same sequence, short runs (each its own engine + buffers)
@@ -244,12 +254,14 @@ def main():
             tc_gpu[prec] = dst.cpu()
             alt[prec] = {"frames_per_s": n_alt / dt, "ms_per_step": 1000.0 * dt / n_alt, "steps": n_alt}
             del trk
+            gc.collect()
             torch.cuda.empty_cache()
         out["alt_precisions"] = alt
     if world == 1 and not args.no_alt_corr and args.precision != "fp32":
         # the other correlation mode, same sequence, short run; in the default (volume-free) mode this is also where
         # the volume lookup -- the named HBM-roofline kernel -- is measured live
         other = "volume" if corr_mode == "otf" else "otf"
+        torch.cuda.reset_peak_memory_stats()
         trk = make_tracker(args.precision, corr=other)
         pl = trk.flower.engine.plan(H, W)
         for f in frames[:2]:
@@ -263,10 +275,12 @@ def main():
         torch.cuda.synchronize()
         dt = time.perf_counter() - t1
         evs, pl.lookup_events = pl.lookup_events, None
-        out["alt_corr"] = {other: {"frames_per_s": n_alt / dt, "ms_per_step": 1000.0 * dt / n_alt, "steps": n_alt}}
+        out["alt_corr"] = {other: {"frames_per_s": n_alt / dt, "ms_per_step": 1000.0 * dt / n_alt, "steps": n_alt,
+                                   "hbm_allocated_peak_gb": torch.cuda.max_memory_allocated() / 2 ** 30}}
         if other == "volume":
             out["roofline_lookup"] = lookup_roofline(evs, pl.P)
         del trk, pl
+        gc.collect()
         torch.cuda.empty_cache()
     if world == 1 and not args.no_alt_corr:
         # the weight head restricted to the template-mask region (the weights the tracker reads) -- or, with
@@ -285,6 +299,7 @@ def main():
             "frames_per_s": n_alt / dt, "ms_per_step": 1000.0 * dt / n_alt, "steps": n_alt,
             "tracks_identical_to_timed_run": bool(same)}}
         del trk
+        gc.collect()
         torch.cuda.empty_cache()
     if world == 1 and not args.no_cpu_baseline:
         torch.set_num_threads(usable_cores())

@@ -103,6 +103,19 @@ typedef struct woft_conv_params {
     int32_t ld_bias_map;
     const int32_t* out_index; /* WOFT_EPI_WH_MEAN only, optional: image i writes out[out_index[i]] (the weight head
                               evaluated on a subset of the source pixels)                        */
+    /* Weight head only (halo == 2, 9 x 9 windows, 3 x 3 taps, cin_pad == 128, split-bf16 precisions): when
+       wh0_lookup != NULL the head's FIRST conv (5 -> 128 channels, 3 x 3, zero padding, ReLU;
+       weighted_raft.py:336,363-376) is evaluated inside this launch, 32 channels at a time, from the lookup
+       window of the source pixel -- in0 is ignored, the 1.3 GB activation between the two layers never exists.
+       Input channels of window position t: lookup[s][4 t .. 4 t + 3] and mean[s] (woft_wh_conv0's layout). */
+    const float* wh0_lookup;   /* [P][wh0_ld] fp32, wh0_ld >= 324, % 4 == 0                               */
+    int32_t wh0_ld;
+    const float* wh0_mean;     /* [P]                                                                     */
+    const void* wh0_w;         /* bf16 MFMA fragments [4 chunks][3 K steps][1 or 2 planes hi, lo][64 lanes][8]:
+                                  lane L, element e = W0[32 chunk + L % 32][k = 16 step + 8 (L / 32) + e],
+                                  k = (3 ky + kx) * 5 + ci, zero for k >= 45                                */
+    const float* wh0_bias;     /* [128]                                                                   */
+    const int32_t* wh0_index;  /* optional: window i of this launch is source pixel wh0_index[i]          */
 } woft_conv_params;
 
 int woft_conv2d(const woft_conv_params* p, void* stream);

@@ -138,6 +138,60 @@ def test_wh_conv0(ops, n):
     _close(out.permute(0, 3, 1, 2), ref, 3e-6, rtol=3e-6, what="wh conv0")
 
 
+@pytest.mark.parametrize("precision,tol", [("bf16x3", 3e-5), ("bf16", 3e-2)])
+@pytest.mark.parametrize("subset", [False, True])
+def test_wh_first_two_layers_one_launch(ops, precision, tol, subset):
+    """weighted_raft.py:336-338: conv(5->128)+ReLU evaluated inside the launch of the following 128->128 layer,
+    chunk by chunk on the matrix cores, straight from the lookup windows (woft_conv_params.wh0_*); with an index
+    the launch runs on a subset of the source pixels."""
+    P, n = 41, 9
+    lookup = _rand(P, 4 * n * n + 28, seed=91, scale=3.0)
+    mean = _rand(P, seed=92)
+    w0 = _rand(128, 5, 3, 3, seed=93, scale=1 / math.sqrt(45))
+    b0 = _rand(128, seed=94, scale=0.1)
+    w1 = _rand(128, 128, 3, 3, seed=95, scale=1 / math.sqrt(128 * 9))
+    b1 = _rand(128, seed=96, scale=0.1)
+    x = torch.cat([lookup[:, :4 * n * n].reshape(P, n, n, 4).permute(0, 3, 1, 2), mean.view(P, 1, 1, 1).expand(P, 1, n, n)], 1)
+    a1 = F.relu(F.conv2d(x.double(), w0.double(), b0.double(), padding=1))
+    ref = F.relu(F.conv2d(a1, w1.double(), b1.double(), padding=1)).float()
+    sel = torch.tensor([5, 0, 40, 17, 18, 33, 2], dtype=torch.int32) if subset else None
+    n_win = int(sel.numel()) if subset else P
+    if subset:
+        ref = ref[sel.long()]
+    pc1 = ops.pack_conv(w1, b1)
+    frag = ops.pack_wh0_frags(w0, 2 if precision == "bf16x3" else 1)
+    lk = ops.Act(lookup.cuda().contiguous(), 1, 1, P, 4 * n * n)
+    unused = ops.new_act(n_win, n, n, 128, zero=True)
+    out = ops.new_act(n_win, n, n, 128, zero=True)
+    mn, b0d = mean.cuda().contiguous(), b0.cuda().contiguous()
+    idx = sel.cuda() if subset else None
+    p = ops.conv_params(unused, pc1, out, epi=ops._lib.EPI_RELU, precision=precision, wh0=(lk, mn, frag, b0d, idx))
+    assert p.halo == 2
+    ops.run_conv(p)
+    torch.cuda.synchronize()
+    _close(out.nchw(), ref, tol, rtol=tol, what="fused first layer")
+    # ... and with the head's tail fused as well (one float per window)
+    w6, b6 = _rand(128, seed=97, scale=0.2), -0.21
+    w2 = _rand(128, 128, 3, 3, seed=98, scale=1 / math.sqrt(128 * 9))
+    pc2 = ops.pack_conv(w2, b1)
+    a2 = F.relu(F.conv2d(a1, w2.double(), b1.double(), padding=1))
+    ref6 = ((a2 * w6.double().view(1, 128, 1, 1)).sum(1).mean(dim=(1, 2)) + b6).float()
+    res = torch.full((P,), -7.0, device="cuda")
+    w6d, b6d = w6.cuda(), torch.tensor([b6], device="cuda")
+    q = ops.conv_params(unused, pc2, out, epi=ops._lib.EPI_RELU, precision=precision, wh0=(lk, mn, frag, b0d, idx))
+    q.epi, q.e0, q.e1 = ops._lib.EPI_WH_MEAN, ops.ptr(w6d), ops.ptr(b6d)
+    q.out, q.ldo, q.co_off = ops.ptr(res), 1, 0
+    q.out_index = ops.ptr(idx) if subset else None
+    ops.run_conv(q)
+    torch.cuda.synchronize()
+    if subset:
+        _close(res[sel.long().cuda()], ref6[sel.long()], tol, rtol=tol, what="fused first layer + tail (subset)")
+        rest = torch.ones(P, dtype=torch.bool); rest[sel.long()] = False
+        assert bool((res.cpu()[rest] == -7.0).all())
+    else:
+        _close(res, ref6, tol, rtol=tol, what="fused first layer + tail")
+
+
 @pytest.mark.parametrize("cin,cout,h,w", [(256, 2, 19, 37), (256, 1, 5, 16), (128, 2, 17, 33), (256, 2, 3, 3)])
 def test_conv3x3_narrow(ops, cin, cout, h, w):
     """Flow head conv2 (update.py:10-17) on the vector ALUs: exact fp32 products, written at a channel offset."""

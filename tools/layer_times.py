@@ -34,13 +34,17 @@ def main():
              ("iter", plan.prog_iter, 12), ("mask", [("conv", p) for p in plan.prog_mask], 1),
              ("wh", [("conv", p) for p in plan.prog_wh], 1)]
     total = 0.0
-    if getattr(plan, "wh0_direct", False):
+    if getattr(plan, "wh0_direct", False) and not getattr(plan, "wh0_fused", False):
         from woft_amd import _lib
         lib = _lib.load()
         n = eng.spec.nwin
         progs.append(("wh0", [("call", lambda: _lib.check(lib.woft_wh_conv0(
             _lib.ptr(plan.corr.t), plan.corr.cs, _lib.ptr(plan.wmean), plan.P, n, _lib.ptr(plan.wh0_t),
             _lib.ptr(eng.wh0.bias), _lib.ptr(plan.a1.t), None, _lib.stream_ptr()), "wh_conv0"))], 1))
+    if getattr(plan, "wh0_direct", False) and not getattr(plan, "wh_fused", False):
+        from woft_amd import _lib
+        lib = _lib.load()
+        n = eng.spec.nwin
         progs.append(("whred", [("call", lambda: _lib.check(lib.woft_wh_reduce(
             _lib.ptr(plan.a1.t), 128, n * n, _lib.ptr(eng.wh6_w), eng.wh6_b, plan.P, _lib.ptr(plan.wlow),
             _lib.stream_ptr()), "wh_reduce"))], 1))

@@ -423,8 +423,12 @@ struct HaloRowMap {
 //             two stages at three workgroups per CU (GRU q conv 72 vs 64 us) and not instantiated.
 // NORM (compile time, so that the other layers do not pay for it): p.in_norm != 0, the producer's InstanceNorm (+ ReLU)
 // is applied while the halo is staged.
-template <int TY, int TX, int KY, int KX, int BN, int TERMS, int WM, int STAGES, bool NORM>
+// C0 (9 x 9 windows, 3 x 3 taps, 128 input channels): the INPUT of this layer is not read from memory but computed
+// here, 32 channels at a time, as relu(conv 3x3 (5 -> 128) + bias) of the lookup window of one source pixel (the
+// weight head's first layer, weighted_raft.py:336,363-376) -- see conv0_* below.
+template <int TY, int TX, int KY, int KX, int BN, int TERMS, int WM, int STAGES, bool NORM, bool C0 = false>
 __global__ __launch_bounds__(256, (STAGES == 1 ? 4 : 1)) void conv_halo_bf16_kernel(const woft_conv_params p) {
+    static_assert(!C0 || (TY == 9 && TX == 9 && KY == 3 && KX == 3 && !NORM && STAGES == 2), "C0: weight-head windows");
     constexpr int NWAVES = 4;
     constexpr int NPIX = TY * TX;
     constexpr int BM = (NPIX + 31) / 32 * 32;           // rows (padded to MFMA tiles)
@@ -474,8 +478,26 @@ __global__ __launch_bounds__(256, (STAGES == 1 ? 4 : 1)) void conv_halo_bf16_ker
         hpix[j] = hok[j] ? (img0 * p.h + iy) * p.w + ix : 0;
     }
     f32x4 rh[RH], nmu, nrs;
-    constexpr int NLOAD = RH + (NORM ? 2 : 0);           // vector loads per load_halo (counted by vmcnt below)
+    constexpr int NLOAD = C0 ? 3 * NP : RH + (NORM ? 2 : 0);   // vector loads per load_halo (counted by vmcnt below)
+    // ---- C0: first layer of the weight head, fused ------------------------------------------------------------
+    // a1^T[ch][pix] = sum_k W0[ch][k] x[k][pix], k = tap * 5 + ci (45 -> 48 = 3 MFMA K steps), as a TRANSPOSED
+    // product (A = weights, B = im2col of the window), so that an accumulator lane holds 4 x 4 consecutive channels
+    // of ONE pixel = 8-byte stores into the halo rows.  Wave i < 3 owns pixels 32 i .. 32 i + 31 (natural order);
+    // its im2col fragments are built once from the window (LDS), the 32 x 48 weight slice of the next chunk is
+    // prefetched during the first tap of a chunk (NLOAD loads by EVERY wave: the counted vmcnt waits are per wave).
+    bf16x8 c0x[3][NP], c0w[3][NP];
+    f32x16 c0acc;
+    const int c0pix = wave * 32 + r32;                   // (wave 3: no pixel)
+    const bool c0ok = C0 && wave < 3 && c0pix < 81;
     auto load_halo = [&](int chunk) {                    // NLOAD unconditional 16-byte loads
+        if constexpr (C0) {
+#pragma unroll
+            for (int s3 = 0; s3 < 3; ++s3)
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl)
+                    c0w[s3][pl] = *(const bf16x8*)((const __bf16*)p.wh0_w + (((chunk * 3 + s3) * NP + pl) * 64 + lane) * 8);
+            return;
+        }
         const int c0 = chunk * BK;
         const bool second = (p.in1 != nullptr) && (c0 >= p.c_split);
         const float* src = (second ? p.in1 + (c0 - p.c_split) : p.in0 + c0) + 4 * v;
@@ -485,6 +507,43 @@ __global__ __launch_bounds__(256, (STAGES == 1 ? 4 : 1)) void conv_halo_bf16_ker
         if (NORM) {
             nmu = *(const f32x4*)(p.in_mean + c0 + 4 * v);
             nrs = *(const f32x4*)(p.in_rstd + c0 + 4 * v);
+        }
+    };
+    auto conv0_compute = [&]() {                         // c0acc = W0[chunk] x im2col  (waves 0-2)
+#pragma unroll
+        for (int s3 = 0; s3 < 3; ++s3)
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) asm volatile("" : "+v"(c0w[s3][pl]));
+        if (wave < 3) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) c0acc[r] = 0.f;
+#pragma unroll
+            for (int s3 = 0; s3 < 3; ++s3) {
+                if (NP == 2) {
+                    c0acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c0w[s3][NP - 1], c0x[s3][0], c0acc, 0, 0, 0);
+                    c0acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c0w[s3][0], c0x[s3][NP - 1], c0acc, 0, 0, 0);
+                }
+                c0acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c0w[s3][0], c0x[s3][0], c0acc, 0, 0, 0);
+            }
+        }
+    };
+    auto conv0_store = [&](int chunk) {                  // relu(c0acc + bias) -> bf16 hi / lo rows of the halo
+        if (c0ok) {
+            const int hrow = (c0pix / 9 + 1) * HX + c0pix % 9 + 1;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int ch = 8 * g + 4 * hh;           // accumulator rows (r & 3) + 8 (r >> 2) + 4 hh = channels
+                const f32x4 b4 = *(const f32x4*)(p.wh0_bias + chunk * BK + ch);
+                f32x4 val;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) val[e] = fmaxf(c0acc[4 * g + e] + b4[e], 0.f);
+                const bf16x4 hi = __builtin_convertvector(val, bf16x4);
+                *(bf16x4*)(As + hrow * LDB + ch) = hi;
+                if (NP == 2) {
+                    const f32x4 rem = val - __builtin_convertvector(hi, f32x4);
+                    *(bf16x4*)(As + A_PLANE + hrow * LDB + ch) = __builtin_convertvector(rem, bf16x4);
+                }
+            }
         }
     };
     auto store_halo = [&]() {
@@ -559,9 +618,48 @@ __global__ __launch_bounds__(256, (STAGES == 1 ? 4 : 1)) void conv_halo_bf16_ker
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) b_frag[s2] = (wn * WCOLS + r32) * 32 + (((s2 * 2 + hh) ^ sw) * 8);
 
-    load_halo(0);
-    if (STAGES == 2) dma_b(0, 0);
-    store_halo();
+    if constexpr (C0) {
+        // window of this workgroup's source pixel -> LDS (inside weight stage 1, which the first DMA of the loop
+        // fills only after the barrier below); halo buffer zeroed once: its border rows are the conv's zero padding
+        float* win = (float*)(Bs + B_STAGE);
+        const int src = p.wh0_index ? p.wh0_index[img0] : img0;
+        const float* lk = p.wh0_lookup + (int64_t)src * p.wh0_ld;
+        const float mv = p.wh0_mean[src];
+        if (tid < 81) *(f32x4*)(win + 4 * tid) = *(const f32x4*)(lk + 4 * tid);
+        for (int i = tid; i < A_ELEMS / 8; i += 256) *(f32x4*)(As + 8 * i) = f32x4{0.f, 0.f, 0.f, 0.f};
+        load_halo(0);
+        dma_b(0, 0);
+        __syncthreads();
+        const int py = c0pix / 9, px = c0pix - py * 9;
+#pragma unroll
+        for (int s3 = 0; s3 < 3; ++s3) {
+            float xv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {                // k = 16 s3 + 8 hh + e: both candidates are constants
+                const int k0 = 16 * s3 + e, k1 = k0 + 8;
+                const int t0 = k0 / 5, t1 = k1 / 5;
+                const int dy = hh ? t1 / 3 - 1 : t0 / 3 - 1, dx = hh ? t1 % 3 - 1 : t0 % 3 - 1;
+                const int ci = hh ? k1 % 5 : k0 % 5;
+                const bool kok = hh ? (k1 < 45) : (k0 < 45);
+                const int yy = py + dy, xx = px + dx;
+                const bool ok = c0ok && kok && yy >= 0 && yy < 9 && xx >= 0 && xx < 9;
+                const float wv = win[ok ? (yy * 9 + xx) * 4 + (ci & 3) : 0];
+                xv[e] = ok ? (ci == 4 ? mv : wv) : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const __bf16 hi = (__bf16)xv[e];
+                c0x[s3][0][e] = hi;
+                if (NP == 2) c0x[s3][NP - 1][e] = (__bf16)(xv[e] - (float)hi);
+            }
+        }
+        conv0_compute();
+        conv0_store(0);
+    } else {
+        load_halo(0);
+        if (STAGES == 2) dma_b(0, 0);
+        store_halo();
+    }
     dma_wait<0>();                                       // this wave's DMA has landed before the others read it
     __syncthreads();
     int stage = 0;
@@ -573,6 +671,7 @@ __global__ __launch_bounds__(256, (STAGES == 1 ? 4 : 1)) void conv_halo_bf16_ker
         for (int tap = 0; tap < TAPS; ++tap) {
             // next step's weights (and, during the first tap, the next chunk's halo: RH loads issued AFTER the DMA,
             // so that "at most RH loads in flight" = DMA complete while the halo loads cross the barrier)
+            if (C0 && more && tap == TAPS - 1) conv0_compute();   // (its weights were requested eight taps ago)
             if (STAGES == 2) {
                 if (tap + 1 < TAPS) dma_b((tap + 1) * p.cin_pad + chunk * BK, stage ^ 1);
                 else if (more) dma_b((chunk + 1) * BK, stage ^ 1);
@@ -630,7 +729,8 @@ __global__ __launch_bounds__(256, (STAGES == 1 ? 4 : 1)) void conv_halo_bf16_ker
             if (STAGES == 2) stage ^= 1;
         }
         if (more) {
-            store_halo();
+            if constexpr (C0) conv0_store(chunk + 1);
+            else store_halo();
             __syncthreads();
         }
     };
@@ -682,7 +782,11 @@ int launch_halo(const woft_conv_params& p, hipStream_t s) {
 #define HALO_LAUNCH(KY, KX, T, N) \
     hipLaunchKernelGGL((conv_halo_bf16_kernel<TY, TX, KY, KX, BN, T, WM, STAGES, N>), grid, dim3(256), 0, s, p)
 #define HALO_TAPS(T)                                                                            \
-    if (p.in_norm != 0) {                 /* encoder residual blocks: 3x3 only */                \
+    if (p.wh0_lookup != nullptr) {        /* weight head, first two layers in one launch */      \
+        if constexpr (TY == 9 && STAGES == 2)                                                    \
+            hipLaunchKernelGGL((conv_halo_bf16_kernel<TY, TX, 3, 3, BN, T, WM, STAGES, false, true>), grid, dim3(256), 0, s, p); \
+        else return WOFT_EINVAL;                                                                \
+    } else if (p.in_norm != 0) {          /* encoder residual blocks: 3x3 only */                \
         if (p.taps_y == 3 && p.taps_x == 3 && TY != 9) HALO_LAUNCH(3, 3, T, (TY != 9));         \
         else return WOFT_EINVAL;                                                                \
     } else if (p.taps_y == 3 && p.taps_x == 3) HALO_LAUNCH(3, 3, T, false);                     \
@@ -931,6 +1035,11 @@ extern "C" int woft_conv2d(const woft_conv_params* pp, void* stream) {
                                   p.epi == WOFT_EPI_CTX || p.epi == WOFT_EPI_WH_MEAN || p.out_pitch != 0))
         return WOFT_EINVAL;
     if (p.in_norm != 0 && (p.halo == 0 || p.in1 != nullptr || p.in_mean == nullptr || p.in_rstd == nullptr)) return WOFT_EINVAL;
+    if (p.wh0_lookup != nullptr &&
+        (p.halo != 2 || p.precision == 0 || p.taps_y != 3 || p.taps_x != 3 || p.cin_pad != 128 || p.in1 != nullptr ||
+         p.in_norm != 0 || p.ho != 9 || p.wo != 9 || p.wh0_ld < 324 || p.wh0_ld % 4 != 0 || p.wh0_mean == nullptr ||
+         p.wh0_w == nullptr || p.wh0_bias == nullptr))
+        return WOFT_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     if (p.halo != 0) {
         // LDS-halo kernels: split-bf16 precisions, stride 1, 3x3 / 1x5 / 5x1 taps, non-flat, same-size output

@@ -17,6 +17,7 @@ head's mean-response channel in algebraic form; template-side tensors (fmap1, ne
 when the caller pins the source image.
 """
 import math
+import os
 
 import torch
 
@@ -153,6 +154,9 @@ class RaftEngine:
             self.wh0 = ops.pack_conv(sd[w + "0.weight"], sd[w + "0.bias"], flat_cs=8)
             self.wh2 = ops.pack_conv(sd[w + "2.weight"], sd[w + "2.bias"])
             self.wh4 = ops.pack_conv(sd[w + "4.weight"], sd[w + "4.bias"])
+            # first conv as MFMA fragments for the fused two-layer launch (split-bf16 precisions, 9x9 windows)
+            self.wh0_frag = (ops.pack_wh0_frags(sd[w + "0.weight"], 2 if precision == "bf16x3" else 1)
+                             if precision != "fp32" and self.spec.nwin == 9 else None)
             self.wh6_w = sd[w + "6.weight"].reshape(-1).contiguous().cuda()
             self.wh6_b = float(sd[w + "6.bias"].item())
         self._plans = {}
@@ -261,7 +265,6 @@ class _Plan:
         if eng.weighted:
             n = sp.nwin
             self.x8 = new_act(P, n, n, 5, cs=8, zero=True)
-            self.a1 = new_act(P, n, n, 128)
             self.a2 = new_act(P, n, n, 128)
             self.wmean = z(P)
             self.wlow = z(P)
@@ -270,6 +273,10 @@ class _Plan:
             # first conv (5 -> 128): scalar-operand VALU kernel straight from the lookup buffer for the 7x7 / 9x9
             # windows (woft_wh_conv0), the generic conv on the packed x8 patches otherwise
             self.wh0_direct = n in (7, 9)
+            self.wh0_fused = (eng.wh0_frag is not None and os.environ.get("WOFT_WH0_FUSED", "1") != "0"
+                              and cp(self.a2, eng.wh2, self.a2, epi=EPI.EPI_RELU).halo == 2)
+            # (with the first layer AND the tail fused into the two 128->128 launches only ONE activation exists)
+            self.a1 = self.a2 if self.wh0_fused else new_act(P, n, n, 128)
             self.wh0_t = eng.wh0.wgt[:128].t().contiguous()          # [ky*32 + kx*8 + ci][co]
             self.wh6_b = torch.tensor([eng.wh6_b], dtype=torch.float32, device=dev)
             self.prog_wh, self.wh_fused = self._wh_program(P, None)
@@ -286,6 +293,10 @@ class _Plan:
         a2 = Act(self.a2.t[:n_win * n * n], n_win, n, n, 128)
         prog = ([] if self.wh0_direct else [cp(self.x8, eng.wh0, a1, epi=EPI.EPI_RELU)]) + [
             cp(a1, eng.wh2, a2, epi=EPI.EPI_RELU), cp(a2, eng.wh4, a1, epi=EPI.EPI_RELU)]
+        if self.wh0_fused:          # layers 1 + 2 in one launch: the first activation (1.3 GB at 1080p) never exists
+            assert prog[0].halo == 2
+            prog[0] = cp(a1, eng.wh2, a2, epi=EPI.EPI_RELU,
+                         wh0=(self.corr, self.wmean, eng.wh0_frag, eng.wh0.bias, index))
         last = prog[-1]
         fused = last.halo == 2
         if fused:
@@ -529,7 +540,7 @@ class _Plan:
             n_win = int(region[0].numel()) if region is not None else self.P
             if region is not None:
                 self.wlow.zero_()                                    # pixels outside the region
-            if self.wh0_direct:
+            if self.wh0_direct and not self.wh0_fused:
                 _lib.check(lib.woft_wh_conv0(_lib.ptr(self.corr.t), self.corr.cs, _lib.ptr(self.wmean), n_win, n,
                                              _lib.ptr(self.wh0_t), _lib.ptr(e.wh0.bias), _lib.ptr(self.a1.t),
                                              _lib.ptr(region[0]) if region is not None else None,

@@ -163,10 +163,12 @@ def pick_tiles(m, cout_pad):
 # ------------------------------------------------------------------------------------------
 def conv_params(x, pc, out, co_off=0, epi=_lib.EPI_LINEAR, x2=None, c_split=0, e0=None, e1=None, out1=None,
                 split=0, alpha=1.0, stats=None, ho=None, wo=None, tiles=None, cout=None, precision=0, halo=None,
-                in_norm=0, in_stats=None, bias_map=None, x2_off=0):
+                in_norm=0, in_stats=None, bias_map=None, x2_off=0, wh0=None):
     """Build (and keep alive) a woft_conv_params for `out[:, co_off:co_off+cout] = epi(conv(x))`.
     in_norm = 1 / 2 with in_stats = (mean, rstd): x is a RAW conv output, InstanceNorm (2: + ReLU) applied while
-    loading -- LDS-halo kernel only (check p.halo on the result; the caller falls back to woft_inorm_apply)."""
+    loading -- LDS-halo kernel only (check p.halo on the result; the caller falls back to woft_inorm_apply).
+    wh0 = (lookup Act, mean, fragments (pack_wh0_frags), bias, index | None): the weight head's first conv is
+    evaluated inside this launch from the lookup windows and x is not read (whole-window kernel only: p.halo == 2)."""
     if ho is None or wo is None:
         ho, wo = pc.out_hw(x.h, x.w)
     p = ConvParams()
@@ -220,9 +222,25 @@ def conv_params(x, pc, out, co_off=0, epi=_lib.EPI_LINEAR, x2=None, c_split=0, e
         p.stat_sum, p.stat_sq = ptr(stats[0]), ptr(stats[1])
     else:
         p.stat_sum, p.stat_sq = None, None
-    p._keep = (x, x2, pc, out, e0, e1, out1, stats, in_stats, bias_map)
+    if wh0 is not None:
+        lk, mean, frag, b0, index = wh0
+        assert halo == 2 and p.precision != 0 and pc.cin_pad == 128, "fused first layer: 9x9 whole-window kernel only"
+        p.wh0_lookup, p.wh0_ld, p.wh0_mean = ptr(lk.t), lk.cs, ptr(mean)
+        p.wh0_w, p.wh0_bias, p.wh0_index = ptr(frag), ptr(b0), (ptr(index) if index is not None else None)
+    p._keep = (x, x2, pc, out, e0, e1, out1, stats, in_stats, bias_map, wh0)
     p._m = m
     return p
+
+
+def pack_wh0_frags(w0, planes):
+    """First conv of the weight head (128, 5, 3, 3) (weighted_raft.py:336) -> bf16 MFMA A fragments
+    [4 chunks][3 K steps][planes][64 lanes][8] (woft_conv_params.wh0_w): k = (3 ky + kx) * 5 + ci, 45 -> 48."""
+    k = torch.zeros(128, 48)
+    k[:, :45] = w0.detach().float().cpu().permute(0, 2, 3, 1).reshape(128, 45)
+    k = k.reshape(4, 32, 3, 2, 8).permute(0, 2, 3, 1, 4).reshape(4, 3, 64, 8)      # lane = 32 * (k half) + row
+    hi = k.to(torch.bfloat16)
+    pl = [hi] + ([(k - hi.float()).to(torch.bfloat16)] if planes == 2 else [])
+    return torch.stack(pl, dim=2).contiguous().to(DEV)
 
 
 def run_conv(p):
