@@ -129,6 +129,13 @@ int woft_split_bf16(const float* x, int64_t n, void* hi, void* lo, void* stream)
 int woft_conv3x3_narrow(const float* in, int32_t cs, int32_t n_img, int32_t h, int32_t w, int32_t cin_pad,
                         const float* wgt, const float* bias, int32_t cout, float* out, int64_t ldo, int32_t co_off,
                         void* stream);
+/* The flow head's second conv and the coordinate update in one launch (update.py:10-17, weighted_raft.py:236-237:
+ * delta = conv3x3(in) (2 channels, as woft_conv3x3_narrow, also stored to delta[pixel * ld_delta + 0..1]);
+ * coords1 += delta; flow = coords1 - grid written as woft_coords_update writes it (flow4, flow_cat optional).
+ * One image of h x w pixels; the same fp32 operations as the two separate calls. */
+int woft_flow_head_update(const float* in, int32_t cs, int32_t h, int32_t w, int32_t cin_pad, const float* wgt,
+                          const float* bias, float* delta, int64_t ld_delta, float* coords1, float* flow4,
+                          float* flow_cat, int32_t ld_cat, void* stream);
 /* x (n floats, n % 32 == 0) -> n/32 lines of 128 bytes, line = [bf16 hi of 32 values | bf16 lo of the same 32],
  * hi = bf16(x), lo = bf16(x - hi): the operand format of woft_corr_gemm_bf16 with terms = 3. */
 int woft_split_bf16_lines(const float* x, int64_t n, void* out, void* stream);

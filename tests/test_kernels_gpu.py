@@ -209,6 +209,36 @@ def test_conv3x3_narrow(ops, cin, cout, h, w):
     assert float(out.t[:, 0].abs().max()) == 0.0 and float(out.t[:, 1 + cout:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("cin,h,w", [(256, 19, 37), (128, 5, 16)])
+def test_flow_head_update_one_launch(ops, cin, h, w):
+    """update.py:10-17 + weighted_raft.py:236-237 in one launch: bit-identical to the narrow conv followed by
+    woft_coords_update (same fp32 operations)."""
+    x = F.relu(_rand(1, cin, h, w, seed=64))
+    wt = _rand(2, cin, 3, 3, seed=65, scale=1 / math.sqrt(cin * 9))
+    b = _rand(2, seed=66, scale=0.1)
+    pc = ops.pack_conv(wt, b)
+    xa = ops.act_from_nchw(x)
+    start = (_rand(h * w, 2, seed=67, scale=30.0) + 15.0).cuda()
+    res = []
+    for fused in (False, True):
+        coords = start.clone()
+        delta = ops.new_act(1, h, w, 2, cs=4, zero=True)
+        flow4 = torch.full((h * w, 4), -3.0, device="cuda")
+        cat = torch.full((h * w, 12), -5.0, device="cuda")
+        if fused:
+            ops.flow_head_update(xa, pc, delta, coords, flow4, cat[:, 6:], 12)
+        else:
+            ops.conv3x3_narrow(xa, pc, delta)
+            ops.coords_update(coords, delta.t, delta.cs, w, flow4, cat[:, 6:], 12)
+        torch.cuda.synchronize()
+        res.append((coords, delta.t.clone(), flow4, cat))
+    for a, b_ in zip(res[0], res[1]):
+        assert torch.equal(a, b_)
+    ref = F.conv2d(x.double(), wt.double(), b.double(), padding=1).float()
+    _close(res[1][1][:, :2].reshape(h, w, 2).permute(2, 0, 1)[None], ref, 2e-6, rtol=2e-6, what="flow head delta")
+    assert bool((res[1][3][:, :6] == -5.0).all()) and bool((res[1][3][:, 8:] == -5.0).all())
+
+
 @pytest.mark.parametrize("kh,kw", [(1, 5), (5, 1), (3, 3)])
 @pytest.mark.parametrize("precision,tol", [("fp32", 1.0), ("bf16x3", 4.0)])
 def test_conv_gru_epilogues(ops, kh, kw, precision, tol):

@@ -24,7 +24,9 @@ template <int COUT, int CPL>
 __global__ __launch_bounds__(256) void conv3x3_narrow_kernel(const float* __restrict__ in, int cs, int n_img, int h, int w,
                                                              const float* __restrict__ wgt, int ktot, int cin_pad,
                                                              const float* __restrict__ bias, float* __restrict__ out,
-                                                             int64_t ldo, int co_off) {
+                                                             int64_t ldo, int co_off, float* __restrict__ coords1,
+                                                             float* __restrict__ flow4, float* __restrict__ flow_cat,
+                                                             int ld_cat) {
     typedef typename Vec<CPL>::T vec;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -93,6 +95,18 @@ __global__ __launch_bounds__(256) void conv3x3_narrow_kernel(const float* __rest
             if (lane == 0 && x < w) {
                 orow[(int64_t)x * ldo] = s[0] + b0;
                 if (COUT > 1) orow[(int64_t)x * ldo + COUT - 1] = s[COUT - 1] + b1;
+                if (COUT == 2 && coords1 != nullptr) {   // coords1 += delta (weighted_raft.py:237), same fp32 adds as
+                    const int64_t i = (int64_t)y * w + x; // woft_coords_update on the stored delta (n_img == 1)
+                    const float cx = coords1[i * 2] + (s[0] + b0), cy = coords1[i * 2 + 1] + (s[COUT - 1] + b1);
+                    coords1[i * 2] = cx;
+                    coords1[i * 2 + 1] = cy;
+                    const float fx = cx - (float)x, fy = cy - (float)y;
+                    if (flow4 != nullptr) *(f32x4*)(flow4 + i * 4) = f32x4{fx, fy, 0.f, 0.f};
+                    if (flow_cat != nullptr) {
+                        flow_cat[i * ld_cat] = fx;
+                        flow_cat[i * ld_cat + 1] = fy;
+                    }
+                }
             }
         }
     }
@@ -100,9 +114,9 @@ __global__ __launch_bounds__(256) void conv3x3_narrow_kernel(const float* __rest
 
 }  // namespace
 
-extern "C" int woft_conv3x3_narrow(const float* in, int32_t cs, int32_t n_img, int32_t h, int32_t w, int32_t cin_pad,
-                                   const float* wgt, const float* bias, int32_t cout, float* out, int64_t ldo,
-                                   int32_t co_off, void* stream) {
+static int narrow_launch(const float* in, int32_t cs, int32_t n_img, int32_t h, int32_t w, int32_t cin_pad,
+                         const float* wgt, const float* bias, int32_t cout, float* out, int64_t ldo, int32_t co_off,
+                         float* coords1, float* flow4, float* flow_cat, int32_t ld_cat, void* stream) {
     if (!in || !wgt || !out || n_img <= 0 || h <= 0 || w <= 0) return WOFT_EINVAL;
     if ((cin_pad != 256 && cin_pad != 128) || cs < cin_pad || cs % 4 != 0) return WOFT_EINVAL;
     if (cout < 1 || cout > 2 || co_off < 0 || ldo < co_off + cout) return WOFT_EINVAL;
@@ -112,9 +126,24 @@ extern "C" int woft_conv3x3_narrow(const float* in, int32_t cs, int32_t n_img, i
     hipStream_t s = (hipStream_t)stream;
 #define NARROW(CO, CPL) \
     hipLaunchKernelGGL((conv3x3_narrow_kernel<CO, CPL>), grid, dim3(256), 0, s, in, cs, n_img, h, w, wgt, ktot, cin_pad, \
-                       bias, out, ldo, co_off)
+                       bias, out, ldo, co_off, coords1, flow4, flow_cat, ld_cat)
     if (cin_pad == 256) { if (cout == 2) NARROW(2, 4); else NARROW(1, 4); }
     else { if (cout == 2) NARROW(2, 2); else NARROW(1, 2); }
 #undef NARROW
     return woft_launch_status();
+}
+
+extern "C" int woft_conv3x3_narrow(const float* in, int32_t cs, int32_t n_img, int32_t h, int32_t w, int32_t cin_pad,
+                                   const float* wgt, const float* bias, int32_t cout, float* out, int64_t ldo,
+                                   int32_t co_off, void* stream) {
+    return narrow_launch(in, cs, n_img, h, w, cin_pad, wgt, bias, cout, out, ldo, co_off, nullptr, nullptr, nullptr, 0,
+                         stream);
+}
+
+extern "C" int woft_flow_head_update(const float* in, int32_t cs, int32_t h, int32_t w, int32_t cin_pad,
+                                     const float* wgt, const float* bias, float* delta, int64_t ld_delta,
+                                     float* coords1, float* flow4, float* flow_cat, int32_t ld_cat, void* stream) {
+    if (!coords1 || (flow_cat != nullptr && ld_cat < 2)) return WOFT_EINVAL;
+    return narrow_launch(in, cs, 1, h, w, cin_pad, wgt, bias, 2, delta, ld_delta, 0, coords1, flow4, flow_cat, ld_cat,
+                         stream);
 }

@@ -440,10 +440,11 @@ class _Plan:
                      ("conv", cp(self.rh, q, ho, x2=self.xbuf, c_split=hd, epi=EPI.EPI_GRU_Q, e0=hi, e1=self.zbuf))]
         if len(e.zr) == 1 and not first:
             prog.append(("copy", (self.hA.t, self.hB.t)))
-        prog += [("conv", cp(self.hB, e.fh1, self.fh, epi=EPI.EPI_RELU)),
-                 (("narrow", (self.fh, e.fh2, self.delta)) if ops.narrow_ok(self.fh, e.fh2)
-                  else ("conv", cp(self.fh, e.fh2, self.delta))),
-                 ("coords", None)]
+        prog.append(("conv", cp(self.hB, e.fh1, self.fh, epi=EPI.EPI_RELU)))
+        if ops.narrow_ok(self.fh, e.fh2):                # second conv + coords1 += delta in one launch
+            prog.append(("fh_update", (self.fh, e.fh2, self.delta)))
+        else:
+            prog += [("conv", cp(self.fh, e.fh2, self.delta)), ("coords", None)]
         return prog
 
     # ---- execution ------------------------------------------------------------------------
@@ -471,6 +472,9 @@ class _Plan:
                 self._lookup(a)
             elif kind == "copy":
                 a[1].copy_(a[0])
+            elif kind == "fh_update":
+                off = self.eng.spec.flow_off
+                ops.flow_head_update(a[0], a[1], a[2], self.coords, self.flow4.t, self.xbuf.t[:, off:], self.xbuf.cs)
             elif kind == "coords":
                 off = self.eng.spec.flow_off
                 ops.coords_update(self.coords, self.delta.t, self.delta.cs, self.wf, self.flow4.t,

@@ -289,6 +289,14 @@ def conv3x3_narrow(x, pc, out, co_off=0):
                                           ptr(out.t), out.cs, co_off, stream_ptr()), "woft_conv3x3_narrow")
 
 
+def flow_head_update(x, pc, delta, coords, flow4=None, flow_cat=None, ld_cat=0):
+    """conv3x3_narrow (2 channels -> delta) + coords_update in one launch (woft_flow_head_update)."""
+    assert narrow_ok(x, pc) and pc.cout == 2 and x.n == 1 and coords.shape[0] == x.h * x.w
+    check(_lib.load().woft_flow_head_update(ptr(x.t), x.cs, x.h, x.w, pc.cin_pad, ptr(pc.wgt), ptr(pc.bias), ptr(delta.t),
+                                            delta.cs, ptr(coords), ptr(flow4), ptr(flow_cat), ld_cat, stream_ptr()),
+          "woft_flow_head_update")
+
+
 def narrow_ok(x, pc):
     """True when woft_conv3x3_narrow applies to this layer."""
     return ((pc.taps_y, pc.taps_x, pc.stride, pc.pad_y, pc.pad_x, pc.flat) == (3, 3, 1, 1, 1, 0) and pc.cout <= 2
