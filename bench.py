@@ -8,6 +8,9 @@ iterations) template -> frame, masking + Sobol-500 subsampling, weighted least-s
 re-detection test -- the reference's default configuration (configs/WOFT.py).  Frames are
 synthetic, already resident in HBM when the timed region starts; weights are a seeded
 synthetic checkpoint with the reference's key set (the trained checkpoints are not in the snapshot).
+The sequence is a series of 48-frame clips of SURVEY 8d's motion (with random weights the estimated pose is
+meaningless and eventually leaves the image, where the reference's estimator raises on < 4 points; every clip
+therefore starts from the template's pose -- the per-frame work is the same for every frame of every clip).
 Each rank tracks its own sequence; the finished tracks are all-gathered (RCCL) at the end.
 
 Prints ONE JSON line on rank 0 (see README/DESIGN for the fields).
@@ -30,14 +33,26 @@ LOOKUP_ALGO_BYTES_PER_PIXEL = 4 * (10 * 10 * 4 + 9 * 9 * 4)        # 2896 B (SUR
 HBM_PEAK_GBS = 8000.0                                             # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
+CLIP = 48      # frames per clip of the synthetic sequence
+
+
+def restart_clip(tracker):
+    """Pose state of a freshly initialised tracker (TRK:43-47); template-side tensors stay as they are."""
+    tracker.prev_H2init = np.eye(3)
+    tracker.last_good_H2init = np.eye(3)
+    tracker.lost, tracker.N_lost = False, 0
+
+
 def make_sequence(H, W, seq_id, n_frames):
     """Template (numpy, host) + frames (CUDA uint8 tensors) warped on the device."""
     from woft_amd import ops, synth
     template = synth.make_template(H, W, seq_id=seq_id)
     tg = torch.from_numpy(template).cuda()
     frames = []
-    for t in range(1, n_frames + 1):
+    for t in range(1, min(n_frames, CLIP) + 1):          # (frame i of a longer run is frames[i % CLIP])
         out = torch.empty_like(tg)
+        # SURVEY 8d's motion H_t, t = 1 .. CLIP; longer runs are further clips of the same motion (the tracker's pose
+        # is put back to the template's at each clip start, restart_clip) so that any --steps keeps the object in view
         ops.warp_perspective_u8(tg, synth.seq_homography(t, H, W), out, None)
         frames.append(out)
     torch.cuda.synchronize()
@@ -132,17 +147,23 @@ def main():
     plan = tracker.flower.engine.plan(H, W)
     corr_mode = tracker.flower.engine.corr
 
-    results = []
-    for f in frames[:Wm]:
-        results.append(tracker.track(f))
+    def track_all(trk, first, n):
+        """Track frames[first : first + n] (0-based index i = frame t - 1; a new clip starts where i % CLIP == 0)."""
+        res = []
+        for i in range(first, first + n):
+            if i > 0 and i % CLIP == 0:
+                restart_clip(trk)
+            res.append(trk.track(frames[i % CLIP]))
+        return res
+
+    results = track_all(tracker, 0, Wm)
     wdist.gather_tracks(results[:1])        # untimed: creates the RCCL communicator / warms the collective
     torch.cuda.synchronize()
     plan.lookup_events, plan.wh_events = [], []
     wdist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for f in frames[Wm:]:
-        results.append(tracker.track(f))
+    results += track_all(tracker, Wm, K)
     tracks = wdist.gather_tracks(results[Wm:])
     torch.cuda.synchronize()
     wdist.barrier()
@@ -207,7 +228,7 @@ def main():
         "ms_per_step": 1000.0 * elapsed / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": {"fp32": "f32", "bf16x3": "bf16x3 (split-bf16 MFMA operands emulating fp32, fp32 accumulate)",
                   "bf16": "bf16 (fp32 accumulate)"}[args.precision], "data": "synthetic",
-        "config": {"workload": f"{H}x{W} synthetic sequence per GPU: WeightedRAFT-full {args.iters} iters + "
+        "config": {"workload": f"{H}x{W} synthetic sequence per GPU ({CLIP}-frame clips): WeightedRAFT-full {args.iters} iters + "
                                "weighted LSq homography on Sobol-500 correspondences (reference default config WOFT.py)",
                    "resolution": [H, W], "iters": args.iters, "sequences": world, "correlation": corr_mode,
                    "weight_head": "every template pixel (as the reference's network)" if not args.mask_weight_head else
@@ -241,13 +262,11 @@ def main():
             if prec == args.precision:
                 continue
             trk = make_tracker(prec)
-            for f in frames[:2]:
-                trk.track(f)
+            track_all(trk, 0, min(2, Wm))
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             n_alt = min(K, 8)
-            for f in frames[Wm:Wm + n_alt]:
-                trk.track(f)
+            track_all(trk, Wm, n_alt)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t1
             _, dst, _ = trk.flower.compute_flow(template, frames[0], mode="TC", do_sigmoid=True)
@@ -264,14 +283,12 @@ def main():
         torch.cuda.reset_peak_memory_stats()
         trk = make_tracker(args.precision, corr=other)
         pl = trk.flower.engine.plan(H, W)
-        for f in frames[:2]:
-            trk.track(f)
+        track_all(trk, 0, min(2, Wm))
         torch.cuda.synchronize()
         pl.lookup_events = []
         t1 = time.perf_counter()
         n_alt = min(K, 8)
-        for f in frames[Wm:Wm + n_alt]:
-            trk.track(f)
+        track_all(trk, Wm, n_alt)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t1
         evs, pl.lookup_events = pl.lookup_events, None
@@ -286,12 +303,11 @@ def main():
         # the weight head restricted to the template-mask region (the weights the tracker reads) -- or, with
         # --mask-weight-head, on every pixel: same tracks, short run
         trk = make_tracker(args.precision, mask_wh=not args.mask_weight_head)
-        for f in frames[:Wm]:                        # (same history as the timed run: the tracks must coincide)
-            trk.track(f)
+        track_all(trk, 0, Wm)                        # (same history as the timed run: the tracks must coincide)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         n_alt = min(K, 8)
-        res_alt = [trk.track(f) for f in frames[Wm:Wm + n_alt]]
+        res_alt = track_all(trk, Wm, n_alt)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t1
         same = all(np.array_equal(a[0], b_[0]) for a, b_ in zip(res_alt, results[Wm:Wm + n_alt]))
