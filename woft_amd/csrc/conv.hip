@@ -1052,6 +1052,8 @@ extern "C" int woft_conv2d(const woft_conv_params* pp, void* stream) {
         if (p.halo == 1 && p.tile_n == 64) return launch_halo<8, 16, 64, 2, 2>(p, s);
         if (p.halo == 2 && p.tile_n == 128 && p.ho == 9 && p.wo == 9) return launch_halo<9, 9, 128, 1, 2>(p, s);
         if (p.halo == 4 && p.tile_n == 128) return launch_halo<4, 16, 128, 2, 2>(p, s);
+        if (p.halo == 6 && p.tile_n == 128 && p.in_norm == 0 && p.stat_sum == nullptr)
+            return launch_halo<6, 16, 128, 1, 2>(p, s);
         if (p.halo == 4 && p.tile_n == 64) return launch_halo<4, 16, 64, 2, 2>(p, s);
         return WOFT_EINVAL;
     }

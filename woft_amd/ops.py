@@ -141,7 +141,7 @@ def fold_bn(weight, bias, bn_w, bn_b, mean, var, eps=1e-5):
 
 PRECISION = {"fp32": 0, "bf16x3": 1, "bf16": 2}
 USE_HALO = os.environ.get("WOFT_HALO", "1") != "0"
-HALO_TILES = {1: (8, 16, 1), 2: (9, 9, 1), 4: (4, 16, 1)}     # (TY, TX, images per workgroup)
+HALO_TILES = {1: (8, 16, 1), 2: (9, 9, 1), 4: (4, 16, 1), 6: (6, 16, 1)}     # (TY, TX, images per workgroup)
 HALO_MIN_BLOCKS = int(os.environ.get("WOFT_HALO_MIN_BLOCKS", "400"))
 WH_HALO = int(os.environ.get("WOFT_WH_HALO", "2"))
 
@@ -207,6 +207,8 @@ def conv_params(x, pc, out, co_off=0, epi=_lib.EPI_LINEAR, x2=None, c_split=0, e
                 # only while it still yields ~2 workgroups per CU, else 4x16
                 if tn == 128 and x.n * math.ceil(ho / 8) * math.ceil(wo / 16) * nt < HALO_MIN_BLOCKS:
                     halo = 4
+                elif tn == 128 and p.precision == PRECISION["bf16"] and stats is None and not in_norm:
+                    halo = 6        # plain bf16: one LDS plane -> three 6x16 workgroups per CU (measured faster)
     p.halo = halo
     p.bias_map, p.ld_bias_map = (ptr(bias_map.t), bias_map.cs) if bias_map is not None else (None, 0)
     p.in_norm, p.in_mean, p.in_rstd = 0, None, None
