@@ -206,9 +206,12 @@ __global__ __launch_bounds__(256) void conv_mfma_bf16_kernel(const woft_conv_par
             poff[j] = pok[j] ? (uint32_t)(ibase[j] + iy * p.w + ix) : 0u;
         }
     };
-    f32x4 ra[RA];
-    bool rok[RA];
-    auto load_a = [&]() {                               // the step at the prefetch position
+    // TWO register sets: the rows of step k+2 are requested while step k computes and step k+1's set is converted
+    // into the idle LDS stage -- a short-K layer (1x1 convs: a dozen steps of 24 MFMAs) otherwise waits for the full
+    // HBM latency of its activation rows in every step
+    f32x4 ra0[RA], ra1[RA];
+    bool rok0[RA], rok1[RA];
+    auto load_a = [&](f32x4 (&ra)[RA], bool (&rok)[RA]) {   // the step at the prefetch position
         const int c0 = pf_chunk * BK;
         const bool second = (p.in1 != nullptr) && (c0 >= p.c_split);
         const float* src = (second ? p.in1 + (c0 - p.c_split) : p.in0 + (p.flat ? 0 : c0)) + 4 * v;
@@ -227,7 +230,7 @@ __global__ __launch_bounds__(256) void conv_mfma_bf16_kernel(const woft_conv_par
             tap_rows();
         }
     };
-    auto store_a = [&](int stage) {
+    auto store_a = [&](int stage, f32x4 (&ra)[RA], bool (&rok)[RA]) {
         __bf16* As = Asm + stage * A_STAGE;
 #pragma unroll
         for (int j = 0; j < RA; ++j) {
@@ -305,20 +308,35 @@ __global__ __launch_bounds__(256) void conv_mfma_bf16_kernel(const woft_conv_par
 
     tap_rows();
     dma_b(0, 0);
-    load_a();
-    store_a(0);
-    dma_wait<0>();
+    load_a(ra0, rok0);
+    store_a(0, ra0, rok0);
+    if (nk > 1) {                                        // step 1 -> set 0 (stays in flight across the barrier)
+        advance();
+        load_a(ra0, rok0);
+        dma_wait<RA>();
+    } else {
+        dma_wait<0>();
+    }
     __syncthreads();
     int stage = 0;
-    for (int ks = 0; ks + 1 < nk; ++ks) {
+    // one K step: `cur` holds the rows of step ks + 1 (requested a step ago), `nxt` receives those of step ks + 2
+    auto step = [&](int ks, f32x4 (&cur)[RA], bool (&cok)[RA], f32x4 (&nxt)[RA], bool (&nok)[RA]) {
         dma_b(ks + 1, stage ^ 1);                       // lands in the idle stage while this step computes
-        advance();
-        load_a();
+        const bool ahead = ks + 2 < nk;
+        if (ahead) {
+            advance();
+            load_a(nxt, nok);
+        }
         compute(stage);
-        store_a(stage ^ 1);                             // idle A stage: last read in step ks-1, a barrier ago
-        dma_wait<0>();
+        store_a(stage ^ 1, cur, cok);                   // idle A stage: last read in step ks-1, a barrier ago
+        if (ahead) dma_wait<RA>();                      // (the RA loads of `nxt` were issued after the DMA)
+        else dma_wait<0>();
         __syncthreads();
         stage ^= 1;
+    };
+    for (int ks = 0; ks + 1 < nk; ks += 2) {
+        step(ks, ra0, rok0, ra1, rok1);
+        if (ks + 2 < nk) step(ks + 1, ra1, rok1, ra0, rok0);
     }
     compute(stage);
     __syncthreads();
