@@ -130,12 +130,13 @@ def main():
     template, frames = make_sequence(H, W, rank, Wm + K)
     mask = synth.make_init_mask(H, W)
 
-    def make_tracker(precision, corr=None, mask_wh=None):
+    def make_tracker(precision, corr=None, mask_wh=None, graph=False):
         conf = load_config(ROOT / "pytracking" / "configs" / "WOFT.py")
         conf.mask_weight_head = args.mask_weight_head if mask_wh is None else mask_wh
         conf.flow_config.model = sd
         conf.flow_config.iters = args.iters
         conf.flow_config.precision = precision
+        conf.flow_config.graph = graph
         conf.flow_config.corr = (corr or args.corr) if precision != "fp32" else "volume"
         trk = conf.tracker_class(conf)
         trk.init(template, mask)
@@ -315,6 +316,25 @@ def main():
             "frames_per_s": n_alt / dt, "ms_per_step": 1000.0 * dt / n_alt, "steps": n_alt,
             "tracks_identical_to_timed_run": bool(same)}}
         del trk
+        gc.collect()
+        torch.cuda.empty_cache()
+    if world == 1 and not args.no_alt_corr:
+        # the same path with each flow's launch list replayed as ONE hipGraph (flow config key `graph`; the timed run
+        # launches eagerly because its per-launch HIP events cannot live inside a graph): same tracks, short run
+        trk = make_tracker(args.precision, graph=True)
+        track_all(trk, 0, Wm)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        n_alt = min(K, 8)
+        res_alt = track_all(trk, Wm, n_alt)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        same = all(np.array_equal(a[0], b_[0]) for a, b_ in zip(res_alt, results[Wm:Wm + n_alt]))
+        pl = trk.flower.engine.plan(H, W)
+        out["alt_graph"] = {"frames_per_s": n_alt / dt, "ms_per_step": 1000.0 * dt / n_alt, "steps": n_alt,
+                            "graphs_replayed": bool(any(g is not None for g in getattr(pl, "_graphs", {}).values())),
+                            "tracks_identical_to_timed_run": bool(same)}
+        del trk, pl
         gc.collect()
         torch.cuda.empty_cache()
     if world == 1 and not args.no_cpu_baseline:

@@ -65,11 +65,37 @@ class RAFTWrapper:
             raise ValueError("alternate_corr / corr='otf' runs on the split-bf16 matrix-core path: set precision "
                              "'bf16x3' (fp32-emulating) or 'bf16'")
         self.engine = RaftEngine(state_dict, small=small, weighted=weighted, precision=self.precision, corr=self.corr)
+        # opt-in (flow config key `graph`, env WOFT_GRAPH=1): the ~330 launches of a flow -- a static list per
+        # resolution, fixed buffers, no allocation -- are captured once into a hipGraph and replayed per frame
+        self.use_graph = (os.environ.get("WOFT_GRAPH") or str(int(bool(getattr(self.C, "graph", False))))) == "1"
         self._pinned = None
         self._pinned_key = None
         self._wmask, self._wregion = None, {}
         self._out = {}
         self._cache_errors = set()
+
+    def _run_flow(self, plan, iters, crop, oh, ow, o, weighted, do_sigmoid):
+        """plan.flow() eagerly, or -- use_graph -- as ONE hipGraph launch (captured at the second call with the same
+        arguments; the per-launch event hooks of bench.py force the eager path)."""
+        def eager():
+            plan.flow(iters, crop, oh, ow, flow_up=o["flow"], dst=o["dst"], wout=o["w"] if weighted else None,
+                      do_sigmoid=do_sigmoid)
+        if not self.use_graph or plan.lookup_events is not None or plan.wh_events is not None:
+            return eager()
+        graphs = plan.__dict__.setdefault("_graphs", {})
+        region = plan.wh_region
+        key = (iters, crop, oh, ow, weighted, do_sigmoid, o["flow"].data_ptr(),
+               region[0].data_ptr() if region is not None else 0)
+        g = graphs.get(key)
+        if g is None:
+            eager()                                        # this call's results; also the warm-up the capture needs
+            if key in graphs:                              # (second sighting: capture for the calls to come)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    eager()
+            graphs[key] = g
+        else:
+            g.replay()
 
     # ---- template caching (results-identical: InstanceNorm is per sample, extractor.py:171-190) ----
     def pin_source(self, src_img):
@@ -195,8 +221,7 @@ class RAFTWrapper:
         plan.load_image(1, d, top, left)
         o = self._outputs(oh, ow)
         weighted = self.C.raft_type == "weighted"
-        plan.flow(int(self.C.iters), (top, left), oh, ow, flow_up=o["flow"], dst=o["dst"],
-                  wout=o["w"] if weighted else None, do_sigmoid=bool(do_sigmoid))
+        self._run_flow(plan, int(self.C.iters), (top, left), oh, ow, o, weighted, bool(do_sigmoid))
         logger.debug(f"flow enqueue time [s]: {float(timer() - start_time)}")
         weights = o["w"] if weighted else None
         if self.C.weights_postprocessing_fn and weights is not None:
