@@ -205,8 +205,14 @@ def conv_params(x, pc, out, co_off=0, epi=_lib.EPI_LINEAR, x2=None, c_split=0, e
                 # measured on MI355X: many independent workgroups beat larger tiles (16x16 / multi-patch
                 # workgroups run at 1 block per CU and lose to 8x16 by 1.5-3x), so take the 8x16 tile
                 # only while it still yields ~2 workgroups per CU, else 4x16
-                if tn == 128 and x.n * math.ceil(ho / 8) * math.ceil(wo / 16) * nt < HALO_MIN_BLOCKS:
+                b816 = x.n * math.ceil(ho / 8) * math.ceil(wo / 16)
+                if tn == 128 and b816 * nt < HALO_MIN_BLOCKS:
                     halo = 4
+                    if pc.cout_pad == 128 and 2 * b816 >= HALO_MIN_BLOCKS:
+                        # a 128-wide layer at 1/8 of 1080p: 8x16 pixels x 64 channels (two column tiles, ~510
+                        # workgroups, three per CU) measured 2 % of a frame faster than 4x16 x 128 (~510, two per CU)
+                        halo, tn = 1, 64
+                        p.tile_n = 64
                 elif tn == 128 and p.precision == PRECISION["bf16"] and stats is None and not in_norm:
                     halo = 6        # plain bf16: one LDS plane -> three 6x16 workgroups per CU (measured faster)
     p.halo = halo
