@@ -191,6 +191,10 @@ def conv_params(x, pc, out, co_off=0, epi=_lib.EPI_LINEAR, x2=None, c_split=0, e
     p.out1, p.ldo1 = (ptr(out1.t), out1.cs) if out1 is not None else (None, 0)
     m = x.n * ho * wo
     tm, tn = tiles or pick_tiles(m, pc.cout_pad)
+    if tiles is None and tn == 128 and stats is None and _round_up(p.cout, 64) < pc.cout_pad:
+        tn = 64                         # the last 64 columns of the 128-padded weight matrix are padding (cout 192, 576)
+    if tn == 64 and stats is None:
+        p.cout_pad = _round_up(p.cout, 64)              # column tiles actually launched (convc2: 3 instead of 4 x 64)
     p.tile_m, p.tile_n = tm, tn
     # LDS-halo kernel for the split-bf16 precisions on stride-1 multi-tap convs (see conv.hip)
     if halo is None:
