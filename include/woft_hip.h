@@ -89,8 +89,8 @@ typedef struct woft_conv_params {
     int32_t halo;          /* 0: gather A per tap.  Split-bf16 precisions, stride 1, 3x3/1x5/5x1 only:
                               input halo of the output tile resident in LDS for all taps; tile_m ignored:
                               1 = 8x16 px, 4 = 4x16 px, 6 = 6x16 px with one wave per 32-column band (tile_n 128, no
-                              statistics / in_norm; three workgroups per CU in plain-bf16 mode, where it measured
-                              10-17 % faster than 8x16), 2 = one 9x9 image per workgroup (weight-head patches;
+                              statistics / in_norm; in plain-bf16 mode 10-17 % faster than 8x16 x 128, but 8x16 x 64
+                              is faster still: not chosen by the Python host), 2 = one 9x9 image per workgroup (weight-head patches;
                               ho = wo = 9).  (Larger tiles / several patches per workgroup were measured
                               1.5-3x slower: one workgroup per CU cannot hide its own latencies.) */
     int32_t in_norm;       /* halo != 0 only: 0 = use in0 as is; 1 / 2 = in0 holds a RAW conv output whose

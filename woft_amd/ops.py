@@ -205,20 +205,27 @@ def conv_params(x, pc, out, co_off=0, epi=_lib.EPI_LINEAR, x2=None, c_split=0, e
             if (x.h, x.w) == (9, 9) and tn == 128:
                 halo = WH_HALO if x.n >= 4 * 256 else 2
             elif x.h >= 8 and x.w >= 16:
-                halo = 1
-                # measured on MI355X: many independent workgroups beat larger tiles (16x16 / multi-patch
-                # workgroups run at 1 block per CU and lose to 8x16 by 1.5-3x), so take the 8x16 tile
-                # only while it still yields ~2 workgroups per CU, else 4x16
+                # Tile choice, measured on MI355X with tools/tile_sweep.py (1080p layer shapes).  Many independent
+                # workgroups beat larger tiles (16x16 / multi-patch workgroups run at 1 block per CU and lose to
+                # 8x16 by 1.5-3x): take the 8x16 pixel tile only while it still yields ~2 workgroups per CU, else 4x16.
                 b816 = x.n * math.ceil(ho / 8) * math.ceil(wo / 16)
-                if tn == 128 and b816 * nt < HALO_MIN_BLOCKS:
-                    halo = 4
-                    if pc.cout_pad == 128 and 2 * b816 >= HALO_MIN_BLOCKS:
-                        # a 128-wide layer at 1/8 of 1080p: 8x16 pixels x 64 channels (two column tiles, ~510
-                        # workgroups, three per CU) measured 2 % of a frame faster than 4x16 x 128 (~510, two per CU)
-                        halo, tn = 1, 64
-                        p.tile_n = 64
-                elif tn == 128 and p.precision == PRECISION["bf16"] and stats is None and not in_norm:
-                    halo = 6        # plain bf16: one LDS plane -> three 6x16 workgroups per CU (measured faster)
+                auto = tiles is None
+                if auto and p.precision == PRECISION["bf16"]:
+                    # plain bf16 (one LDS plane, fewer registers): 64-channel column tiles win throughout --
+                    # 8x16 x 64 for the 256-wide layers (~1000 workgroups), 4x16 x 64 for the narrower ones
+                    tn = 64
+                    if stats is None:
+                        p.cout_pad = _round_up(p.cout, 64)
+                    halo = 1 if 4 * b816 * (p.cout_pad // 64) >= 7 * HALO_MIN_BLOCKS else 4   # (>= 700 workgroups)
+                else:
+                    halo = 1
+                    if b816 * nt < HALO_MIN_BLOCKS:
+                        halo = 4
+                        if auto and tn == 128 and pc.cout_pad == 128 and 2 * b816 >= HALO_MIN_BLOCKS:
+                            # a 128-wide layer at 1/8 of 1080p: 8x16 pixels x 64 channels (two column tiles, ~510
+                            # workgroups, three per CU): 2 % of a frame faster than 4x16 x 128 (~510, two per CU)
+                            halo, tn = 1, 64
+                p.tile_n = tn
     p.halo = halo
     p.bias_map, p.ld_bias_map = (ptr(bias_map.t), bias_map.cs) if bias_map is not None else (None, 0)
     p.in_norm, p.in_mean, p.in_rstd = 0, None, None
