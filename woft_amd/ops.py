@@ -219,12 +219,13 @@ def conv_params(x, pc, out, co_off=0, epi=_lib.EPI_LINEAR, x2=None, c_split=0, e
                     halo = 1 if 4 * b816 * (p.cout_pad // 64) >= 7 * HALO_MIN_BLOCKS else 4   # (>= 700 workgroups)
                 else:
                     halo = 1
-                    if b816 * nt < HALO_MIN_BLOCKS:
+                    if auto and tn == 128 and pc.cout_pad == 128 and 2 * b816 >= HALO_MIN_BLOCKS:
+                        # a 128-wide layer: 8x16 pixels x 64 channels (two column tiles, three workgroups per CU) --
+                        # at 1/8 of 1080p 2 % of a frame faster than 4x16 x 128 (~510 workgroups either way, two per
+                        # CU), at 1/4 resolution 7 % faster than 8x16 x 128
+                        tn = 64
+                    elif b816 * nt < HALO_MIN_BLOCKS:
                         halo = 4
-                        if auto and tn == 128 and pc.cout_pad == 128 and 2 * b816 >= HALO_MIN_BLOCKS:
-                            # a 128-wide layer at 1/8 of 1080p: 8x16 pixels x 64 channels (two column tiles, ~510
-                            # workgroups, three per CU): 2 % of a frame faster than 4x16 x 128 (~510, two per CU)
-                            halo, tn = 1, 64
                 p.tile_n = tn
     p.halo = halo
     p.bias_map, p.ld_bias_map = (ptr(bias_map.t), bias_map.cs) if bias_map is not None else (None, 0)
