@@ -1,5 +1,5 @@
 """Tile / kernel choice sweep for the layer shapes of a 1080p frame, all candidates of a layer timed interleaved in
-one process (medians of 9; the choice in ops.conv_params is the first column).  python tools/tile_sweep.py"""
+one process (medians of 9; the choice in ops.conv_params is the first column).  python tools/tile_sweep.py [precision] [hf,wf]"""
 import sys
 from pathlib import Path
 
@@ -11,12 +11,12 @@ from woft_amd import ops
 
 def main():
     prec = sys.argv[1] if len(sys.argv) > 1 else "bf16x3"
-    hf, wf = 135, 240
+    hf, wf = (int(v) for v in sys.argv[2].split(",")) if len(sys.argv) > 2 else (135, 240)   # 1/8-resolution grid
     layers = [("gru zr 1x5 256->256", 1, hf, wf, 256, 256, 1, 5), ("gru zr 5x1 256->256", 1, hf, wf, 256, 256, 5, 1),
               ("gru q 1x5 256->128", 1, hf, wf, 256, 128, 1, 5), ("convc2 3x3 256->192", 1, hf, wf, 256, 192, 3, 3),
               ("convf2 3x3 128->64", 1, hf, wf, 128, 64, 3, 3), ("conv 3x3 256->126", 1, hf, wf, 256, 126, 3, 3),
-              ("fh1 3x3 128->256", 1, hf, wf, 128, 256, 3, 3), ("fnet 3x3 64->64 @1/2", 1, 540, 960, 64, 64, 3, 3),
-              ("fnet 3x3 96->96 @1/4", 1, 270, 480, 96, 96, 3, 3), ("fnet 3x3 128->128 @1/8", 1, hf, wf, 128, 128, 3, 3)]
+              ("fh1 3x3 128->256", 1, hf, wf, 128, 256, 3, 3), ("fnet 3x3 64->64 @1/2", 1, 4 * hf, 4 * wf, 64, 64, 3, 3),
+              ("fnet 3x3 96->96 @1/4", 1, 2 * hf, 2 * wf, 96, 96, 3, 3), ("fnet 3x3 128->128 @1/8", 1, hf, wf, 128, 128, 3, 3)]
     cands = [None, (1, 128), (1, 64), (4, 128), (4, 64), (6, 128)]
     for name, n, h, w, cin, cout, kh, kw in layers:
         wt = torch.randn(cout, cin, kh, kw) * 0.05

@@ -221,14 +221,17 @@ def conv_params(x, pc, out, co_off=0, epi=_lib.EPI_LINEAR, x2=None, c_split=0, e
                         p.cout_pad = _round_up(p.cout, 64)
                     halo = 1 if 4 * b816 * (p.cout_pad // 64) >= 7 * HALO_MIN_BLOCKS else 4   # (>= 700 workgroups)
                 else:
-                    halo = 1
-                    if auto and tn == 128 and pc.cout_pad == 128 and 2 * b816 >= HALO_MIN_BLOCKS:
-                        # a 128-wide layer: 8x16 pixels x 64 channels (two column tiles, three workgroups per CU) --
-                        # at 1/8 of 1080p 2 % of a frame faster than 4x16 x 128 (~510 workgroups either way, two per
-                        # CU), at 1/4 resolution 7 % faster than 8x16 x 128
-                        tn = 64
-                    elif b816 * nt < HALO_MIN_BLOCKS:
-                        halo = 4
+                    # bf16x3: 64-channel column tiles (three workgroups per CU) unless their grid lands just over
+                    # one round of the 768 resident slots while the 128-wide tiles (two per CU) still fit in one
+                    # round -- the 256-wide layers at 1/8 of 1080p; 4x16 pixel tiles when 8x16 gives too few workgroups
+                    if auto:
+                        w64 = b816 * math.ceil(p.cout / 64)
+                        wide_ok = pc.cout_pad % 128 == 0 and b816 * (pc.cout_pad // 128) <= 512
+                        if tn == 128 and not (wide_ok and 768 < w64 < 1536):
+                            tn = 64
+                        if tn == 64 and stats is None:   # (with statistics the rows keep the padded width)
+                            p.cout_pad = _round_up(p.cout, 64)
+                    halo = 1 if b816 * (p.cout_pad // tn) >= HALO_MIN_BLOCKS else 4
                 p.tile_n = tn
     p.halo = halo
     p.bias_map, p.ld_bias_map = (ptr(bias_map.t), bias_map.cs) if bias_map is not None else (None, 0)
