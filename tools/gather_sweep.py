@@ -13,7 +13,7 @@ from woft_amd.engine import RaftEngine
 def main():
     prec = sys.argv[1] if len(sys.argv) > 1 else "bf16x3"
     h, w = 1080, 1920
-    eng = RaftEngine(synth.make_state_dict(seed=7), small=False, weighted=True, precision=prec, corr="otf")
+    eng = RaftEngine(synth.make_state_dict(seed=7), small=False, weighted=True, precision=prec, corr=("volume" if prec == "fp32" else "otf"))
     plan = eng.plan(h, w)
     img = torch.randint(0, 255, (h, w, 3), dtype=torch.uint8, device="cuda")
     plan.load_image(0, img, 0, 0)

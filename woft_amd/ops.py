@@ -191,6 +191,8 @@ def conv_params(x, pc, out, co_off=0, epi=_lib.EPI_LINEAR, x2=None, c_split=0, e
     p.out1, p.ldo1 = (ptr(out1.t), out1.cs) if out1 is not None else (None, 0)
     m = x.n * ho * wo
     tm, tn = tiles or pick_tiles(m, pc.cout_pad)
+    if tiles is None and p.precision == 0 and tm == 128 and math.ceil(m / 128) * (pc.cout_pad // tn) < 2048:
+        tm = 64                         # fp32 kernel: 64-row tiles up to ~2000 workgroups (3-15 % per layer, gather_sweep.py fp32)
     if tiles is None and p.precision != 0 and (pc.flat or pc.taps_y * pc.taps_x == 1):
         tm, tn = 64, 64                 # short-K gather layers (1x1, flat 7x7): 64 x 64 tiles measured 5-35 % faster
                                         # than 128-wide ones at every resolution of a 1080p frame (tools/gather_sweep.py)
