@@ -114,6 +114,9 @@ def main():
                          "default mode it also measures the volume lookup for 'roofline_lookup')")
     ap.add_argument("--no-alt-precisions", action="store_true",
                     help="skip the short extra runs at the other two precisions (reported under 'alt_precisions')")
+    ap.add_argument("--tracker-config", default="WOFT", choices=["WOFT", "WOFT_IRLS"],
+                    help="reference-format tracker config under pytracking/configs: weighted LSq (the reference's "
+                         "default, WOFT.py) or the IRLS estimator (BASELINE config 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-template-cache", action="store_true",
                     help="recompute the template's features every frame, as the reference does")
@@ -131,7 +134,7 @@ def main():
     mask = synth.make_init_mask(H, W)
 
     def make_tracker(precision, corr=None, mask_wh=None, graph=False):
-        conf = load_config(ROOT / "pytracking" / "configs" / "WOFT.py")
+        conf = load_config(ROOT / "pytracking" / "configs" / (args.tracker_config + ".py"))
         conf.mask_weight_head = args.mask_weight_head if mask_wh is None else mask_wh
         conf.flow_config.model = sd
         conf.flow_config.iters = args.iters
@@ -230,7 +233,9 @@ def main():
         "dtype": {"fp32": "f32", "bf16x3": "bf16x3 (split-bf16 MFMA operands emulating fp32, fp32 accumulate)",
                   "bf16": "bf16 (fp32 accumulate)"}[args.precision], "data": "synthetic",
         "config": {"workload": f"{H}x{W} synthetic sequence per GPU ({CLIP}-frame clips): WeightedRAFT-full {args.iters} iters + "
-                               "weighted LSq homography on Sobol-500 correspondences (reference default config WOFT.py)",
+                               + ("weighted LSq homography on Sobol-500 correspondences (reference default config WOFT.py)"
+                                if args.tracker_config == "WOFT" else
+                                "IRLS (Huber) homography on Sobol-500 correspondences (reference config WOFT_IRLS.py)"),
                    "resolution": [H, W], "iters": args.iters, "sequences": world, "correlation": corr_mode,
                    "weight_head": "every template pixel (as the reference's network)" if not args.mask_weight_head else
                                   "1/8-res pixels of the template mask (N_in = HW/4, SURVEY 8d) + upsampling support: "
