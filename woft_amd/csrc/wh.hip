@@ -11,18 +11,29 @@ __global__ void colsum_stage1(const float* __restrict__ f, int64_t n_pix, int c,
     const int64_t per = (n_pix + n_part - 1) / n_part;
     const int64_t beg = (int64_t)blockIdx.x * per;
     const int64_t end = beg + per < n_pix ? beg + per : n_pix;
+    // (eight independent chains: the single-accumulator loop was one dependent load latency per pixel)
     for (int ch = threadIdx.x; ch < c; ch += blockDim.x) {
-        double s = 0.0;
-        for (int64_t q = beg; q < end; ++q) s += (double)f[q * c + ch];
-        partial[(int64_t)blockIdx.x * c + ch] = s;
+        double s[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        int64_t q = beg;
+        for (; q + 8 <= end; q += 8) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s[k] += (double)f[(q + k) * c + ch];
+        }
+        for (; q < end; ++q) s[0] += (double)f[q * c + ch];
+        partial[(int64_t)blockIdx.x * c + ch] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
     }
 }
 __global__ void colsum_stage2(const double* __restrict__ partial, int n_part, int c, double* __restrict__ total) {
     const int ch = blockIdx.x * blockDim.x + threadIdx.x;
     if (ch >= c) return;
-    double s = 0.0;
-    for (int b = 0; b < n_part; ++b) s += partial[(int64_t)b * c + ch];
-    total[ch] = s;
+    double s[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    int b = 0;
+    for (; b + 8 <= n_part; b += 8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s[k] += partial[(int64_t)(b + k) * c + ch];
+    }
+    for (; b < n_part; ++b) s[0] += partial[(int64_t)b * c + ch];
+    total[ch] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
 }
 
 // mean[p] = alpha * <f1[p], total>   -- one wavefront per pixel, shuffle reduction
