@@ -1,7 +1,9 @@
 #!/usr/bin/env python
 """Benchmark of the WOFT hot path on MI355X: tracked frames/sec at 1080p, 12 RAFT iterations.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]      (N>1: launched by torch.distributed.run)
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  (N>1: one rank per GPU over RCCL; launched by torch.distributed.run -- by the caller, or by bench.py itself
+   when it is started as a plain `python bench.py --gpus N` without the torchrun environment)
 
 One step = one tracker.track() call: pre-warp of the frame, weighted-RAFT flow (full model, 12
 iterations) template -> frame, masking + Sobol-500 subsampling, weighted least-squares homography,
@@ -122,10 +124,32 @@ def main():
                     help="recompute the template's features every frame, as the reference does")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher -- N ranks of this same command line, one per GPU
+        # (LOCAL_RANK -> device), rendezvous on the loopback address; rank 0 prints the JSON line.  On a box with fewer
+        # than N GPUs (the 1-GPU test box) the ranks share device 0 and gather over gloo (WOFT_SINGLE_DEVICE).
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        if torch.cuda.device_count() < args.gpus:
+            env["WOFT_SINGLE_DEVICE"] = "1"
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+        proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+        for line in proc.stdout:                 # stdout carries the ONE JSON line; library chatter goes to stderr
+            (sys.stdout if line.lstrip().startswith("{") else sys.stderr).write(line)
+            sys.stdout.flush()
+        sys.exit(proc.wait())
+
     from woft_amd import dist as wdist, ops, synth
     from pytracking.utils.config import load_config
     rank, world, local = wdist.init_distributed()
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch {args.gpus} ranks "
+                         f"(or run plain `python bench.py --gpus {args.gpus}`, which launches them itself)")
     H, W, K, Wm = args.height, args.width, args.steps, args.warmup
     assert H % 8 == 0 and W % 8 == 0
 

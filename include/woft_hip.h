@@ -268,22 +268,42 @@ int woft_resize_linear_u8(const uint8_t* img, int32_t h, int32_t w, int32_t c, u
 
 /* Correspondence masking + order-preserving compaction + Sobol subsampling on the device
  * (tracker/YAOF_tracker_single_control.py:287-327; configs/..._wLSq.py:31-53), outputs in woft_hfit's format.
- * dst: [2][h*w] (x plane, y plane) target coords of source pixel i = y*w + x; w: [h*w] or NULL; tmask: uint8 [h][w];
- * check_dst != 0 adds the bounds test on dst and, if pwmask != NULL, pwmask[rint(dy)][rint(dx)].
- * sobol_u: [n_draw] float32 1-D Sobol points (n_draw <= 1024; 0 = keep all).  ws: woft_tc_select_ws_bytes(h*w) bytes.
+ * The correspondences live on the flow grid gh x gw (the frame; with padding_mode 'crop' the frame cropped to a
+ * multiple of 8, optical_flow/raft.py:235-247), the masks have the frame's size mh x mw (gh <= mh, gw <= mw).
+ * dst: [2][gh*gw] (x plane, y plane) target coords of source pixel i = y*gw + x; w: [gh*gw] or NULL; tmask, pwmask:
+ * uint8 [mh][mw]; check_dst != 0 adds the bounds test of dst against (mw, mh) and, if pwmask != NULL,
+ * pwmask[rint(dy)][rint(dx)].
+ * sobol_u: [n_draw] float32 1-D Sobol points (n_draw <= 1024; 0 = keep all).  ws: woft_tc_select_ws_bytes(gh*gw) bytes.
  * pa[k] = (dst_x, dst_y), pb[k] = (src_x, src_y), wout[k]; count[0] = selected (<= cap), count[1] = kept by the masks. */
 int64_t woft_tc_select_ws_bytes(int64_t n);
-int woft_tc_select(const float* dst, const float* w, const uint8_t* tmask, const uint8_t* pwmask, int32_t h,
-                   int32_t wimg, int32_t check_dst, const float* sobol_u, int32_t n_draw, void* ws,
-                   float* pa, float* pb, float* wout, int32_t cap, int32_t* count, void* stream);
+int woft_tc_select(const float* dst, const float* w, const uint8_t* tmask, const uint8_t* pwmask, int32_t gh,
+                   int32_t gw, int32_t mh, int32_t mw, int32_t check_dst, const float* sobol_u, int32_t n_draw,
+                   void* ws, float* pa, float* pb, float* wout, int32_t cap, int32_t* count, void* stream);
+/* The keep rule of woft_tc_select alone (`_mask_coords` / `_mask_coords_flow`, YAOF_tracker_single_control.py:287-327):
+ * flags[i] = 1 where correspondence i survives, uint8 [gh*gw].  For callers that compact with their own code (the
+ * tracker's generic path hands the compacted tensors to the config's subsampler / estimator callables). */
+int woft_tc_flags(const float* dst, const uint8_t* tmask, const uint8_t* pwmask, int32_t gh, int32_t gw, int32_t mh,
+                  int32_t mw, int32_t check_dst, uint8_t* flags, void* stream);
 
 /* Weighted / iteratively re-weighted least-squares homography, utils/least_squares_H.py:142-210
  * (n_irls = 0) and :280-346 (n_irls = 5 -> 6 solves); reweight: 0 none, 1 L1 (:268-269),
  * 2 Huber(k) (:272-277).  pa, pb: [n][2] points (A -> B), w: [n] or NULL; n = min(count[0], n_max)
  * when count != NULL (device), else n_max.  Hout: 9 floats (row major, device).
- * status[0] (device) = 0 ok, 1 fewer than 4 points, 2 singular system. */
+ * status[0] (device) = 0 ok, 1 fewer than 4 points, 2 singular system.
+ * ws: NULL, or woft_hfit_ws_bytes() bytes of device scratch: with it, fits of more than WOFT_HFIT_SINGLE_MAX
+ * correspondences (configs without a subsampler: up to H*W) run as a streaming multi-workgroup pipeline instead of
+ * in one workgroup; same arithmetic (fp32 rows, fp64 Gram matrix on the fp64 matrix cores, fp64 Cholesky). */
+#define WOFT_HFIT_SINGLE_MAX 8192
+int64_t woft_hfit_ws_bytes(void);
 int woft_hfit(const float* pa, const float* pb, const float* w, int32_t n_max, const int32_t* count,
-              int32_t reweight, float huber_k, int32_t n_irls, float* Hout, int32_t* status, void* stream);
+              int32_t reweight, float huber_k, int32_t n_irls, void* ws, float* Hout, int32_t* status, void* stream);
+/* ONE re-weighted solve of the same system, for arbitrary `reweighting_fn` callables (least_squares_H.py:280,323-337):
+ * rew: [2n] per-row re-weights sqrt(reweighting_fn(residual)) of the previous step or NULL (= ones, first step);
+ * first != 0 (re)computes the normalisation into ws; res (may be NULL): [2n] residuals A x - b of THIS step's solution
+ * on the weighted, not re-weighted, system (:334) -- the host applies the user's callable to them and calls again;
+ * Hout / status as woft_hfit (H of this step's solution, de-normalised). */
+int woft_hfit_step(const float* pa, const float* pb, const float* w, int32_t n, const float* rew, int32_t first,
+                   void* ws, float* res, float* Hout, int32_t* status, void* stream);
 /* torch_proj_errors + inlier fraction (least_squares_H.py:474-489; configs/..._wLSq.py:14-21):
  * frac[0] = mean(|proj(H, A) - B| <= thr). */
 int woft_inlier_frac(const float* pa, const float* pb, int32_t n_max, const int32_t* count, const float* H,

@@ -125,6 +125,12 @@ def gen_flow():
     np.savez_compressed(GOLD / "flow_full_136x200_it12.npz", img1=a, img2=b, seed=7, iters=12,
                         flow_low=flow_low.numpy(), flow_up=flow_up.numpy(),
                         w_low=w_low.numpy(), w_up=w_up.numpy())
+    # case C: the same pair at 32 iterations (BASELINE config 3: the refinement loop of weighted_raft.py:228-237
+    # run to the depth the bf16 EPE budget of SURVEY 8d is stated at); outputs only
+    flow_low, flow_up, vol, w_low, w_up = net(to_t(a), to_t(b), iters=32, test_mode=True)
+    np.savez_compressed(GOLD / "flow_full_136x200_it32.npz", img1=a, img2=b, seed=7, iters=32,
+                        flow_low=flow_low.numpy(), flow_up=flow_up.numpy(),
+                        w_low=w_low.numpy(), w_up=w_up.numpy())
 
     # ---- small plain RAFT (config 1 family) -----------------------------------------
     sds = synth.make_state_dict(seed=8, small=True, weighted=False)
@@ -265,6 +271,98 @@ def gen_hfit():
     np.savez_compressed(GOLD / "sobol.npz", **sob)
 
 
+def install_functional_cv2():
+    """SURVEY 8c fixture (7): the reference TRACKER needs cv2.warpPerspective / resize / findContours to do real
+    work.  OpenCV is absent from the image, so the stub below supplies them with the float-bilinear arithmetic of
+    oracle/tracker_ref.py (which the HIP warp kernel implements): the fixture pins the reference's state machine,
+    masking, subsampling, estimator plumbing and homography composition -- NOT OpenCV's fixed-point interpolation,
+    which stays parity-unpinned."""
+    from scipy import ndimage
+    from oracle import tracker_ref as TR
+    cv2 = sys.modules["cv2"]
+    cv2.INTER_NEAREST, cv2.INTER_LINEAR = 0, 1
+    cv2.RETR_EXTERNAL, cv2.CHAIN_APPROX_NONE = 0, 1
+
+    def warpPerspective(src, M, dsize, flags=1, **kw):
+        assert tuple(dsize) == (src.shape[1], src.shape[0]) and not kw
+        if flags == cv2.INTER_NEAREST:
+            return TR.warp_nearest(src, M)
+        return TR.warp_linear_u8(src, M) if src.dtype == np.uint8 else TR.warp_linear(src, M)
+
+    def resize(img, dsize, fx=None, fy=None, **kw):
+        assert dsize is None and fx == fy and not kw
+        return TR.resize_linear_u8(img, 1.0 / fx)
+
+    def findContours(mask, mode, method):
+        _, n = ndimage.label(mask > 0, structure=np.ones((3, 3), dtype=bool))     # external contours = 8-connected blobs
+        ys, xs = np.nonzero(mask)
+        return [np.stack([xs, ys], 1)[:, None, :].astype(np.int32)] * n, None      # (the tracker only counts them)
+
+    cv2.warpPerspective, cv2.resize, cv2.findContours = warpPerspective, resize, findContours
+
+
+@torch.no_grad()
+def gen_tracker():
+    """Runs of the reference's own YAOFTrackerSingleControl (tracker/YAOF_tracker_single_control.py:18-327) built
+    from the reference's own config files, on short synthetic sequences: per frame H_cur2init and the meta fields."""
+    import tempfile
+    from pytracking.utils.config import load_config
+    install_functional_cv2()
+    sd = synth.make_state_dict(seed=7, small=False, weighted=True)
+    H, W, iters = 128, 160, 4
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        model = os.path.join(td, "sd.pth")
+        torch.save(sd, model)
+
+        def run(name, cfg, seq_id, frame_ts, force_fail=(), mutate=None):
+            conf = load_config(REF / "pytracking/configs" / cfg)
+            conf.flow_config.model = model
+            conf.flow_config.iters = iters
+            if mutate:
+                mutate(conf)
+            state = {"i": 0}
+            orig = conf.redet_success_fn
+
+            def redet(*a):                       # config-level hook: the re-detection test fails on chosen frames
+                ok = orig(*a)
+                return ok if state["i"] not in force_fail else (ok & False)
+            conf.redet_success_fn = redet
+            trk = conf.tracker_class(conf)
+            template = synth.make_template(H, W, seq_id=seq_id)
+            mask = synth.make_init_mask(H, W)
+            trk.init(template, mask)
+            frames, Hs, meta = [], [], []
+            for i, t in enumerate(frame_ts):
+                state["i"] = i
+                f = synth.make_frame(template, t)
+                Hc, m = trk.track(f)
+                frames.append(f)
+                Hs.append(np.asarray(Hc, np.float64))
+                loc = getattr(m, "H_local_cur2init", None)
+                meta.append([float(bool(m.lost)), float(m.N_lost), float(bool(m.global_H_success)),
+                             0.0 if loc is None else 1.0])
+                out[f"{name}_Hglobal_{i}"] = np.asarray(m.H_global_cur2init, np.float64)
+                out[f"{name}_lastgood_{i}"] = np.asarray(m.last_good_H2init, np.float64)
+                if loc is not None:
+                    out[f"{name}_Hlocal_{i}"] = np.asarray(loc, np.float64)
+            out[f"{name}_template"], out[f"{name}_mask"] = template, mask
+            out[f"{name}_frames"] = np.stack(frames)
+            out[f"{name}_H"], out[f"{name}_meta"] = np.stack(Hs), np.asarray(meta)
+            out[f"{name}_force_fail"] = np.asarray(sorted(force_fail), np.int64)
+
+        # (a) default config, 5 frames; (b) the same with the re-detection test failing on frames 2 and 3: the
+        #     lost / local-flow branch (TRK:171-207) and the recovery; (c) the IRLS config (ablation_08)
+        run("woft", "WOFT.py", 3, [1, 2, 3, 4, 5])
+        run("lost", "WOFT.py", 4, [1, 2, 3, 4, 5, 6], force_fail=(2, 3))
+        def cuda_flag(conf):                     # the IRLS estimator insists on is_cuda (least_squares_H.py:292-293)
+            est = conf.H_estimator
+            conf.H_estimator = lambda a, b, w: torch.Tensor(est(a.as_subclass(FakeCuda), b, w))
+        run("irls", "ablation_08.py", 5, [1, 2, 3], mutate=cuda_flag)
+    out["iters"], out["seed"] = iters, 7
+    np.savez_compressed(GOLD / "tracker_ref_runs.npz", **out)
+
+
 def main():
     GOLD.mkdir(parents=True, exist_ok=True)
     install_stubs()
@@ -276,6 +374,8 @@ def main():
         gen_wrapper()
     if only in (None, "hfit"):
         gen_hfit()
+    if only in (None, "tracker"):
+        gen_tracker()
     for p in sorted(GOLD.iterdir()):
         print(f"{p.name:40s} {p.stat().st_size/1024:9.1f} KB")
 

@@ -101,6 +101,8 @@ class TrackerRef:
         self.subsample = subsample
         self.no_prewarp_after_N = no_prewarp_after_N
         self.no_local_H = no_local_H
+        self.force_fail = ()          # frame indices (0-based track() calls) whose re-detection test is made to fail
+        self._n_tracked = 0
         if estimator == "qr":
             self.H_estimator = hfit_ref.find_homography_nonhomogeneous_QR
         elif estimator == "irls_huber2":
@@ -150,6 +152,9 @@ class TrackerRef:
         H_global = hfit_ref.compose_H(prewarp_H, Hpw[0].numpy())
         meta.H_global_cur2init = H_global.copy()
         ok = hfit_ref.redet_success(Hpw, tc, cur)
+        if self._n_tracked in self.force_fail:                   # (config-level hook of the golden runs, gen_golden.py)
+            ok = False
+        self._n_tracked += 1
         if ok:
             H_cur = H_global
             self.lost, self.N_lost = False, 0

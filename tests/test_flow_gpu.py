@@ -180,6 +180,31 @@ def test_reduced_precision_operating_points(golden_dir, precision, epe_mean, epe
 
 
 @torch.no_grad()
+@pytest.mark.parametrize("precision,corr,epe_mean,epe_max,wtol", [
+    ("fp32", "volume", 1e-3, 1e-2, 1e-4), ("bf16x3", "otf", 1e-3, 1e-2, 1e-4), ("bf16x3", "volume", 1e-3, 1e-2, 1e-4),
+    ("bf16", "otf", 0.15, 1.0, 5e-3), ("bf16", "volume", 0.15, 1.0, 5e-3)])
+def test_32_iterations_vs_reference_golden(golden_dir, precision, corr, epe_mean, epe_max, wtol):
+    """BASELINE config 3 (32 refinement iterations; bf16 operating point) against the REFERENCE's flow at 32
+    iterations (weighted_raft.py:228-237 run 32 times; tests/golden/flow_full_136x200_it32.npz).  Budgets of SURVEY
+    8d: fp32-class arithmetic (fp32, bf16x3) EPE mean <= 1e-3 px / max <= 1e-2 px; bf16 EPE mean <= 0.15 px @ 32 it,
+    sigmoid(w) <= 5e-3."""
+    g = np.load(golden_dir / "flow_full_136x200_it32.npz")
+    assert int(g["iters"]) == 32
+    sd = synth.make_state_dict(seed=int(g["seed"]))
+    fc = _flow_config(sd, 32, precision=precision)
+    fc.corr = corr
+    flower = fc.of_class(fc)
+    assert flower.engine.corr == corr and flower.engine.precision == precision
+    flow, w = flower.compute_flow(g["img1"], g["img2"], mode="flow", do_sigmoid=True)
+    torch.cuda.synchronize()
+    m, mx = _epe(flow, torch.from_numpy(g["flow_up"])[0])
+    print(f"32 it, {precision}/{corr}: EPE mean {m:.2e} max {mx:.2e} (mean |flow| "
+          f"{float(np.sqrt((g['flow_up'] ** 2).sum(1)).mean()):.2f} px)")
+    assert m < epe_mean and mx < epe_max, (m, mx)
+    assert float((w.cpu() - torch.sigmoid(torch.from_numpy(g["w_up"])[0])).abs().max()) < wtol
+
+
+@torch.no_grad()
 def test_cached_flow_wire_format(tmp_path):
     """Pre-computed flow (utils/caching.py:53-59: '<i>-<i+1>.npz' with fp16 'half_flow' / 'half_weights') goes
     through the same TC / sigmoid post-processing as a computed one (raft.py:92-109,152-195); a missing file falls

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from oracle import hfit_ref, raft_ref
+from oracle import hfit_ref, raft_ref, tracker_ref
 from woft_amd import synth
 
 
@@ -57,6 +57,7 @@ def test_full_model_with_intermediates(golden_dir):
 @torch.no_grad()
 @pytest.mark.parametrize("name,small,weighted", [
     ("flow_full_136x200_it12", False, True),
+    ("flow_full_136x200_it32", False, True),
     ("flow_small_128x160_it4", True, False),
     ("flow_wsmall_128x160_it4", True, True),
 ])
@@ -158,3 +159,33 @@ def test_sobol(golden_dir):
     for N in (400, 501, 600, 2000, 518400):
         m = hfit_ref.sobol_subsample_mask(N, 500)
         assert np.array_equal(np.nonzero(m)[0], g[f"n{N}"])
+
+
+def _box_err(Ha, Hb, H, W):
+    c = np.array([[W / 4, H / 4, 1], [3 * W / 4, H / 4, 1], [3 * W / 4, 3 * H / 4, 1], [W / 4, 3 * H / 4, 1.0]]).T
+    pa, pb = np.linalg.inv(Ha) @ c, np.linalg.inv(Hb) @ c
+    return np.abs(pa[:2] / pa[2] - pb[:2] / pb[2]).max()
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("name,estimator", [("woft", "qr"), ("lost", "qr"), ("irls", "irls_huber2")])
+def test_tracker_state_machine_vs_reference_runs(golden_dir, name, estimator):
+    """SURVEY 8c fixture (7): oracle/tracker_ref.py against runs of the reference's own YAOFTrackerSingleControl
+    (reference configs WOFT.py / ablation_08.py, functional numpy cv2 stub; oracle/gen_golden.py: gen_tracker) --
+    per frame the homography, lost / N_lost / global_H_success, the pre-warp used and the local-branch result."""
+    g = np.load(golden_dir / "tracker_ref_runs.npz")
+    sd = synth.make_state_dict(seed=int(g["seed"]))
+    ref = tracker_ref.TrackerRef(sd, iters=int(g["iters"]), estimator=estimator)
+    ref.force_fail = tuple(int(i) for i in g[f"{name}_force_fail"])
+    ref.init(g[f"{name}_template"], g[f"{name}_mask"])
+    H, W = g[f"{name}_mask"].shape
+    for i, f in enumerate(g[f"{name}_frames"]):
+        Hc, m = ref.track(f)
+        lost, n_lost, ok, has_local = g[f"{name}_meta"][i]
+        assert (m.lost, m.N_lost, bool(m.global_H_success)) == (bool(lost), int(n_lost), bool(ok)), (name, i)
+        assert _box_err(Hc, g[f"{name}_H"][i], H, W) < 0.02, (name, i)
+        assert _box_err(m.H_global_cur2init, g[f"{name}_Hglobal_{i}"], H, W) < 0.02
+        assert np.allclose(m.last_good_H2init, g[f"{name}_lastgood_{i}"], atol=1e-3)
+        assert hasattr(m, "H_local_cur2init") == bool(has_local)
+        if has_local:
+            assert _box_err(m.H_local_cur2init, g[f"{name}_Hlocal_{i}"], H, W) < 0.02

@@ -222,3 +222,121 @@ def test_weight_head_on_mask_region_only():
             assert np.array_equal(w_reg[0, sel], w_full[0, sel])
     for a, b in zip(outs[True], outs[False]):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("name,cfg", [("woft", "WOFT.py"), ("lost", "WOFT.py"), ("irls", "WOFT_IRLS.py")])
+@pytest.mark.parametrize("backend", ["device", "callables"])
+def test_tracker_vs_reference_tracker_runs(golden_dir, monkeypatch, name, cfg, backend):
+    """SURVEY 8c fixture (7): the HIP tracker against runs of the REFERENCE's own YAOFTrackerSingleControl
+    (oracle/gen_golden.py: gen_tracker -- reference configs WOFT.py / ablation_08.py, functional cv2 stub): per frame
+    the homography (box corners < 1 px), lost / N_lost / global_H_success and the local-branch result, incl. the frames
+    whose re-detection test was made to fail (lost -> local flow -> recovery).  Both solver back ends."""
+    from pytracking.utils.config import load_config
+    from woft_amd import presets
+    g = np.load(golden_dir / "tracker_ref_runs.npz")
+    monkeypatch.setenv("WOFT_FUSED", "1" if backend == "device" else "0")
+    sd = synth.make_state_dict(seed=int(g["seed"]))
+    conf = load_config(ROOT / "pytracking" / "configs" / cfg)
+    conf.flow_config.model = sd
+    conf.flow_config.iters = int(g["iters"])
+    tracker = conf.tracker_class(conf)
+    assert (tracker._fused is not None) == (backend == "device")
+    mask = g[f"{name}_mask"]
+    H, W = mask.shape
+    tracker.init(g[f"{name}_template"], mask)
+    fail = set(int(i) for i in g[f"{name}_force_fail"])
+    normal, never = conf.redet_success_fn, presets.redetection_by_inliers(1e-6, 0.999)
+    for i, f in enumerate(g[f"{name}_frames"]):
+        tracker.C.redet_success_fn = never if i in fail else normal           # config-level hook, as in the golden run
+        tracker._fused = tracker._fused_specs()
+        Hg, mg = tracker.track(f)
+        lost, n_lost, ok, has_local = g[f"{name}_meta"][i]
+        assert (mg.lost, mg.N_lost, bool(mg.global_H_success)) == (bool(lost), int(n_lost), bool(ok)), (name, i)
+        assert _corners_err(Hg, g[f"{name}_H"][i], H, W) < 1.0, (name, i)
+        assert _corners_err(mg.H_global_cur2init, g[f"{name}_Hglobal_{i}"], H, W) < 1.0
+        assert np.allclose(mg.last_good_H2init, g[f"{name}_lastgood_{i}"], atol=1e-2)
+        assert hasattr(mg, "H_local_cur2init") == bool(has_local)
+        if has_local:
+            assert _corners_err(mg.H_local_cur2init, g[f"{name}_Hlocal_{i}"], H, W) < 1.0
+
+
+@pytest.mark.parametrize("backend", ["device", "callables"])
+def test_tracker_crop_padding_mode(monkeypatch, backend):
+    """padding_mode 'crop' (optical_flow/raft.py:235-247) on frames that are not multiples of 8: the flow grid is
+    smaller than the frame, the masks are not -- both back ends must index them as the reference does (the oracle
+    tracker does it with the reference's own indexing expressions)."""
+    from pytracking.utils.config import load_config
+    H, W, iters = 133, 171, 3                                  # flow grid 128 x 168
+    monkeypatch.setenv("WOFT_FUSED", "1" if backend == "device" else "0")
+    sd = synth.make_state_dict(seed=7)
+    template = synth.make_template(H, W, seq_id=9)
+    frames = [synth.make_frame(template, t) for t in (1, 2, 3)]
+    mask = synth.make_init_mask(H, W)
+    conf = load_config(ROOT / "pytracking" / "configs" / "WOFT.py")
+    conf.flow_config.model = sd
+    conf.flow_config.iters = iters
+    conf.flow_config.padding_mode = "crop"
+    tracker = conf.tracker_class(conf)
+    tracker.init(template, mask)
+    ref = tracker_ref.TrackerRef(sd, iters=iters, padding_mode="crop")
+    ref.init(template, mask)
+    for f in frames:
+        Hg, mg = tracker.track(f)
+        Hr, mr = ref.track(f)
+        assert tracker.flower.last_flow_shape["H"] == 128 and tracker.flower.last_flow_shape["W"] == 168
+        assert mg.lost == mr.lost and mg.N_lost == mr.N_lost
+        assert _corners_err(Hg, Hr, H, W) < 1.0
+
+
+def test_tracker_without_subsampler_fits_every_kept_correspondence(monkeypatch):
+    """Configs without `subsampler_fn` (N up to the in-mask count) fit all kept correspondences: the
+    device back end streams them through the multi-workgroup fit; it must equal the callable back end."""
+    from pytracking.utils.config import load_config
+    H, W, iters = 256, 320, 3                                  # mask 128 x 160 = 20480 correspondences > 8192
+    sd = synth.make_state_dict(seed=7)
+    template = synth.make_template(H, W, seq_id=10)
+    frames = [synth.make_frame(template, t) for t in (1, 2)]
+    mask = synth.make_init_mask(H, W)
+    outs = {}
+    for fused in (True, False):
+        monkeypatch.setenv("WOFT_FUSED", "1" if fused else "0")
+        conf = load_config(ROOT / "pytracking" / "configs" / "WOFT_IRLS.py")
+        conf.flow_config.model = sd
+        conf.flow_config.iters = iters
+        conf.flow_config.precision = "bf16x3"
+        conf.subsampler_fn = None
+        trk = conf.tracker_class(conf)
+        assert (trk._fused is not None) == fused
+        trk.init(template, mask)
+        outs[fused] = [trk.track(f) for f in frames]
+        if fused:
+            assert trk._fb["fit_ws"] is not None and trk._fb["pa"].shape[0] == H * W
+    for (Ha, ma), (Hb, mb) in zip(outs[True], outs[False]):
+        assert ma.lost == mb.lost and bool(ma.global_H_success) == bool(mb.global_H_success)
+        assert np.array_equal(Ha, Hb), np.abs(Ha - Hb).max()
+
+
+def test_operator_outputs_are_not_aliased():
+    """compute_flow returns tensors of its own (the reference returns fresh tensors): a forward / backward pair must
+    not share memory; borrow=True (the tracker's private fast path) may."""
+    from pytracking.utils.config import load_config
+    sd = synth.make_state_dict(seed=7)
+    conf = load_config(ROOT / "pytracking" / "configs" / "WOFT.py")
+    fc = conf.flow_config
+    fc.model, fc.iters = sd, 2
+    flower = fc.of_class(fc)
+    a = synth.make_template(128, 160, seq_id=1)
+    b = synth.make_frame(a, 2)
+    f, wf = flower.compute_flow(a, b, mode="flow")
+    f0 = f.clone()
+    gflow, wg = flower.compute_flow(b, a, mode="flow")
+    assert f.data_ptr() != gflow.data_ptr() and wf.data_ptr() != wg.data_ptr()
+    assert torch.equal(f, f0) and not torch.equal(f, gflow)
+    _, d1, w1 = flower.compute_flow(a, b, mode="TC", do_sigmoid=True)
+    _, d2, w2 = flower.compute_flow(b, a, mode="TC", do_sigmoid=True)
+    assert d1.data_ptr() != d2.data_ptr() and w1.data_ptr() != w2.data_ptr()
+    _, d3, _ = flower.compute_flow(a, b, mode="TC", do_sigmoid=True, borrow=True)
+    _, d4, _ = flower.compute_flow(b, a, mode="TC", do_sigmoid=True, borrow=True)
+    assert d3.data_ptr() == d4.data_ptr()
+    with pytest.raises(TypeError):
+        flower.compute_flow(a.astype(np.float32), b.astype(np.float32))

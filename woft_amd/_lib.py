@@ -78,8 +78,11 @@ _SIGS = {
     "woft_warp_perspective_u8": (i32, [vp, i32, i32, i32, C.POINTER(C.c_double), vp, vp, i32, vp]),
     "woft_resize_linear_u8": (i32, [vp, i32, i32, i32, vp, i32, i32, f32, f32, vp]),
     "woft_tc_select_ws_bytes": (i64, [i64]),
-    "woft_tc_select": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, i32, vp, vp, vp, vp, i32, vp, vp]),
-    "woft_hfit": (i32, [vp, vp, vp, i32, vp, i32, f32, i32, vp, vp, vp]),
+    "woft_tc_select": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, i32, vp, vp, vp, vp, i32, vp, vp]),
+    "woft_tc_flags": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]),
+    "woft_hfit_ws_bytes": (i64, []),
+    "woft_hfit": (i32, [vp, vp, vp, i32, vp, i32, f32, i32, vp, vp, vp, vp]),
+    "woft_hfit_step": (i32, [vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp]),
     "woft_inlier_frac": (i32, [vp, vp, i32, vp, vp, f32, vp, vp]),
 }
 

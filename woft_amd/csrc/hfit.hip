@@ -10,8 +10,14 @@
 // fp64 matrix cores, v_mfma_f64_16x16x4_f64 -- one MFMA consumes the 4 system rows of 2
 // correspondences, lane (c = lane & 15, k = lane >> 4) supplying element c of row k as BOTH operands
 // (A[i][k] = B[k][i] = R_k[i]).  One workgroup does the whole fit in a single launch (N <= 500 after
-// the Sobol subsampler of the default configs; larger N loops).
+// the Sobol subsampler of the default configs).  Configs without a subsampler fit up to H*W = 2 M (1080p) / 8.3 M
+// (4K) correspondences: with a workspace the same arithmetic runs as a streaming multi-workgroup pipeline
+// (`hfit_sum` -> `hfit_dist` -> per solve `hfit_gram` + `hfit_solve`; 20 B per correspondence per pass, partial
+// Gram matrices reduced in a fixed order -> deterministic).  The same pipeline, one solve per call, serves
+// ARBITRARY re-weighting callables (least_squares_H.py:280,337): `woft_hfit_step` takes the per-row re-weights the
+// host computed from the residuals of the previous call and returns the residuals A x - b of its own solution.
 #include "common.h"
+#include <algorithm>
 
 namespace {
 
@@ -248,13 +254,321 @@ __global__ __launch_bounds__(HT) void inlier_frac_kernel(const float* __restrict
     if (threadIdx.x == 0) frac[0] = (n > 0) ? (float)(tot[0] / n) : 0.f;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Streaming multi-workgroup pipeline (large N, external re-weights).  Workspace (doubles first):
+//   psum[G][4] | pdist[G][2] | pgram[G][81] | then floats: sol[8] | norm[8] (s1, t1x, t1y, s2, t2x, t2y, n, -)
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int MT = 256;            // threads per workgroup of the streaming kernels
+constexpr int MAXG = 1024;         // workgroups (4 per CU)
+
+struct MWs {
+    double* psum;
+    double* pdist;
+    double* pgram;
+    float* sol;
+    float* norm;
+};
+__host__ __device__ inline MWs mws_layout(void* ws) {
+    MWs o;
+    o.psum = (double*)ws;
+    o.pdist = o.psum + MAXG * 4;
+    o.pgram = o.pdist + MAXG * 2;
+    o.sol = (float*)(o.pgram + MAXG * 81);
+    o.norm = o.sol + 8;
+    return o;
+}
+inline int mws_groups(int n_max) { return (int)std::min<int64_t>(MAXG, std::max<int64_t>(1, ((int64_t)n_max + 2047) / 2048)); }
+
+template <int CNT>
+__device__ void block_sum_m(double (&vals)[CNT], double* red /* [MT/64][CNT] */, double* out /* global [CNT] */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) {
+        const double s = wave_sum(vals[i]);
+        if (lane == 0) red[wave * CNT + i] = s;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < CNT) {
+        double s = 0.0;
+        for (int wv = 0; wv < MT / 64; ++wv) s += red[wv * CNT + threadIdx.x];
+        out[threadIdx.x] = s;
+    }
+}
+
+__device__ __forceinline__ int fit_count(const int* count, int n_max) { return count ? min(count[0], n_max) : n_max; }
+
+__global__ __launch_bounds__(MT) void hfit_sum_kernel(const float* __restrict__ pa, const float* __restrict__ pb, int n_max,
+                                                      const int* __restrict__ count, void* ws) {
+    __shared__ double red[(MT / 64) * 4];
+    const MWs s = mws_layout(ws);
+    const int n = fit_count(count, n_max);
+    double v[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int64_t i = (int64_t)blockIdx.x * MT + threadIdx.x; i < n; i += (int64_t)gridDim.x * MT) {
+        const float2 a = ((const float2*)pa)[i], b = ((const float2*)pb)[i];
+        v[0] += (double)a.x; v[1] += (double)a.y; v[2] += (double)b.x; v[3] += (double)b.y;
+    }
+    block_sum_m<4>(v, red, s.psum + blockIdx.x * 4);
+}
+
+// means from the partial sums (fixed order); every workgroup repeats the small reduction
+__device__ __forceinline__ void fit_means(const MWs& s, int n, double* sh /* [4] */) {
+    if (threadIdx.x < 4) {
+        double t = 0.0;
+        for (int g = 0; g < (int)gridDim.x; ++g) t += s.psum[g * 4 + threadIdx.x];
+        sh[threadIdx.x] = t / n;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(MT) void hfit_dist_kernel(const float* __restrict__ pa, const float* __restrict__ pb, int n_max,
+                                                       const int* __restrict__ count, void* ws) {
+    __shared__ double red[(MT / 64) * 2];
+    __shared__ double mean[4];
+    const MWs s = mws_layout(ws);
+    const int n = fit_count(count, n_max);
+    if (n < 1) return;
+    fit_means(s, n, mean);
+    const float m1x = (float)mean[0], m1y = (float)mean[1], m2x = (float)mean[2], m2y = (float)mean[3];
+    double v[2] = {0.0, 0.0};
+    for (int64_t i = (int64_t)blockIdx.x * MT + threadIdx.x; i < n; i += (int64_t)gridDim.x * MT) {
+        const float2 a = ((const float2*)pa)[i], b = ((const float2*)pb)[i];
+        const float ax = a.x - m1x, ay = a.y - m1y, bx = b.x - m2x, by = b.y - m2y;
+        v[0] += (double)sqrtf(ax * ax + ay * ay);
+        v[1] += (double)sqrtf(bx * bx + by * by);
+    }
+    block_sum_m<2>(v, red, s.pdist + blockIdx.x * 2);
+}
+
+// normalisation parameters from the partials -> shared nf[6] (same formulas as the single-workgroup kernel)
+__device__ __forceinline__ void fit_norm(const MWs& s, int n, double* mean /* [4] */, double* dist /* [2] */, float* nf) {
+    fit_means(s, n, mean);
+    if (threadIdx.x < 2) {
+        double t = 0.0;
+        for (int g = 0; g < (int)gridDim.x; ++g) t += s.pdist[g * 2 + threadIdx.x];
+        dist[threadIdx.x] = t / n;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float m1x = (float)mean[0], m1y = (float)mean[1], m2x = (float)mean[2], m2y = (float)mean[3];
+        const float s1 = sqrtf(2.0f) / ((float)dist[0] + 1e-8f), s2 = sqrtf(2.0f) / ((float)dist[1] + 1e-8f);
+        nf[0] = s1; nf[1] = -s1 * m1x; nf[2] = -s1 * m1y; nf[3] = s2; nf[4] = -s2 * m2x; nf[5] = -s2 * m2y;
+    }
+    __syncthreads();
+}
+
+// partial Gram matrix of this workgroup's share of the rows.  Row re-weights: `rew` (2 per correspondence, external)
+// or, when use_sol, sqrt(reweight_fn(residual of `sol`)) of the built-in losses.
+__global__ __launch_bounds__(MT) void hfit_gram_kernel(const float* __restrict__ pa, const float* __restrict__ pb,
+                                                       const float* __restrict__ w, int n_max,
+                                                       const int* __restrict__ count, const float* __restrict__ rew,
+                                                       int reweight, float huber_k, int use_sol, void* ws) {
+    __shared__ double mean[4], dist[2];
+    __shared__ float nf[6];
+    __shared__ double red[(MT / 64) * 81];
+    const MWs s = mws_layout(ws);
+    const int n = fit_count(count, n_max);
+    if (n < 4) return;
+    fit_norm(s, n, mean, dist, nf);
+    const float s1 = nf[0], t1x = nf[1], t1y = nf[2], s2 = nf[3], t2x = nf[4], t2y = nf[5];
+    if (blockIdx.x == 0 && threadIdx.x < 6) s.norm[threadIdx.x] = nf[threadIdx.x];
+    float sol[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sol[k] = use_sol ? s.sol[k] : 0.f;
+    typedef double f64x4 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ec = lane & 15, ek = lane >> 4;
+    f64x4 g4 = {0.0, 0.0, 0.0, 0.0};
+    const int64_t stride = (int64_t)gridDim.x * (MT / 64) * 2;
+    for (int64_t base = ((int64_t)blockIdx.x * (MT / 64) + wave) * 2; base < n; base += stride) {
+        const int64_t i = base + (ek >> 1);
+        double val = 0.0;
+        if (i < n && ec < 9) {
+            const float2 a = ((const float2*)pa)[i], b = ((const float2*)pb)[i];
+            const float x1 = s1 * a.x + t1x, y1 = s1 * a.y + t1y, x2 = s2 * b.x + t2x, y2 = s2 * b.y + t2y;
+            const float wv = (w != nullptr) ? w[i] : 1.f;
+            float rx[9], ry[9];
+            build_rows(x1, y1, x2, y2, wv, rx, ry);
+            float q = 1.f;
+            if (rew != nullptr) {
+                q = rew[2 * i + (ek & 1)];
+            } else if (use_sol && reweight != 0) {
+                float resx = -rx[8], resy = -ry[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    resx += rx[k] * sol[k];
+                    resy += ry[k] * sol[k];
+                }
+                q = sqrtf(reweight_fn((ek & 1) ? resy : resx, reweight, huber_k));
+            }
+            float e = 0.f;
+#pragma unroll
+            for (int k = 0; k < 9; ++k)
+                if (k == ec) e = (ek & 1) ? ry[k] : rx[k];
+            val = (double)(e * q);
+        }
+        g4 = __builtin_amdgcn_mfma_f64_16x16x4f64(val, val, g4, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = ek + 4 * r;
+        if (row < 9 && ec < 9) red[wave * 81 + row * 9 + ec] = g4[r];
+    }
+    __syncthreads();
+    if (threadIdx.x < 81) {
+        double sacc = 0.0;
+        for (int wv = 0; wv < MT / 64; ++wv) sacc += red[wv * 81 + threadIdx.x];
+        s.pgram[(int64_t)blockIdx.x * 81 + threadIdx.x] = sacc;
+    }
+}
+
+__device__ bool cholesky_solve8(const double* gram /* [81] */, float* sol_out) {
+    double L[8][8], rhs[8];
+    for (int i = 0; i < 8; ++i) {
+        for (int j = 0; j <= i; ++j) {
+            double s = gram[i * 9 + j];
+            for (int k = 0; k < j; ++k) s -= L[i][k] * L[j][k];
+            if (i == j) {
+                if (!(s > 0.0)) return false;
+                L[i][i] = sqrt(s);
+            } else {
+                L[i][j] = s / L[j][j];
+            }
+        }
+    }
+    for (int i = 0; i < 8; ++i) {
+        double s = gram[i * 9 + 8];
+        for (int k = 0; k < i; ++k) s -= L[i][k] * rhs[k];
+        rhs[i] = s / L[i][i];
+    }
+    for (int i = 7; i >= 0; --i) {
+        double s = rhs[i];
+        for (int k = i + 1; k < 8; ++k) s -= L[k][i] * rhs[k];
+        rhs[i] = s / L[i][i];
+    }
+    for (int i = 0; i < 8; ++i) sol_out[i] = (float)rhs[i];
+    return true;
+}
+
+__device__ void denormalise(const float* sol, float s1, float t1x, float t1y, float s2, float t2x, float t2y, float* Hout) {
+    // H = T2^-1 * Hn * T1, then H / (h33 + 1e-8)   (least_squares_H.py:204-209, 340-345)
+    const double hn[9] = {sol[0], sol[1], sol[2], sol[3], sol[4], sol[5], sol[6], sol[7], 1.0};
+    const double T1[9] = {s1, 0, t1x, 0, s1, t1y, 0, 0, 1};
+    const double i2 = 1.0 / (double)s2;
+    const double T2i[9] = {i2, 0, -(double)t2x * i2, 0, i2, -(double)t2y * i2, 0, 0, 1};
+    double tmp[9], hh[9];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+            double s = 0;
+            for (int k = 0; k < 3; ++k) s += hn[r * 3 + k] * T1[k * 3 + c];
+            tmp[r * 3 + c] = s;
+        }
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+            double s = 0;
+            for (int k = 0; k < 3; ++k) s += T2i[r * 3 + k] * tmp[k * 3 + c];
+            hh[r * 3 + c] = s;
+        }
+    const double den = hh[8] + 1e-8;
+    for (int i = 0; i < 9; ++i) Hout[i] = (float)(hh[i] / den);
+}
+
+// one workgroup: reduce the partial Gram matrices (fixed order), solve, publish sol (and H / status)
+__global__ __launch_bounds__(128) void hfit_solve_kernel(int n_max, const int* __restrict__ count, int groups, void* ws,
+                                                         float* __restrict__ Hout, int* __restrict__ status) {
+    __shared__ double gram[81];
+    const MWs s = mws_layout(ws);
+    const int n = fit_count(count, n_max);
+    if (n < 4) {
+        if (threadIdx.x == 0) {
+            status[0] = 1;
+            for (int i = 0; i < 9; ++i) Hout[i] = nanf("");
+        }
+        return;
+    }
+    if (threadIdx.x < 81) {
+        double t = 0.0;
+        for (int g = 0; g < groups; ++g) t += s.pgram[(int64_t)g * 81 + threadIdx.x];
+        gram[threadIdx.x] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (status[0] == 2) return;                       // an earlier solve of this fit was singular
+        float sol[8];
+        if (!cholesky_solve8(gram, sol)) {
+            status[0] = 2;
+            for (int i = 0; i < 9; ++i) Hout[i] = nanf("");
+            return;
+        }
+        for (int i = 0; i < 8; ++i) s.sol[i] = sol[i];
+        denormalise(sol, s.norm[0], s.norm[1], s.norm[2], s.norm[3], s.norm[4], s.norm[5], Hout);
+        status[0] = 0;
+    }
+}
+
+// res[2i], res[2i+1] = rows of (A x - b) for the weighted (not re-weighted) system, least_squares_H.py:334
+__global__ __launch_bounds__(MT) void hfit_resid_kernel(const float* __restrict__ pa, const float* __restrict__ pb,
+                                                        const float* __restrict__ w, int n_max,
+                                                        const int* __restrict__ count, const void* ws,
+                                                        float* __restrict__ res) {
+    const MWs s = mws_layout(const_cast<void*>(ws));
+    const int n = fit_count(count, n_max);
+    const int64_t i = (int64_t)blockIdx.x * MT + threadIdx.x;
+    if (i >= n) return;
+    const float s1 = s.norm[0], t1x = s.norm[1], t1y = s.norm[2], s2 = s.norm[3], t2x = s.norm[4], t2y = s.norm[5];
+    const float2 a = ((const float2*)pa)[i], b = ((const float2*)pb)[i];
+    float rx[9], ry[9];
+    build_rows(s1 * a.x + t1x, s1 * a.y + t1y, s2 * b.x + t2x, s2 * b.y + t2y, (w != nullptr) ? w[i] : 1.f, rx, ry);
+    float resx = -rx[8], resy = -ry[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        resx += rx[k] * s.sol[k];
+        resy += ry[k] * s.sol[k];
+    }
+    ((float2*)res)[i] = make_float2(resx, resy);
+}
+
 }  // namespace
 
+extern "C" int64_t woft_hfit_ws_bytes(void) { return (int64_t)MAXG * (4 + 2 + 81) * 8 + 16 * 4; }
+
 extern "C" int woft_hfit(const float* pa, const float* pb, const float* w, int32_t n_max, const int32_t* count,
-                         int32_t reweight, float huber_k, int32_t n_irls, float* Hout, int32_t* status, void* stream) {
+                         int32_t reweight, float huber_k, int32_t n_irls, void* ws, float* Hout, int32_t* status,
+                         void* stream) {
     if (!pa || !pb || !Hout || !status || n_max < 0 || reweight < 0 || reweight > 2 || n_irls < 0) return WOFT_EINVAL;
-    hipLaunchKernelGGL(hfit_kernel, dim3(1), dim3(HT), 0, (hipStream_t)stream, pa, pb, w, n_max, count, reweight,
-                       huber_k, n_irls + 1, Hout, status);
+    hipStream_t st = (hipStream_t)stream;
+    if (ws == nullptr || n_max <= WOFT_HFIT_SINGLE_MAX) {
+        hipLaunchKernelGGL(hfit_kernel, dim3(1), dim3(HT), 0, st, pa, pb, w, n_max, count, reweight, huber_k, n_irls + 1,
+                           Hout, status);
+        return woft_launch_status();
+    }
+    const int G = mws_groups(n_max);
+    (void)hipMemsetAsync(status, 0, sizeof(int32_t), st);
+    hipLaunchKernelGGL(hfit_sum_kernel, dim3(G), dim3(MT), 0, st, pa, pb, n_max, count, ws);
+    hipLaunchKernelGGL(hfit_dist_kernel, dim3(G), dim3(MT), 0, st, pa, pb, n_max, count, ws);
+    const int solves = (reweight != 0) ? n_irls + 1 : 1;     // without a loss every pass re-solves the same system
+    for (int it = 0; it < solves; ++it) {
+        hipLaunchKernelGGL(hfit_gram_kernel, dim3(G), dim3(MT), 0, st, pa, pb, w, n_max, count, (const float*)nullptr,
+                           reweight, huber_k, it > 0 ? 1 : 0, ws);
+        hipLaunchKernelGGL(hfit_solve_kernel, dim3(1), dim3(128), 0, st, n_max, count, G, ws, Hout, status);
+    }
+    return woft_launch_status();
+}
+
+extern "C" int woft_hfit_step(const float* pa, const float* pb, const float* w, int32_t n, const float* rew, int32_t first,
+                              void* ws, float* res, float* Hout, int32_t* status, void* stream) {
+    if (!pa || !pb || !ws || !Hout || !status || n < 0) return WOFT_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int G = mws_groups(n);
+    if (first) {
+        (void)hipMemsetAsync(status, 0, sizeof(int32_t), st);
+        hipLaunchKernelGGL(hfit_sum_kernel, dim3(G), dim3(MT), 0, st, pa, pb, n, (const int*)nullptr, ws);
+        hipLaunchKernelGGL(hfit_dist_kernel, dim3(G), dim3(MT), 0, st, pa, pb, n, (const int*)nullptr, ws);
+    }
+    hipLaunchKernelGGL(hfit_gram_kernel, dim3(G), dim3(MT), 0, st, pa, pb, w, n, (const int*)nullptr, rew, 0, 0.f, 0, ws);
+    hipLaunchKernelGGL(hfit_solve_kernel, dim3(1), dim3(128), 0, st, n, (const int*)nullptr, G, ws, Hout, status);
+    if (res != nullptr && n >= 4)
+        hipLaunchKernelGGL(hfit_resid_kernel, dim3((n + MT - 1) / MT), dim3(MT), 0, st, pa, pb, w, n, (const int*)nullptr,
+                           (const void*)ws, res);
     return woft_launch_status();
 }
 

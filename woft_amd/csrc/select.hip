@@ -3,7 +3,7 @@
 //  configs/YAOFT_single_control_repRAFT_sub500_noreliableinl_wLSq.py:31-53 `subsampler`).
 //
 // Reference semantics reproduced exactly:
-//   keep[i] = tmask[y_i][x_i]                                   (source pixel i = y_i * W + x_i inside the mask)
+//   keep[i] = tmask[y_i][x_i]                                   (source pixel i = y_i * gw + x_i inside the mask)
 //             and, when check_dst:  not (dx < 0 or dy < 0 or rint(dx) >= W or rint(dy) >= H)
 //                                   and (pwmask == NULL or pwmask[rint(dy)][rint(dx)])
 //   N = number kept; if n_draw == 0 or n_draw >= N: every kept correspondence is selected, else the
@@ -55,11 +55,41 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* total) {
     return base + inc - v;
 }
 
+// The correspondences live on the flow grid (gh x gw: the frame, or the frame cropped to a multiple of 8 with
+// padding_mode 'crop', optical_flow/raft.py:235-247); the masks have the frame's size (mh x mw).
+struct Geo {
+    int gh, gw, mh, mw;
+};
+
+__device__ __forceinline__ bool keep_flag(const float* __restrict__ dst, const uint8_t* __restrict__ tmask,
+                                          const uint8_t* __restrict__ pwmask, const Geo g, int check_dst, int64_t i,
+                                          int64_t n) {
+    const int64_t mi = (g.gw == g.mw) ? i : (i / g.gw) * g.mw + (i % g.gw);
+    bool keep = tmask[mi] != 0;
+    if (keep && check_dst) {
+        const float dx = dst[i], dy = dst[n + i];
+        // NaN compares false below; treat it as out of bounds explicitly
+        const bool oob = !(dx >= 0.f) || !(dy >= 0.f) || rintf(dx) >= (float)g.mw || rintf(dy) >= (float)g.mh;
+        keep = !oob;
+        if (keep && pwmask != nullptr) keep = pwmask[(int64_t)rintf(dy) * g.mw + (int64_t)rintf(dx)] != 0;
+    }
+    return keep;
+}
+
+// flags only (the tracker's generic path: the host compacts with the boolean mask, as the reference does)
+__global__ __launch_bounds__(256) void flags_kernel(const float* __restrict__ dst, const uint8_t* __restrict__ tmask,
+                                                    const uint8_t* __restrict__ pwmask, Geo g, int check_dst,
+                                                    uint8_t* __restrict__ flags) {
+    const int64_t n = (int64_t)g.gh * g.gw;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) flags[i] = keep_flag(dst, tmask, pwmask, g, check_dst, i, n) ? 1 : 0;
+}
+
 __global__ __launch_bounds__(256) void select_flags_kernel(const float* __restrict__ dst, const uint8_t* __restrict__ tmask,
-                                                           const uint8_t* __restrict__ pwmask, int h, int w,
+                                                           const uint8_t* __restrict__ pwmask, Geo g,
                                                            int check_dst, int* ws, int nb) {
     const Ws s = ws_layout(ws, nb);
-    const int64_t n = (int64_t)h * w;
+    const int64_t n = (int64_t)g.gh * g.gw;
     const int64_t i0 = (int64_t)blockIdx.x * CHUNK + threadIdx.x * 4;
     int cnt = 0;
     uint8_t f[4] = {0, 0, 0, 0};
@@ -67,15 +97,7 @@ __global__ __launch_bounds__(256) void select_flags_kernel(const float* __restri
     for (int e = 0; e < 4; ++e) {
         const int64_t i = i0 + e;
         if (i >= n) continue;
-        bool keep = tmask[i] != 0;
-        if (keep && check_dst) {
-            const float dx = dst[i], dy = dst[n + i];
-            // NaN compares false below; treat it as out of bounds explicitly
-            const bool oob = !(dx >= 0.f) || !(dy >= 0.f) || rintf(dx) >= (float)w || rintf(dy) >= (float)h;
-            keep = !oob;
-            if (keep && pwmask != nullptr) keep = pwmask[(int64_t)rintf(dy) * w + (int64_t)rintf(dx)] != 0;
-        }
-        f[e] = keep ? 1 : 0;
+        f[e] = keep_flag(dst, tmask, pwmask, g, check_dst, i, n) ? 1 : 0;
         cnt += f[e];
     }
     if (i0 < n) {
@@ -203,17 +225,30 @@ extern "C" int64_t woft_tc_select_ws_bytes(int64_t n) {
     return (4 + 2 * nb + MAX_DRAW) * 4 + ((n + 15) / 16) * 16;
 }
 
-extern "C" int woft_tc_select(const float* dst, const float* w, const uint8_t* tmask, const uint8_t* pwmask, int32_t h,
-                              int32_t wimg, int32_t check_dst, const float* sobol_u, int32_t n_draw, void* ws,
-                              float* pa, float* pb, float* wout, int32_t cap, int32_t* count, void* stream) {
-    if (!dst || !tmask || !ws || !pa || !pb || !count || h <= 0 || wimg <= 0 || cap <= 0) return WOFT_EINVAL;
+extern "C" int woft_tc_flags(const float* dst, const uint8_t* tmask, const uint8_t* pwmask, int32_t gh, int32_t gw,
+                             int32_t mh, int32_t mw, int32_t check_dst, uint8_t* flags, void* stream) {
+    if (!tmask || !flags || gh <= 0 || gw <= 0 || gh > mh || gw > mw || (check_dst && !dst)) return WOFT_EINVAL;
+    const int64_t n = (int64_t)gh * gw;
+    const Geo g = {gh, gw, mh, mw};
+    hipLaunchKernelGGL(flags_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dst, tmask,
+                       pwmask, g, check_dst, flags);
+    return woft_launch_status();
+}
+
+extern "C" int woft_tc_select(const float* dst, const float* w, const uint8_t* tmask, const uint8_t* pwmask, int32_t gh,
+                              int32_t gw, int32_t mh, int32_t mw, int32_t check_dst, const float* sobol_u,
+                              int32_t n_draw, void* ws, float* pa, float* pb, float* wout, int32_t cap, int32_t* count,
+                              void* stream) {
+    if (!dst || !tmask || !ws || !pa || !pb || !count || gh <= 0 || gw <= 0 || gh > mh || gw > mw || cap <= 0)
+        return WOFT_EINVAL;
     if (n_draw < 0 || n_draw > MAX_DRAW || (n_draw > 0 && !sobol_u)) return WOFT_EINVAL;
-    const int64_t n = (int64_t)h * wimg;
+    const int64_t n = (int64_t)gh * gw;
     const int nb = (int)((n + CHUNK - 1) / CHUNK);
+    const Geo g = {gh, gw, mh, mw};
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(select_flags_kernel, dim3(nb), dim3(256), 0, s, dst, tmask, pwmask, h, wimg, check_dst, (int*)ws, nb);
+    hipLaunchKernelGGL(select_flags_kernel, dim3(nb), dim3(256), 0, s, dst, tmask, pwmask, g, check_dst, (int*)ws, nb);
     hipLaunchKernelGGL(select_plan_kernel, dim3(1), dim3(1024), 0, s, (int*)ws, nb, sobol_u, n_draw, cap, count);
-    hipLaunchKernelGGL(select_gather_kernel, dim3(nb), dim3(256), 0, s, dst, w, h, wimg, (const int*)ws, nb, pa, pb,
+    hipLaunchKernelGGL(select_gather_kernel, dim3(nb), dim3(256), 0, s, dst, w, gh, gw, (const int*)ws, nb, pa, pb,
                        wout, cap);
     return woft_launch_status();
 }

@@ -151,6 +151,13 @@ class RaftEngine:
         self.q_inp = [ops.pack_conv(w_, b_, padding=pd, cin_layout=ctx) for w_, b_, pd in q_w]
         if weighted:
             w = "weight_head.net."
+            # the head's kernels are laid out for weight_head_structure [(128, 3)] * 3 (weighted_raft.py:318-345 with
+            # optical_flow/configs/v2_SNOB_large_g05_RAFT.py:16): 3x3 convs 5 -> 128 -> 128 -> 128, then 1x1 -> 1
+            want = {"0": (128, 5, 3, 3), "2": (128, 128, 3, 3), "4": (128, 128, 3, 3), "6": (1, 128, 1, 1)}
+            have = {k.split(".")[2]: tuple(v.shape) for k, v in sd.items() if k.startswith(w) and k.endswith(".weight")}
+            if have != want:
+                raise NotImplementedError(f"weight head layers {have}: the HIP path implements weight_head_structure "
+                                          f"[(128, 3)] * 3 = {want}")
             self.wh0 = ops.pack_conv(sd[w + "0.weight"], sd[w + "0.bias"], flat_cs=8)
             self.wh2 = ops.pack_conv(sd[w + "2.weight"], sd[w + "2.bias"])
             self.wh4 = ops.pack_conv(sd[w + "4.weight"], sd[w + "4.bias"])

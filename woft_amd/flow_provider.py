@@ -44,6 +44,9 @@ class RAFTWrapper:
         cp = config.class_params
         if cp.mask_estimation:
             raise NotImplementedError("mask_estimation (MaskHead) is unset in every shipped config")
+        if self.C.backbone_model:
+            raise NotImplementedError("backbone_model (a second checkpoint merged into the state-dict, raft.py:58-62) "
+                                      "is unset in every shipped RAFT config")
         if self.C.raft_type not in ("orig", "weighted"):
             raise ValueError(f"Unknown RAFT type {self.C.raft_type}")
         logger.info(f"Loading weights from: {self.C.model}")
@@ -60,7 +63,7 @@ class RAFTWrapper:
         # the reference's `alternate_corr` switch selects, corr.py:72-100).  Bit-identical results in the split-bf16
         # precisions, where "otf" is faster and needs no P x P buffer: it is the default there.
         self.corr = os.environ.get("WOFT_CORR") or getattr(self.C, "corr", None) or \
-            ("volume" if self.precision == "fp32" else "otf")
+            ("otf" if cp.alternate_corr or self.precision != "fp32" else "volume")
         if self.corr == "otf" and self.precision == "fp32":
             raise ValueError("alternate_corr / corr='otf' runs on the split-bf16 matrix-core path: set precision "
                              "'bf16x3' (fp32-emulating) or 'bf16'")
@@ -145,13 +148,13 @@ class RAFTWrapper:
                                                    torch.div(torch.arange(h * w, device="cuda"), w, rounding_mode="floor")]))
         return self._out[key]
 
-    def _cached_flow(self, src_img, identifier, mode, numpy_out, do_sigmoid):
+    def _cached_flow(self, src_img, identifier, mode, numpy_out, do_sigmoid, borrow=False):
         """utils/caching.py:53-59 wire format: <flow_cache_dir>/<dataset>/<sequence>/<i>-<i+1>.npz holding
         'half_flow' (2,H,W) and 'half_weights' (1,H,W) (any float dtype, cast to fp32); then the same
         post-processing as a computed flow (raft.py:152-195)."""
         dataset_name, seq_name, frame_i = identifier
         path = Path(self.C.flow_cache_dir) / dataset_name / seq_name / f"{frame_i}-{frame_i + 1}.npz"
-        data = np.load(path, allow_pickle=True)
+        data = np.load(path, allow_pickle=False)           # plain float arrays: nothing to unpickle
         flow = np.ascontiguousarray(data["half_flow"].astype(np.float32))
         wts = data["half_weights"].astype(np.float32)
         wts = np.ascontiguousarray(wts) if wts.size > 1 else None
@@ -167,29 +170,38 @@ class RAFTWrapper:
         _lib.check(lib.woft_flow_to_tc(_lib.ptr(o["flow"]), _lib.ptr(wl), h, w, _lib.ptr(o["dst"]),
                                        _lib.ptr(o["w"]) if wl is not None else None, int(bool(do_sigmoid)),
                                        _lib.stream_ptr()), "woft_flow_to_tc")
-        weights = o["w"] if wl is not None else None
+        return self._deliver(o, o["w"] if wl is not None else None, mode, h, w, numpy_out, borrow)
+
+    def _deliver(self, o, weights, mode, oh, ow, numpy_out, borrow):
+        """The caller's view of the outputs.  The kernels write into per-resolution buffers that the NEXT call at the
+        same size overwrites; like the reference, compute_flow hands out tensors of its own (device copies, a few
+        microseconds) unless the caller passes borrow=True and consumes the results before its next call (the
+        tracker does)."""
+        own = (lambda t: t) if borrow else (lambda t: t.clone())
+        host = lambda t: t.cpu().numpy()
         if mode == "flow":
-            wout = weights.reshape(1, h, w) if weights is not None else None
+            wts = weights.reshape(1, oh, ow) if weights is not None else None
             if numpy_out:
-                return o["flow"].cpu().numpy(), (wout.cpu().numpy() if wout is not None else None)
-            return o["flow"], wout
-        self.last_flow_shape = {"batch": 1, "delta": 2, "H": h, "W": w}
+                return host(o["flow"]), (host(wts) if wts is not None else None)
+            return own(o["flow"]), (own(wts) if wts is not None else None)
+        self.last_flow_shape = {"batch": 1, "delta": 2, "H": oh, "W": ow}
         if numpy_out:
-            return (o["src"].cpu().numpy(), o["dst"].cpu().numpy(), weights.cpu().numpy() if weights is not None else None)
-        return o["src"], o["dst"], weights
+            return host(o["src"]), host(o["dst"]), (host(weights) if weights is not None else None)
+        return o["src"], own(o["dst"]), (own(weights) if weights is not None else None)     # (src: constant grid)
 
     def compute_flow(self, src_img, dst_img, mode="TC", vis=False, src_img_identifier=None,
-                     numpy_out=False, do_sigmoid=False):
+                     numpy_out=False, do_sigmoid=False, borrow=False):
         """src_img / dst_img: (H, W, 3) uint8 BGR (numpy, or CUDA tensors already on the device).
         mode 'TC' -> (src_coords (2,HW) int64, dst_coords (2,HW) f32, weights (1,HW) f32 | None)
-        mode 'flow' -> (flow (2,H,W), weights (1,H,W) | None)."""
+        mode 'flow' -> (flow (2,H,W), weights (1,H,W) | None).
+        borrow (extension, default off): return the provider's own output buffers, valid until the next call."""
         assert mode in ["flow", "TC"]
         assert src_img.shape == dst_img.shape
         if src_img_identifier is not None:                 # pre-computed flow (raft.py:92-109)
             try:
-                return self._cached_flow(src_img, src_img_identifier, mode, numpy_out, do_sigmoid)
-            except Exception as ex:                        # the reference logs each distinct error once
-                key = (type(ex), str(ex))
+                return self._cached_flow(src_img, src_img_identifier, mode, numpy_out, do_sigmoid, borrow)
+            except (OSError, KeyError) as ex:              # no such file / no such array: compute the flow instead
+                key = (type(ex), str(ex))                  # (the reference logs each distinct error once)
                 if key not in self._cache_errors:
                     self._cache_errors.add(key)
                     logger.warning(f"no cached flow: {ex}")
@@ -203,6 +215,8 @@ class RAFTWrapper:
                 t = a if a.is_cuda else a.cuda(non_blocking=True)
             else:
                 t = torch.from_numpy(np.ascontiguousarray(a)).cuda(non_blocking=True)
+            if t.dtype != torch.uint8 or t.dim() != 3 or t.shape[2] != 3:
+                raise TypeError(f"compute_flow takes (H, W, 3) uint8 BGR images, got {tuple(t.shape)} {t.dtype}")
             if (lh, lw) != (H, W):
                 t = t[:lh, :lw].contiguous()
             return t.contiguous()
@@ -227,16 +241,4 @@ class RAFTWrapper:
         if self.C.weights_postprocessing_fn and weights is not None:
             # the reference applies it to the logits before the sigmoid (raft.py:152-159)
             raise NotImplementedError("weights_postprocessing_fn is None in every shipped config")
-        if mode == "flow":
-            flow = o["flow"]
-            wts = weights.reshape(1, oh, ow) if weights is not None else None
-            if numpy_out:
-                flow = flow.cpu().numpy()
-                wts = wts.cpu().numpy() if wts is not None else None
-            return flow, wts
-        self.last_flow_shape = {"batch": 1, "delta": 2, "H": oh, "W": ow}
-        src_coords, dst_coords = o["src"], o["dst"]
-        if numpy_out:
-            return (src_coords.cpu().numpy(), dst_coords.cpu().numpy(),
-                    weights.cpu().numpy() if weights is not None else None)
-        return src_coords, dst_coords, weights
+        return self._deliver(o, weights, mode, oh, ow, numpy_out, borrow)

@@ -1,6 +1,6 @@
 """Homography estimators with the reference's operator API
 (/root/reference/pytracking/utils/least_squares_H.py): same function names, argument meaning,
-return shapes and AssertionError behaviour; the arithmetic runs in the HIP fit kernel
+return shapes and AssertionError behaviour; the arithmetic runs in the HIP fit kernels
 (csrc/hfit.hip) on the device the points live on.
 """
 import numpy as np
@@ -39,6 +39,15 @@ def _check(points1, points2):
         raise AssertionError(points1.shape)
 
 
+def _operands(points1, points2, weights, b):
+    pa = points1[b].float().contiguous()
+    pb = points2[b].float().contiguous()
+    w = weights[b].float().reshape(-1).contiguous() if weights is not None else None
+    if w is not None and w.numel() != pa.shape[0]:
+        raise AssertionError(weights.shape)
+    return pa, pb, w
+
+
 def _fit(points1, points2, weights, reweight, huber_k, n_irls):
     if not points1.is_cuda:
         raise AssertionError("correspondences should be on GPU")
@@ -46,10 +55,28 @@ def _fit(points1, points2, weights, reweight, huber_k, n_irls):
     out = torch.empty(B, 3, 3, dtype=torch.float32, device=points1.device)
     status = torch.zeros(B, dtype=torch.int32, device=points1.device)
     for b in range(B):
-        pa = points1[b].float().contiguous()
-        pb = points2[b].float().contiguous()
-        w = weights[b].float().contiguous() if weights is not None else None
+        pa, pb, w = _operands(points1, points2, weights, b)
         ops.hfit(pa, pb, w, out[b].view(9), status[b:b + 1], reweight=reweight, huber_k=huber_k, n_irls=n_irls)
+    return out
+
+
+def _fit_callable(points1, points2, weights, reweighting_fn, n_iter):
+    """IRLS with an arbitrary loss (least_squares_H.py:323-337): every pass is one device-side re-weighted solve
+    (woft_hfit_step) that also returns the residuals A x - b of its solution on the weighted system; the user's
+    callable sees them as a (1, 2N, 1) device tensor -- two consecutive rows per correspondence, the reference's
+    row order -- and its result, square-rooted, re-weights the rows of the next pass."""
+    B, N = points1.shape[0], points1.shape[1]
+    dev = points1.device
+    out = torch.empty(B, 3, 3, dtype=torch.float32, device=dev)
+    status = torch.zeros(B, dtype=torch.int32, device=dev)
+    res = torch.empty(2 * N, dtype=torch.float32, device=dev)
+    for b in range(B):
+        pa, pb, w = _operands(points1, points2, weights, b)
+        rew = None
+        for it in range(n_iter + 1):
+            ops.hfit_step(pa, pb, w, rew, it == 0, res, out[b].view(9), status[b:b + 1])
+            rew = torch.sqrt(reweighting_fn(res.view(1, 2 * N, 1))).to(dtype=torch.float32, device=dev)
+            rew = rew.expand(1, 2 * N, 1).reshape(-1).contiguous()
     return out
 
 
@@ -62,7 +89,9 @@ def find_homography_nonhomogeneous_QR(points1, points2, weights=None):
 
 def find_homography_IRLSq_QR(points1, points2, weights=None, reweighting_fn=IRLSq_L1, n_iter=5):
     """IRLS m-estimator (least_squares_H.py:280-346): n_iter + 1 solves, per-row re-weighting
-    sqrt(reweighting_fn(A x - b)) from the weighted algebraic residual."""
+    sqrt(reweighting_fn(A x - b)) from the weighted algebraic residual.  Losses built from IRLSq_L1 / IRLSq_Huber
+    (what the reference's configs use, configs/..._wIRLSq.py:24-31) run in ONE launch; any other callable is
+    driven pass by pass on device tensors (_fit_callable)."""
     _check(points1, points2)
     if not points1.is_cuda:
         raise AssertionError("correspondences should be on GPU")
@@ -70,12 +99,12 @@ def find_homography_IRLSq_QR(points1, points2, weights=None, reweighting_fn=IRLS
         kind = reweighting_fn(_Probe())
     except Exception:
         kind = None
-    if isinstance(kind, tuple) and kind[0] == "l1" and kind[2] == 1e-8:
-        return _fit(points1, points2, weights, 1, 0.0, n_iter)
-    if isinstance(kind, tuple) and kind[0] == "huber" and kind[2] == 1e-8:
-        return _fit(points1, points2, weights, 2, kind[1], n_iter)
-    raise NotImplementedError("find_homography_IRLSq_QR on the HIP path supports reweighting functions built from "
-                              "IRLSq_L1 / IRLSq_Huber (the ones the reference configs use)")
+    if isinstance(kind, tuple) and len(kind) == 3 and kind[2] == 1e-8:
+        if kind[0] == "l1":
+            return _fit(points1, points2, weights, 1, 0.0, n_iter)
+        if kind[0] == "huber":
+            return _fit(points1, points2, weights, 2, kind[1], n_iter)
+    return _fit_callable(points1, points2, weights, reweighting_fn, n_iter)
 
 
 def torch_proj_errors(GT_H, pts_A, pts_B):

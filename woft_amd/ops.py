@@ -473,18 +473,55 @@ def tc_select_ws(n):
     return torch.empty(int(_lib.load().woft_tc_select_ws_bytes(n)), dtype=torch.uint8, device=DEV)
 
 
-def tc_select(dst, w, tmask_u8, pwmask_u8, h, wimg, check_dst, sobol_u, ws, pa, pb, wout, count):
-    """Mask + compact + Sobol-subsample correspondences on the device (see csrc/select.hip)."""
+def tc_select(dst, w, tmask_u8, pwmask_u8, h, wimg, check_dst, sobol_u, ws, pa, pb, wout, count, grid=None):
+    """Mask + compact + Sobol-subsample correspondences on the device (see csrc/select.hip).  (h, wimg): size of the
+    masks (the frame); grid = (gh, gw): size of the flow grid when it differs (padding_mode 'crop')."""
     n_draw = 0 if sobol_u is None else sobol_u.numel()
-    check(_lib.load().woft_tc_select(ptr(dst), ptr(w), ptr(tmask_u8), ptr(pwmask_u8), h, wimg, int(check_dst),
+    gh, gw = grid or (h, wimg)
+    assert dst.numel() == 2 * gh * gw and tmask_u8.numel() == h * wimg and (w is None or w.numel() == gh * gw)
+    check(_lib.load().woft_tc_select(ptr(dst), ptr(w), ptr(tmask_u8), ptr(pwmask_u8), gh, gw, h, wimg, int(check_dst),
                                      ptr(sobol_u), n_draw, ptr(ws), ptr(pa), ptr(pb), ptr(wout), pa.shape[0],
                                      ptr(count), stream_ptr()), "woft_tc_select")
 
 
-def hfit(pa, pb, w, Hout, status, count=None, reweight=0, huber_k=1.0, n_irls=0):
+def tc_flags(dst, tmask_u8, pwmask_u8, h, wimg, check_dst, grid=None, out=None):
+    """The keep rule of tc_select alone -> bool tensor (gh*gw,) (woft_tc_flags)."""
+    gh, gw = grid or (h, wimg)
+    assert tmask_u8.numel() == h * wimg and (dst is None or dst.numel() == 2 * gh * gw)
+    flags = out if out is not None else torch.empty(gh * gw, dtype=torch.uint8, device=tmask_u8.device)
+    check(_lib.load().woft_tc_flags(ptr(dst), ptr(tmask_u8), ptr(pwmask_u8), gh, gw, h, wimg, int(check_dst),
+                                    ptr(flags), stream_ptr()), "woft_tc_flags")
+    return flags.view(torch.bool)
+
+
+_HFIT_WS = {}
+
+
+def hfit_ws(device=None):
+    """Scratch of the streaming fit (woft_hfit_ws_bytes), one per device, reused (stream-ordered)."""
+    dev = torch.device(device or DEV)
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    if key not in _HFIT_WS:
+        _HFIT_WS[key] = torch.empty(int(_lib.load().woft_hfit_ws_bytes()), dtype=torch.uint8, device=dev)
+    return _HFIT_WS[key]
+
+
+HFIT_SINGLE_MAX = 8192
+
+
+def hfit(pa, pb, w, Hout, status, count=None, reweight=0, huber_k=1.0, n_irls=0, ws=None):
     n = pa.shape[0]
+    if ws is None and n > HFIT_SINGLE_MAX:
+        ws = hfit_ws(pa.device)
     check(_lib.load().woft_hfit(ptr(pa), ptr(pb), ptr(w), n, ptr(count), reweight, float(huber_k), n_irls,
-                                ptr(Hout), ptr(status), stream_ptr()), "woft_hfit")
+                                ptr(ws), ptr(Hout), ptr(status), stream_ptr()), "woft_hfit")
+
+
+def hfit_step(pa, pb, w, rew, first, res, Hout, status, ws=None):
+    """One re-weighted solve with externally supplied row re-weights; residuals of its solution -> res."""
+    ws = ws if ws is not None else hfit_ws(pa.device)
+    check(_lib.load().woft_hfit_step(ptr(pa), ptr(pb), ptr(w), pa.shape[0], ptr(rew), int(bool(first)), ptr(ws),
+                                     ptr(res), ptr(Hout), ptr(status), stream_ptr()), "woft_hfit_step")
 
 
 def inlier_frac(pa, pb, Hm, frac, thr=5.0, count=None):

@@ -3,10 +3,21 @@ YAOFTrackerSingleControl (/root/reference/pytracking/tracker/YAOF_tracker_single
 TRK below) with the same constructor / init / track / set_fast_meta surface, the same config keys
 and the same `meta` fields, so reference-style config files and WOFT_demo.py drive it unchanged.
 
-Differences that are not visible in the results: frames live on the GPU (the two
-cv2.warpPerspective calls of TRK:89-95 are one HIP kernel), the template's feature / context
-tensors are computed once (the flow provider pins the template image), and there is a single
-device->host read per frame for the homography and one for the re-detection test.
+Organisation (this file's own, not the reference's): a frame is `_global_stage` (template ->
+pre-warped frame) and, when the re-detection test rejects its homography, `_local_stage`
+(frame t-1 -> frame t); both hand a dense correspondence field plus the two masks that prune it
+to ONE solver, `_solve`, which has two interchangeable back ends with identical results (tested
+bit for bit):
+
+  * device back end  -- configs built from woft_amd.presets (tagged callables): masking,
+    order-preserving compaction, Sobol selection, H fit and inlier test are HIP kernels
+    (csrc/select.hip, csrc/hfit.hip) with ONE device->host read per flow;
+  * callable back end -- any other reference-format config: the keep rule runs as the same
+    `select` kernel (woft_tc_flags), the surviving correspondences are handed to the config's own
+    subsampler / estimator / re-detection callables exactly as TRK:141-162,196-199 hands them.
+
+Frames live on the GPU (the two cv2.warpPerspective calls of TRK:89-95 are one HIP kernel) and the
+template's feature / context tensors are computed once (the flow provider pins the template).
 """
 import logging
 import os
@@ -20,6 +31,7 @@ from . import ops
 from .homography import compose_H
 
 logger = logging.getLogger(__name__)
+_EYE = np.eye(3)
 
 
 def _count_components(mask_bool):
@@ -29,22 +41,39 @@ def _count_components(mask_bool):
 
 
 def make_forward_compatible(subsampler_fn):
-    """3-argument subsamplers get a 4th (post-hoc weights) argument (TRK:344-362)."""
-    if len(signature(subsampler_fn).parameters) == 3:
-        def new_fn(coords_a, coords_b, weights, post_weights):
-            if post_weights is not None:
-                raise NotImplementedError("Using post-hoc weights post-processing with a subsampler that takes only 3 arguments")
-            return subsampler_fn(coords_a, coords_b, weights) + (None,)
-        if hasattr(subsampler_fn, "woft_spec"):
-            new_fn.woft_spec = subsampler_fn.woft_spec
-        return new_fn
-    return subsampler_fn
+    """Subsamplers written for (coords_a, coords_b, weights) are lifted to the 4-argument form that also carries the
+    post-hoc weights (TRK:344-362); a lifted one cannot forward post-hoc weights and says so."""
+    if len(signature(subsampler_fn).parameters) != 3:
+        return subsampler_fn
+
+    def lifted(coords_a, coords_b, weights, post_weights):
+        if post_weights is not None:
+            raise NotImplementedError("a 3-argument subsampler cannot carry post-hoc processed weights; "
+                                      "give it a 4th parameter")
+        return (*subsampler_fn(coords_a, coords_b, weights), None)
+    if hasattr(subsampler_fn, "woft_spec"):
+        lifted.woft_spec = subsampler_fn.woft_spec
+    return lifted
 
 
-def _to_gpu_u8(img):
+def _device_u8(img, copy=False):
+    """(H, W[, C]) uint8 image -> packed CUDA tensor (the kernels take raw pointers to packed uint8 rows)."""
     if isinstance(img, torch.Tensor):
-        return img if img.is_cuda else img.cuda()
-    return torch.from_numpy(np.ascontiguousarray(img)).cuda()
+        t = img if img.is_cuda else img.cuda()
+    else:
+        a = np.asarray(img)
+        if a.dtype != np.uint8:
+            raise TypeError(f"frames and masks must be uint8, got {a.dtype}")
+        return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    if t.dtype != torch.uint8:
+        raise TypeError(f"frames and masks must be uint8, got {t.dtype}")
+    if not t.is_contiguous():
+        return t.contiguous()
+    return t.clone() if copy and t is img else t
+
+
+class _Fit(SimpleNamespace):
+    """Result of one solve: H (3x3 float64, cur -> src) and, for the global stage, the re-detection verdict."""
 
 
 class YAOFTrackerSingleControl:
@@ -55,13 +84,12 @@ class YAOFTrackerSingleControl:
         self.flower = config.flow_config.of_class(config.flow_config)
         self.device = "cuda"
         self._fused = self._fused_specs()
+        self._replay = None
 
-    # ---- fused device-side path --------------------------------------------------------------
+    # ---- which solver back end ------------------------------------------------------------------
     def _fused_specs(self):
-        """When the config's estimator / subsampler / re-detection callables are the tagged ones of
-        woft_amd.presets, masking + Sobol selection + H fit + inlier test run as HIP kernels with ONE
-        device->host read per flow (results identical to calling the callables).  Any other config takes
-        the generic path that calls them as the reference tracker does."""
+        """Parameters of the device back end when the config's estimator / subsampler / re-detection callables are
+        the tagged ones of woft_amd.presets, else None (callable back end)."""
         C = self.C
         if os.environ.get("WOFT_FUSED", "1") == "0":
             return None
@@ -82,264 +110,188 @@ class YAOFTrackerSingleControl:
                     min_frac=float(red[2]), n_draw=n_draw,
                     sobol_u=torch.from_numpy(sobol_points(n_draw).astype(np.float32)).cuda() if n_draw else None)
 
-    def _fused_buffers(self, h, w):
-        key = (h, w)
-        if getattr(self, "_fb_key", None) != key:
-            cap = 1024 if self._fused["n_draw"] else h * w
-            self._fb = dict(ws=ops.tc_select_ws(h * w), pa=torch.empty(cap, 2, device=self.device),
+    def _fused_buffers(self, n_grid):
+        if getattr(self, "_fb_key", None) != n_grid:
+            cap = 1024 if self._fused["n_draw"] else n_grid
+            self._fb = dict(ws=ops.tc_select_ws(n_grid), pa=torch.empty(cap, 2, device=self.device),
                             pb=torch.empty(cap, 2, device=self.device), w=torch.empty(cap, device=self.device),
-                            res=torch.zeros(16, dtype=torch.float32, device=self.device))
-            self._fb_key = key
+                            res=torch.zeros(16, dtype=torch.float32, device=self.device),
+                            fit_ws=ops.hfit_ws(self.device) if cap > ops.HFIT_SINGLE_MAX else None)
+            self._fb_key = n_grid
         return self._fb
 
-    def _fused_fit(self, dst, weights, tmask_u8, pwmask_u8, h, w, check_dst):
-        """-> (H 3x3 float64 mapping dst -> src, success flag, #kept, #selected)."""
-        F, b = self._fused, self._fused_buffers(h, w)
-        res = b["res"]
-        ires = res.view(torch.int32)
-        ops.tc_select(dst, weights, tmask_u8, pwmask_u8, h, w, check_dst, F["sobol_u"], b["ws"], b["pa"], b["pb"],
-                      b["w"], ires[12:14])
-        ops.hfit(b["pa"], b["pb"], b["w"], res[0:9], ires[10:11], count=ires[12:13], reweight=F["reweight"],
-                 huber_k=F["huber_k"], n_irls=F["n_irls"])
-        ops.inlier_frac(b["pa"], b["pb"], res[0:9], res[9:10], thr=F["thr"], count=ires[12:13])
-        host = res.cpu()                                             # the frame's single device->host read
-        ih = host.view(torch.int32)
-        status, n_sel, n_kept = int(ih[10]), int(ih[12]), int(ih[13])
-        if status == 1:
-            raise AssertionError(torch.Size([1, n_sel, 2]))          # least_squares_H.py:162 (fewer than 4 points)
-        Hm = host[0:9].numpy().astype(np.float64).reshape(3, 3)
-        return Hm, bool(float(host[9]) > F["min_frac"]), n_kept, n_sel
-
+    # ---- public surface (TRK:19-57) -----------------------------------------------------------------
     def init(self, img, mask, img_identifier=None):
-        if self.C.downscale_inputs:                                  # TRK:27-30
-            k = self.C.downscale_inputs
-            img = ops.resize_by_factor_u8(_to_gpu_u8(img), k)
-            mask = ops.resize_by_factor_u8(_to_gpu_u8(np.ascontiguousarray(mask) if not isinstance(mask, torch.Tensor)
-                                                      else mask), k)
+        k = self.C.downscale_inputs
+        if k:                                                        # TRK:27-30
+            img = ops.resize_by_factor_u8(_device_u8(img), k)
+            mask = ops.resize_by_factor_u8(_device_u8(mask), k)
             img_identifier = None
         mask_np = mask.cpu().numpy() if isinstance(mask, torch.Tensor) else np.asarray(mask)
+        inside = mask_np > 0
+        assert _count_components(inside) == 1                        # TRK:36-37 (single contour)
         self.template_img = img
-        self.template_mask = torch.from_numpy(mask_np > 0).to(self.device)
         self.np_template_mask = mask_np
-        self._template_mask_u8 = torch.from_numpy((mask_np > 0).astype(np.uint8) * 255).to(self.device)
-        assert _count_components(mask_np > 0) == 1                   # TRK:36-37 (single contour)
+        self.template_mask = torch.from_numpy(inside).to(self.device)
+        self._template_mask_u8 = torch.from_numpy(inside.astype(np.uint8) * 255).to(self.device)
         if hasattr(self.flower, "pin_source"):
             self.flower.pin_source(self.template_img)
             # opt-in (config key mask_weight_head = True): only correspondences that start inside the template mask
-            # survive _mask_coords (TRK:287-312), so the flow weights of the other template pixels are never read and
+            # survive the keep rule (TRK:287-312), so the flow weights of the other template pixels are never read and
             # the weight head can skip them -- identical tracks, ~25 % faster at a quarter-frame mask.  Default: the
             # head is evaluated on every pixel, as the reference's network does.
             if hasattr(self.flower, "pin_weight_region") and self.C.mask_weight_head:
-                self.flower.pin_weight_region(mask_np > 0)
-        self.prev_H2init = np.eye(3)
-        self.last_good_H2init = np.eye(3)
-        self.prev_img_identifier = img_identifier
-        self.prev_img = img
-        self.fast_forward = False
-        self.lost = False
-        self.N_lost = 0
+                self.flower.pin_weight_region(inside)
+        self._set_pose(_EYE.copy(), good=True)
+        self.prev_img, self.prev_img_identifier = img, img_identifier
+        self.lost, self.N_lost = False, 0
+        self._replay = None
 
     def set_fast_meta(self, meta):
-        self.fast_forward = True
-        self.fast_forward_H2init = meta.estim_H_current2template
-        self.fast_forward_meta = meta
+        """Next track() call replays a stored result instead of computing flow (TRK:49-55)."""
         if self.C.downscale_inputs:
             raise NotImplementedError("Fastforward not compatible with input downscaling yet.")
+        self._replay = meta
+
+    @property
+    def fast_forward(self):
+        return self._replay is not None
 
     def track(self, input_img, debug=False, img_identifier=None):
-        meta = SimpleNamespace()
         if self.C.downscale_inputs:                                  # TRK:60-61
-            input_img = ops.resize_by_factor_u8(_to_gpu_u8(input_img), self.C.downscale_inputs)
-        if self.fast_forward:                                        # TRK:63-76
-            H_cur2init = self.fast_forward_H2init
-            meta = self.fast_forward_meta
-            self.last_good_H2init = H_cur2init
+            input_img = ops.resize_by_factor_u8(_device_u8(input_img), self.C.downscale_inputs)
+        if self._replay is not None:                                 # TRK:63-76
+            meta, self._replay = self._replay, None
+            H_cur2init = meta.estim_H_current2template
             self.lost, self.N_lost = False, 0
+            self.prev_H2init = self.last_good_H2init = H_cur2init
+            self.prev_img = input_img.clone() if isinstance(input_img, torch.Tensor) else np.array(input_img)
             self.prev_img_identifier = img_identifier
-            self.prev_img = input_img
-            self.prev_H2init = H_cur2init
-            self.fast_forward = False
             return H_cur2init, meta
 
+        meta = SimpleNamespace()
         if self.C.no_prewarp_after_N and self.N_lost > self.C.no_prewarp_after_N:
-            self.last_good_H2init = np.eye(3)
+            self.last_good_H2init = _EYE.copy()                      # TRK:78-79
         meta.last_good_H2init = self.last_good_H2init.copy()
+        frame = _device_u8(input_img, copy=True)                     # (becomes prev_img: the reference keeps a copy)
 
-        # 'global' flow: template -> current frame pre-warped by the last good homography (TRK:85-102)
         prewarp_H = self.last_good_H2init
-        frame = _to_gpu_u8(input_img)
-        Hh, Ww = frame.shape[:2]
-        valid = None
-        if np.array_equal(prewarp_H, np.eye(3)):
-            prewarped, pw_mask = frame, None                         # identity warp: same image, mask all-true
-        else:
-            prewarped = torch.empty_like(frame)
-            valid = torch.empty(Hh, Ww, dtype=torch.uint8, device=self.device)
-            ops.warp_perspective_u8(frame, prewarp_H, prewarped, valid)
-            pw_mask = valid > 0
-        template_coords, cur_pw_coords, weights = self.flower.compute_flow(
-            self.template_img, prewarped, mode="TC", vis=False, do_sigmoid=True)
-        if self._fused is not None:
-            return self._track_fused(meta, frame, prewarp_H, cur_pw_coords, weights,
-                                     None if pw_mask is None or self.C.do_not_mask_TCs_by_prewarped else valid,
-                                     img_identifier)
-        post_hoc_weights = None
-        if self.C.post_hoc_weights_postprocessing_fn:
-            post_hoc_weights = self.flower.postprocess_weights(weights.clone(), self.C.post_hoc_weights_postprocessing_fn)
-        if pw_mask is None:
-            pw_mask = torch.ones(Hh, Ww, dtype=torch.bool, device=self.device)
-        template_coords, cur_pw_coords, weights, post_hoc_weights, _ = self._mask_coords(
-            template_coords, cur_pw_coords, weights, post_hoc_weights, pw_mask,
-            do_pw_mask=not self.C.do_not_mask_TCs_by_prewarped)
-        template_coords = template_coords.float()
-        if self.C.subsampler_fn:
-            template_coords, cur_pw_coords, weights, post_hoc_weights = self.C.subsampler_fn(
-                template_coords, cur_pw_coords, weights, post_hoc_weights)
-
-        H_prewarped2init = self.C.H_estimator(cur_pw_coords.t()[None], template_coords.t()[None], weights).float()
-        np_H_prewarped2init = H_prewarped2init.detach().cpu().numpy()[0].astype(np.float64)
-        H_global_cur2init = compose_H(prewarp_H, np_H_prewarped2init)
-        meta.H_global_cur2init = H_global_cur2init.copy()
-        global_H_success = bool(self.C.redet_success_fn(
-            H_prewarped2init, template_coords, cur_pw_coords,
-            post_hoc_weights if post_hoc_weights is not None else weights))
-        logger.debug(f"global_H_success: {global_H_success}")
-
-        if global_H_success:
-            H_cur2init = H_global_cur2init
+        fit = self._global_stage(frame, prewarp_H)
+        H_global = compose_H(prewarp_H, fit.H)
+        meta.H_global_cur2init = H_global.copy()
+        logger.debug(f"global_H_success: {fit.success}")
+        if fit.success:
             self.lost, self.N_lost = False, 0
+            H_cur2init = H_global
         else:
-            self.lost = True
-            self.N_lost += 1
-            if self.C.no_local_H:
-                H_cur2init = H_global_cur2init
-            else:                                                    # local flow t-1 -> t (TRK:178-207)
-                prev_coords, cur_coords, weights = self.flower.compute_flow(
-                    self.prev_img, frame, mode="TC", src_img_identifier=None, do_sigmoid=True,
-                    numpy_out=bool(self.C.flow_numpy_out))
-                post_hoc_weights = None
-                if self.C.post_hoc_weights_postprocessing_fn:
-                    post_hoc_weights = self.flower.postprocess_weights(weights.clone(), self.C.post_hoc_weights_postprocessing_fn)
-                prev_coords, cur_coords, weights, post_hoc_weights = self._mask_coords_flow(
-                    prev_coords, cur_coords, weights, post_hoc_weights)
-                if self.C.subsampler_fn:
-                    prev_coords, cur_coords, weights, post_hoc_weights = self.C.subsampler_fn(
-                        prev_coords, cur_coords, weights, post_hoc_weights)
-                try:
-                    H_flow = self.C.H_estimator(cur_coords.t()[None], prev_coords.float().t()[None], weights)
-                    H_flow = H_flow.detach().cpu().numpy()[0].astype(np.float64)
-                    if not np.all(np.isfinite(H_flow)):
-                        raise FloatingPointError("singular homography system")
-                    H_local_cur2init = compose_H(H_flow, self.prev_H2init)
-                except Exception:
-                    logger.warning("local flow RANSAC failed")
-                    H_local_cur2init = self.prev_H2init
-                meta.H_local_cur2init = H_local_cur2init.copy()
-                H_cur2init = H_local_cur2init
-
+            self.lost, self.N_lost = True, self.N_lost + 1
+            H_cur2init = H_global
+            if not self.C.no_local_H:
+                H_cur2init = meta.H_local_cur2init = self._local_stage(frame)
         if debug:
             logger.debug("debug visualisation (TRK:210-264) needs the OpenCV GUI and is not part of the HIP path")
 
-        self.prev_img_identifier = img_identifier
-        self.prev_img = frame
-        self.prev_H2init = H_cur2init.copy()
-        if not self.lost:
-            self.last_good_H2init = H_cur2init.copy()
-        meta.lost = self.lost
-        meta.N_lost = self.N_lost
-        meta.global_H_success = global_H_success
-        if self.C.downscale_inputs:                                  # TRK:280-283
-            k = self.C.downscale_inputs
+        self.prev_img, self.prev_img_identifier = frame, img_identifier
+        self._set_pose(H_cur2init.copy(), good=not self.lost)
+        meta.lost, meta.N_lost, meta.global_H_success = self.lost, self.N_lost, fit.success
+        k = self.C.downscale_inputs
+        if k:                                                        # TRK:280-283
             H_cur2init = compose_H(np.diag([1.0 / k, 1.0 / k, 1.0]), H_cur2init, np.diag([float(k), float(k), 1.0]))
         return H_cur2init, meta
 
-    def _track_fused(self, meta, frame, prewarp_H, cur_pw_coords, weights, pw_valid_u8, img_identifier):
-        """TRK:134-278 with masking / selection / fit / inlier test on the device."""
-        Hh, Ww = frame.shape[:2]
-        Hpw, success, _, _ = self._fused_fit(cur_pw_coords, weights, self._template_mask_u8, pw_valid_u8, Hh, Ww, 1)
-        H_global_cur2init = compose_H(prewarp_H, Hpw)
-        meta.H_global_cur2init = H_global_cur2init.copy()
-        if success:
-            H_cur2init = H_global_cur2init
-            self.lost, self.N_lost = False, 0
-        else:
-            self.lost = True
-            self.N_lost += 1
-            if self.C.no_local_H:
-                H_cur2init = H_global_cur2init
-            else:
-                _, cur_coords, weights = self.flower.compute_flow(self.prev_img, frame, mode="TC",
-                                                                  src_img_identifier=None, do_sigmoid=True)
-                if np.array_equal(self.prev_H2init, np.eye(3)):
-                    prev_mask_u8 = self._template_mask_u8
-                else:
-                    prev_mask_u8 = torch.empty_like(self._template_mask_u8)
-                    ops.warp_perspective_u8(self._template_mask_u8, np.linalg.inv(self.prev_H2init), prev_mask_u8,
-                                            None, nearest=True)
-                try:
-                    H_flow, _, _, _ = self._fused_fit(cur_coords, weights, prev_mask_u8, None, Hh, Ww, 0)
-                    if not np.all(np.isfinite(H_flow)):
-                        raise FloatingPointError("singular homography system")
-                    H_local_cur2init = compose_H(H_flow, self.prev_H2init)
-                except Exception:
-                    logger.warning("local flow RANSAC failed")
-                    H_local_cur2init = self.prev_H2init
-                meta.H_local_cur2init = H_local_cur2init.copy()
-                H_cur2init = H_local_cur2init
-        self.prev_img_identifier = img_identifier
-        self.prev_img = frame
-        self.prev_H2init = H_cur2init.copy()
-        if not self.lost:
-            self.last_good_H2init = H_cur2init.copy()
-        meta.lost = self.lost
-        meta.N_lost = self.N_lost
-        meta.global_H_success = success
-        if self.C.downscale_inputs:
-            k = self.C.downscale_inputs
-            H_cur2init = compose_H(np.diag([1.0 / k, 1.0 / k, 1.0]), H_cur2init, np.diag([float(k), float(k), 1.0]))
-        return H_cur2init, meta
+    def _set_pose(self, H, good):
+        self.prev_H2init = H
+        if good:
+            self.last_good_H2init = H.copy()
 
-    def _mask_coords(self, template_coords, cur_coords, weights, post_weights, pw_mask=None, do_pw_mask=True):
-        """TRK:287-312."""
-        in_template_mask = self.template_mask[template_coords[1, :], template_coords[0, :]]
-        if pw_mask is not None:
-            H, W = pw_mask.shape
-            cur_coords_int = cur_coords.round().long()
-            cur_coords_oob = torch.logical_or(
-                torch.any(cur_coords < 0, dim=0),
-                torch.logical_or(cur_coords_int[0, :] >= W, cur_coords_int[1, :] >= H))
-            in_pw_mask = ~cur_coords_oob
-            if do_pw_mask:
-                cx = cur_coords_int[0].clamp(0, W - 1)
-                cy = cur_coords_int[1].clamp(0, H - 1)
-                in_pw_mask = in_pw_mask & pw_mask[cy, cx]
-            in_mask = torch.logical_and(in_template_mask, in_pw_mask)
-        else:
-            in_mask = in_template_mask
-        template_coords = template_coords[:, in_mask]
-        cur_coords = cur_coords[:, in_mask]
-        if weights is not None:
-            weights = weights[:, in_mask]
-        if post_weights is not None:
-            post_weights = post_weights[:, in_mask]
-        return template_coords, cur_coords, weights, post_weights, in_mask
+    # ---- the two flow stages ------------------------------------------------------------------------
+    def _flow(self, src, dst):
+        """-> (grid coords (2, n) int64, target coords (2, n) f32, weights (1, n) f32 | None, (gh, gw)); borrowed
+        buffers of the provider: consumed before the next flow."""
+        kw = {"borrow": True} if hasattr(self.flower, "pin_source") else {}
+        src_xy, dst_xy, w = self.flower.compute_flow(src, dst, mode="TC", vis=False, src_img_identifier=None,
+                                                     do_sigmoid=True, **kw)
+        s = getattr(self.flower, "last_flow_shape", None)
+        return src_xy, dst_xy, w, ((s["H"], s["W"]) if s else None)
 
-    def _mask_coords_flow(self, prev_coords, cur_coords, weights, post_weights):
-        """TRK:314-327: template mask carried to frame t-1 by inv(prev_H2init), nearest neighbour."""
-        Hm = np.linalg.inv(self.prev_H2init)
-        if np.array_equal(self.prev_H2init, np.eye(3)):
-            prev_mask = self.template_mask
+    def _global_stage(self, frame, prewarp_H):
+        """Template -> frame pre-warped by the last good homography (TRK:85-162).  Kept: correspondences that start
+        in the template mask, land inside the frame and (unless do_not_mask_TCs_by_prewarped) on a pixel the pre-warp
+        actually filled."""
+        valid = None
+        if np.array_equal(prewarp_H, _EYE):
+            prewarped = frame                                        # identity warp: same image, every pixel filled
         else:
-            warped = torch.empty_like(self._template_mask_u8)
-            ops.warp_perspective_u8(self._template_mask_u8, Hm, warped, None, nearest=True)
-            prev_mask = warped > 0
-        if not isinstance(prev_coords, torch.Tensor):
-            prev_mask = prev_mask.cpu().numpy()
-        in_mask = prev_mask[prev_coords[1, :], prev_coords[0, :]]
-        prev_coords = prev_coords[:, in_mask]
-        cur_coords = cur_coords[:, in_mask]
-        if weights is not None:
-            weights = weights[:, in_mask]
-        if post_weights is not None:
-            post_weights = post_weights[:, in_mask]
-        return prev_coords, cur_coords, weights, post_weights
+            prewarped = torch.empty_like(frame)
+            valid = torch.empty(frame.shape[:2], dtype=torch.uint8, device=self.device)
+            ops.warp_perspective_u8(frame, prewarp_H, prewarped, valid)
+        if self.C.do_not_mask_TCs_by_prewarped:
+            valid = None
+        src_xy, dst_xy, w, grid = self._flow(self.template_img, prewarped)
+        return self._solve(src_xy, dst_xy, w, grid, frame.shape[:2], self._template_mask_u8, valid, bounds=True,
+                           judge=True)
+
+    def _local_stage(self, frame):
+        """Frame t-1 -> frame t, chained onto the previous pose (TRK:171-207).  Kept: correspondences that start in
+        the template mask carried to frame t-1 (nearest-neighbour warp by inv(prev_H2init), TRK:314-327).  A failed
+        fit keeps the previous pose."""
+        src_xy, dst_xy, w, grid = self._flow(self.prev_img, frame)
+        if np.array_equal(self.prev_H2init, _EYE):
+            prev_mask = self._template_mask_u8
+        else:
+            prev_mask = torch.empty_like(self._template_mask_u8)
+            ops.warp_perspective_u8(self._template_mask_u8, np.linalg.inv(self.prev_H2init), prev_mask, None,
+                                    nearest=True)
+        try:
+            fit = self._solve(src_xy, dst_xy, w, grid, frame.shape[:2], prev_mask, None, bounds=False, judge=False)
+            if not np.all(np.isfinite(fit.H)):
+                raise FloatingPointError("singular homography system")
+            return compose_H(fit.H, self.prev_H2init)
+        except Exception as ex:
+            logger.warning(f"frame-to-frame homography failed ({type(ex).__name__}): pose of the previous frame kept")
+            return self.prev_H2init
+
+    # ---- the solver ---------------------------------------------------------------------------------
+    def _solve(self, src_xy, dst_xy, w, grid, frame_hw, src_mask_u8, dst_valid_u8, bounds, judge):
+        """Prune the dense field and fit H (target -> source coordinates); judge: also run the re-detection test."""
+        Hh, Ww = frame_hw
+        grid = grid or (Hh, Ww)
+        if self._fused is not None:
+            return self._solve_device(dst_xy, w, grid, (Hh, Ww), src_mask_u8, dst_valid_u8, bounds)
+        return self._solve_callables(src_xy, dst_xy, w, grid, (Hh, Ww), src_mask_u8, dst_valid_u8, bounds, judge)
+
+    def _solve_device(self, dst_xy, w, grid, frame_hw, src_mask_u8, dst_valid_u8, bounds):
+        F, b = self._fused, self._fused_buffers(grid[0] * grid[1])
+        res = b["res"]
+        ires = res.view(torch.int32)
+        ops.tc_select(dst_xy, w, src_mask_u8, dst_valid_u8, frame_hw[0], frame_hw[1], bounds, F["sobol_u"], b["ws"],
+                      b["pa"], b["pb"], b["w"], ires[12:14], grid=grid)
+        ops.hfit(b["pa"], b["pb"], b["w"], res[0:9], ires[10:11], count=ires[12:13], reweight=F["reweight"],
+                 huber_k=F["huber_k"], n_irls=F["n_irls"], ws=b["fit_ws"])
+        ops.inlier_frac(b["pa"], b["pb"], res[0:9], res[9:10], thr=F["thr"], count=ires[12:13])
+        host = res.cpu()                                             # the flow's single device->host read
+        ih = host.view(torch.int32)
+        if int(ih[10]) == 1:
+            raise AssertionError(torch.Size([1, int(ih[12]), 2]))    # least_squares_H.py:162 (fewer than 4 points)
+        return _Fit(H=host[0:9].numpy().astype(np.float64).reshape(3, 3), success=bool(float(host[9]) > F["min_frac"]))
+
+    def _solve_callables(self, src_xy, dst_xy, w, grid, frame_hw, src_mask_u8, dst_valid_u8, bounds, judge):
+        C = self.C
+        post = None
+        if C.post_hoc_weights_postprocessing_fn:
+            post = self.flower.postprocess_weights(w.clone(), C.post_hoc_weights_postprocessing_fn)
+        keep = ops.tc_flags(dst_xy if bounds else None, src_mask_u8, dst_valid_u8, frame_hw[0], frame_hw[1], bounds,
+                            grid=grid)
+        pick = lambda t: None if t is None else t[:, keep]
+        src_xy, dst_xy, w, post = pick(src_xy).float(), pick(dst_xy), pick(w), pick(post)
+        if C.flow_numpy_out and not judge:                           # (the reference asks numpy of the local flow only)
+            to_np = lambda t: None if t is None else t.cpu().numpy()
+            src_xy, dst_xy, w, post = to_np(src_xy), to_np(dst_xy), to_np(w), to_np(post)
+        if C.subsampler_fn:
+            src_xy, dst_xy, w, post = C.subsampler_fn(src_xy, dst_xy, w, post)
+        H = C.H_estimator(dst_xy.T[None], src_xy.T[None], w)
+        H = H.float() if isinstance(H, torch.Tensor) else torch.as_tensor(np.asarray(H)).float()
+        fit = _Fit(H=H.detach().cpu().numpy()[0].astype(np.float64), success=None)
+        if judge:
+            fit.success = bool(C.redet_success_fn(H, src_xy, dst_xy, post if post is not None else w))
+        return fit
