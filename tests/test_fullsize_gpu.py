@@ -136,9 +136,11 @@ def test_hfit_recovers_known_homography_fullres(ops):
     assert float(fr.item()) == 1.0
 
 
-def test_flow_of_identical_frames_is_deterministic_fullsize():
+@pytest.mark.parametrize("precision,corr,iters", [("bf16x3", "otf", 2), ("bf16", "otf", 32), ("bf16", "volume", 32)])
+def test_flow_of_identical_frames_is_deterministic_fullsize(precision, corr, iters):
     """1080p end to end: two runs of the same pair are bit-identical (no atomics / no order dependence on the
-    path), the pinned-template cache gives the same answer as a cold call, and the int64 source grid is exact."""
+    path), the pinned-template cache gives the same answer as a cold call, and the int64 source grid is exact.
+    ("bf16", 32 iterations: BASELINE config 3's operating point at its full size, both correlation modes.)"""
     from woft_amd import synth
     from woft_amd.config import Config
     from woft_amd.flow_provider import RAFTWrapper
@@ -146,8 +148,9 @@ def test_flow_of_identical_frames_is_deterministic_fullsize():
     c = Config()
     c.of_class, c.raft_type, c.class_params = RAFTWrapper, "weighted", Config()
     c.class_params.small = False
-    c.model, c.iters, c.padding_mode, c.precision = synth.make_state_dict(seed=7), 2, "nopad", "bf16x3"
+    c.model, c.iters, c.padding_mode, c.precision, c.corr = synth.make_state_dict(seed=7), iters, "nopad", precision, corr
     fl = RAFTWrapper(c)
+    assert fl.engine.precision == precision and fl.engine.corr == corr
     t = synth.make_template(H, W, seq_id=9)
     f = np.roll(t, (3, -5), axis=(0, 1)).copy()
     s1, d1, w1 = fl.compute_flow(t, f, mode="TC", do_sigmoid=True)
