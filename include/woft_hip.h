@@ -118,6 +118,12 @@ typedef struct woft_conv_params {
                                   k = (3 ky + kx) * 5 + ci, zero for k >= 45                                */
     const float* wh0_bias;     /* [128]                                                                   */
     const int32_t* wh0_index;  /* optional: window i of this launch is source pixel wh0_index[i]          */
+    /* halo == 8 (8x16-pixel tiles, split-bf16 precisions, stride 1, 3x3 / 1x5 / 5x1, no in_norm): the weight operand is
+       streamed global -> registers instead of through LDS; it is read from wgt_frag, the same weights in MFMA-fragment
+       order: [cout_pad / 32 bands][cin_pad / 32 chunks][taps][planes: hi (, lo)][2 k halves][64 lanes][8] bf16, lane L
+       element e of k half s = W[32 band + L % 32][tap][32 chunk + 8 (2 s + L / 32) + e].  tile_n 128: one wave per
+       32-column band and all 128 rows; tile_n 64: 2 x 2 waves.                                                   */
+    const void* wgt_frag;
 } woft_conv_params;
 
 int woft_conv2d(const woft_conv_params* p, void* stream);

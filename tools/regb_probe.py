@@ -1,0 +1,61 @@
+"""One update-block layer, one kernel variant, a few launches -- the target of PMC passes.
+  python tools/regb_probe.py <case: zr|fh1|q> <halo: 0 (default choice) | 8> [tile_n]"""
+import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import torch
+
+from woft_amd import ops, _lib
+
+case, halo = sys.argv[1], int(sys.argv[2])
+tn = int(sys.argv[3]) if len(sys.argv) > 3 else None
+prec = sys.argv[4] if len(sys.argv) > 4 else "bf16x3"
+hf, wf = 135, 240
+cin, x2c, cout, kh, kw = {"zr": (128, 128, 256, 1, 5), "q": (128, 128, 128, 5, 1), "fh1": (128, 0, 256, 3, 3),
+                          "c2": (256, 0, 192, 3, 3)}[case]
+wt = torch.randn(cout, cin + x2c, kh, kw) * 0.05
+pc = ops.pack_conv(wt, torch.randn(cout) * 0.1, padding=(kh // 2, kw // 2))
+x = ops.new_act(1, hf, wf, cin)
+x.t.normal_()
+x2 = None
+if x2c:
+    x2 = ops.new_act(1, hf, wf, x2c)
+    x2.t.normal_()
+out = ops.new_act(1, hf, wf, cout, cs=ops._round_up(cout, 4), zero=True)
+p = ops.conv_params(x, pc, out, x2=x2, c_split=cin if x2c else 0, epi=_lib.EPI_RELU, precision=prec,
+                    halo=halo or None, tiles=(128, tn) if tn else None)
+import os
+stamps = None
+if os.environ.get("STAMPS"):
+    stamps = torch.zeros(4096 * 16, dtype=torch.int64, device="cuda")
+    p.in_mean, p.in_rstd = 1, stamps.data_ptr()
+_lib.load().woft_set_tuning(3, int(os.environ.get("DYN_LDS", "0")))
+import time
+ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(12)]
+for _ in range(3):
+    ops.run_conv(p)
+for s_, e_ in ev:
+    s_.record(); ops.run_conv(p); e_.record()
+torch.cuda.synchronize()
+ts = sorted(s_.elapsed_time(e_) for s_, e_ in ev)
+print(f"median {ts[6]*1e3:.1f} us  (grid {p._m_tiles * (p.cout_pad // p.tile_n)})")
+for _ in range(0):
+    ops.run_conv(p)
+torch.cuda.synchronize()
+print("done", p.halo, p.tile_n)
+
+if stamps is not None:
+    import numpy as np
+    nb = p._m_tiles * (p.cout_pad // p.tile_n)
+    st = stamps.cpu().numpy().reshape(-1, 16)[:nb]
+    t0 = st[:, 0].min()
+    start, pro, end = st[:, 0] - t0, st[:, 1] - st[:, 0], st[:, 15] - t0
+    nch = p.cin_pad // 32
+    chunks = np.diff(st[:, 1:1 + nch], axis=1)
+    epi = st[:, 15] - st[:, 14]
+    print(f"kernel span {end.max()} ticks; WG start min/med/max {start.min()}/{int(np.median(start))}/{start.max()}; "
+          f"WG duration med {int(np.median(st[:,15]-st[:,0]))} max {int((st[:,15]-st[:,0]).max())}")
+    print(f"  first chunk (incl. prologue) med {int(np.median(pro))}; later chunks med {int(np.median(chunks))} "
+          f"p10 {int(np.percentile(chunks,10))} p90 {int(np.percentile(chunks,90))}; epilogue med {int(np.median(epi))}")
+    print(f"  ticks per us: {end.max() / (ts[6]*1e3):.1f}")

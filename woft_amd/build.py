@@ -11,7 +11,8 @@ LIBDIR = HERE / "lib"
 LIB = LIBDIR / "libwoft_hip.so"
 STAMP = LIBDIR / "libwoft_hip.stamp"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math", "-ffp-contract=off"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math", "-ffp-contract=off",
+         "-Wno-c++20-extensions"]
 
 
 def _sources():

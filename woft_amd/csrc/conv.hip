@@ -29,6 +29,7 @@
 
 #include "conv_common.h"
 #include "dma.h"
+#include "halo_map.h"
 
 namespace {
 
@@ -133,9 +134,6 @@ __global__ __launch_bounds__(256) void conv_mfma_f32_kernel(const woft_conv_para
 }
 
 // ---- split-bf16 kernel -------------------------------------------------------------------------
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-constexpr int LDB = 40;      // bf16 tiles: elements per row (80 B: 16-B aligned, conflict-free b128 reads)
 
 // Per-tap ("gather") implicit GEMM on split-bf16 operands: any stride / tap shape / flat packing, 1x1 included.
 // A rows (fp32, NHWC) are fetched one K step ahead into registers, split into bf16 hi / lo and written to the idle
@@ -343,82 +341,6 @@ __global__ __launch_bounds__(256) void conv_mfma_bf16_kernel(const woft_conv_par
     // the operand stages are dead: reuse them
     woft::conv_epilogue<BM, BN>(p, acc, (float*)smem + wave * woft::STAGE_FLOATS, m0, n0, wm, wn, lane, M, m_tile);
 }
-
-// ---- which pixel of the TY x TX patch each MFMA tile row holds ----------------------------------
-// ds_read_b128 serves a wave in four groups of 16 lanes -- {0-3,12-15,20-27}, {4-11,16-19,28-31} and the same +32
-// -- one LDS cycle per group when the 16 addresses fall into 16 different 16-byte slots of a 256-byte line.  The
-// halo rows have an 80-byte pitch (5 slots), so two pixels collide iff their halo row indices are congruent
-// mod 16; a tap only adds a constant to all of them.  The row <-> pixel assignment is ours to choose, so it is
-// chosen per group:
-//   TX == 16: a group = the 16 pixels of ONE patch row (halo rows r .. r+15: all residues)          [tile_row_perm]
-//   9 x 9   : the 81 pixels are dealt by residue of (11 ty + tx) mod 16 -- no residue class has more than 6
-//             members, there are 6 groups -- so each group gets at most one pixel per residue             [kPerm9]
-// (rows without a pixel repeat another pixel of their group: same address = broadcast, and are never stored).
-__device__ __forceinline__ constexpr int tile_row_perm(int l) {          // lane (0..31) -> 16 * group + slot
-    return l < 4 ? l : l < 12 ? l + 12 : l < 16 ? l - 8 : l < 20 ? l + 8 : l < 28 ? l - 12 : l;
-}
-constexpr int lane_of_slot(int g, int t) {                               // inverse of tile_row_perm
-    return g == 0 ? (t < 4 ? t : t < 8 ? t + 8 : t + 12) : (t < 8 ? t + 4 : t < 12 ? t + 8 : t + 16);
-}
-struct Perm9 {
-    unsigned char v[96];                                                 // pixel index (0..80) | 0x80 if filler
-};
-constexpr Perm9 make_perm9() {
-    Perm9 t{};
-    for (int i = 0; i < 96; ++i) t.v[i] = 0xFF;
-    int cnt[16] = {};
-    for (int pix = 0; pix < 81; ++pix) {
-        const int c = ((pix / 9) * 11 + pix % 9) % 16;
-        const int k = cnt[c]++;                                          // group 0..5 = (tile k/2, half k%2)
-        t.v[(k / 2) * 32 + lane_of_slot(k % 2, c)] = (unsigned char)pix;
-    }
-    for (int k = 0; k < 6; ++k) {
-        int filler = 0;
-        for (int c = 0; c < 16; ++c)
-            if (t.v[(k / 2) * 32 + lane_of_slot(k % 2, c)] != 0xFF) { filler = t.v[(k / 2) * 32 + lane_of_slot(k % 2, c)]; break; }
-        for (int c = 0; c < 16; ++c)
-            if (t.v[(k / 2) * 32 + lane_of_slot(k % 2, c)] == 0xFF) t.v[(k / 2) * 32 + lane_of_slot(k % 2, c)] = (unsigned char)(filler | 0x80);
-    }
-    return t;
-}
-__device__ const Perm9 kPerm9 = make_perm9();
-struct Perm9Mask {
-    unsigned m[3];                                                       // bit r of m[i]: row r of tile i holds a pixel
-};
-constexpr Perm9Mask make_perm9_mask() {
-    const Perm9 t = make_perm9();
-    Perm9Mask k{};
-    for (int i = 0; i < 96; ++i)
-        if ((t.v[i] & 0x80) == 0) k.m[i / 32] |= 1u << (i % 32);
-    return k;
-}
-
-// tile row (0 .. BM-1) -> pixel of the patch (ty * TX + tx) and whether the row holds a pixel at all
-template <int TY, int TX>
-__device__ __forceinline__ int halo_row_pixel(int row, bool& valid) {
-    if constexpr (TY == 9 && TX == 9) {
-        const int e = kPerm9.v[row];
-        valid = (e & 0x80) == 0;
-        return e & 0x7F;
-    } else {
-        static_assert(TX == 16, "patch width 16 or the 9x9 table");
-        const int pl = (row & ~31) + tile_row_perm(row & 31);
-        valid = pl < TY * TX;
-        return valid ? pl : 0;
-    }
-}
-
-template <int TY, int TX>
-struct HaloRowMap {
-    int img0, n_img, y0, x0, ho, wo;
-    __device__ __forceinline__ int64_t operator()(int row) const {
-        bool valid;
-        const int pl = halo_row_pixel<TY, TX>(row, valid);
-        if (!valid) return -1;
-        const int y = y0 + pl / TX, x = x0 + pl % TX;
-        return (y < ho && x < wo) ? ((int64_t)img0 * ho + y) * wo + x : -1;
-    }
-};
 
 // LDS-halo convolution, stride 1, KY x KX taps in {3x3, 1x5, 5x1}, split-bf16 MFMA.
 //
@@ -1018,6 +940,8 @@ int launch_conv(const woft_conv_params& p, hipStream_t s) {
 
 }  // namespace
 
+int woft_conv_regb_launch(const woft_conv_params& p, void* stream);     // conv_regb.hip
+
 extern "C" int woft_conv2d(const woft_conv_params* pp, void* stream) {
     if (pp == nullptr) return WOFT_EINVAL;
     const woft_conv_params& p = *pp;
@@ -1048,6 +972,13 @@ extern "C" int woft_conv2d(const woft_conv_params* pp, void* stream) {
     if (p.e1 != nullptr && p.lde1 % 4 != 0) return WOFT_EINVAL;
     if (p.out1 != nullptr && (p.ldo1 % 4 != 0 || p.split % 4 != 0)) return WOFT_EINVAL;
     if ((p.stat_sum == nullptr) != (p.stat_sq == nullptr)) return WOFT_EINVAL;
+    // epilogue contract (conv_common.h): 16-byte aligned outputs, no column remap; a ragged last channel group only with
+    // the element-wise kinds and without statistics / per-pixel bias
+    if (p.epi != WOFT_EPI_WH_MEAN) {
+        if (p.out_pitch != 0 || p.ldo % 4 != 0 || p.co_off % 4 != 0 || p.epi == WOFT_EPI_CTX) return WOFT_EINVAL;
+        const bool simple = p.epi == WOFT_EPI_LINEAR || p.epi == WOFT_EPI_RELU || p.epi == WOFT_EPI_SIGMOID || p.epi == WOFT_EPI_TANH;
+        if (p.cout % 4 != 0 && (!simple || p.stat_sum != nullptr || p.bias_map != nullptr)) return WOFT_EINVAL;
+    }
     if (p.in_norm < 0 || p.in_norm > 2) return WOFT_EINVAL;
     if (p.bias_map != nullptr && (p.cout % 4 != 0 || p.ld_bias_map < p.cout || p.ld_bias_map % 4 != 0 ||
                                   p.epi == WOFT_EPI_CTX || p.epi == WOFT_EPI_WH_MEAN || p.out_pitch != 0))
@@ -1066,6 +997,7 @@ extern "C" int woft_conv2d(const woft_conv_params* pp, void* stream) {
         const int64_t cs_max = (p.in1 != nullptr && p.cs1 > p.cs0) ? p.cs1 : p.cs0;
         if ((int64_t)p.n_img * p.h * p.w * cs_max >= (1ll << 31)) return WOFT_EINVAL;     // 32-bit element offsets
         if ((int64_t)p.taps_y * p.taps_x * p.cin_pad >= (1 << 20)) return WOFT_EINVAL;
+        if (p.halo == 8) return woft_conv_regb_launch(p, stream);
         if (p.halo == 1 && p.tile_n == 128) return launch_halo<8, 16, 128, 2, 2>(p, s);
         if (p.halo == 1 && p.tile_n == 64) return launch_halo<8, 16, 64, 2, 2>(p, s);
         if (p.halo == 2 && p.tile_n == 128 && p.ho == 9 && p.wo == 9) return launch_halo<9, 9, 128, 1, 2>(p, s);
@@ -1108,9 +1040,12 @@ extern "C" int woft_corr_gemm_bf16(const void* a, const void* b, int64_t m, int6
     return woft_launch_status();
 }
 
+int g_regb_dyn_lds = 0;     // developer knob [3]: extra dynamic LDS bytes of conv_regb launches (occupancy experiments)
+
 extern "C" int woft_set_tuning(int key, int value) {
     if (key < 0 || key >= 4) return WOFT_EINVAL;
     g_tuning[key] = value;
+    if (key == 3) g_regb_dyn_lds = value;
     return WOFT_OK;
 }
 

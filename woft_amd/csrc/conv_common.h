@@ -95,49 +95,53 @@ __device__ __forceinline__ void a_load(const woft_conv_params& p, const ARows<RA
 constexpr int STAGE_LD = 36;
 constexpr int STAGE_FLOATS = 32 * STAGE_LD;     // per wave
 
-__device__ __forceinline__ float epi_scalar(const woft_conv_params& p, float y, int64_t m, int n, bool& skip_store) {
-    skip_store = false;
-    switch (p.epi) {
-        case WOFT_EPI_RELU: return fmaxf(y, 0.f);
-        case WOFT_EPI_SIGMOID: return sigmoidf_(y);
-        case WOFT_EPI_TANH: return tanhf(y);
-        case WOFT_EPI_RELU_RES_RELU: return fmaxf(p.e0[m * p.lde0 + n] + fmaxf(y, 0.f), 0.f);
-        case WOFT_EPI_GRU_ZR:
-            y = sigmoidf_(y);
-            if (n >= p.split) {
-                p.out1[m * p.ldo1 + (n - p.split)] = y * p.e0[m * p.lde0 + (n - p.split)];
-                skip_store = true;
-            }
-            return y;
-        case WOFT_EPI_GRU_Q: {
-            const float z = p.e1[m * p.lde1 + n], hprev = p.e0[m * p.lde0 + n];
-            return (1.f - z) * hprev + z * tanhf(y);
-        }
-        case WOFT_EPI_CTX: return (n < p.split) ? tanhf(y) : fmaxf(y, 0.f);
-        default: return y;
-    }
-}
-
 // RowMap: local row of the workgroup tile -> global output pixel index m, or -1 (no such pixel)
 struct LinearRows {
     int64_t m0, M;
     __device__ __forceinline__ int64_t operator()(int row) const { const int64_t m = m0 + row; return m < M ? m : -1; }
 };
 
+// The epilogue's parameters are read ONCE into registers and laundered through an empty asm so that they stay there.
+// (The first version read them through `p.` inside the (tile, pass) loops; the compiler re-materialised them from the
+// kernel-argument segment each time -- s_load_dword + s_waitcnt lgkmcnt(0), ~330 scalar-cache round trips per wave.
+// In-kernel stamps (tools/regb_probe.py) showed the ReLU epilogue of a 128 x 128 tile taking 29-42 k cycles: 15-20 us of
+// a 68 us GRU-gate launch, as much as the whole main loop of the plain-bf16 mode.)
+template <class T>
+__device__ __forceinline__ T keep_sgpr(T x) {
+    asm volatile("" : "+s"(x));
+    return x;
+}
+
+// Launch-time contract (woft_conv2d validates it): ldo, co_off multiples of 4, no column remap; a ragged last channel
+// group (cout % 4 != 0) only with the element-wise kinds LINEAR / RELU / SIGMOID / TANH and without statistics.
 template <int TM, int TN, int WROWS, int WCOLS, typename RowMap>
 __device__ __forceinline__ void conv_epilogue_t(const woft_conv_params& p, f32x16 (&acc)[TM][TN], float* stage,
                                                 const RowMap& rowmap, int n0, int wm, int wn, int lane, int m_tile) {
+    float* const out = keep_sgpr(p.out);
+    float* const out1 = keep_sgpr(p.out1);
+    const float* const bias = keep_sgpr(p.bias);
+    const float* const bias_map = keep_sgpr(p.bias_map);
+    const float* const e0 = keep_sgpr(p.e0);
+    const float* const e1 = keep_sgpr(p.e1);
+    float* const stat_sum = keep_sgpr(p.stat_sum);
+    float* const stat_sq = keep_sgpr(p.stat_sq);
+    const int64_t ldo = keep_sgpr(p.ldo);
+    const int ldo1 = keep_sgpr(p.ldo1), lde0 = keep_sgpr(p.lde0), lde1 = keep_sgpr(p.lde1);
+    const int ld_bias_map = keep_sgpr(p.ld_bias_map), co_off = keep_sgpr(p.co_off), cout = keep_sgpr(p.cout);
+    const int cout_pad = keep_sgpr(p.cout_pad), split = keep_sgpr(p.split), epi = keep_sgpr(p.epi);
+    const float alpha = keep_sgpr(p.alpha);
+    const bool do_stats = stat_sum != nullptr;
+    const bool no_store = p.out_w == -12345;                   // (micro-benchmark ablation, tools/bench_conv.py)
+
     const int r32 = lane & 31, hh = lane >> 5;
     const int rr = lane >> 3, c4 = (lane & 7) * 4;
-    const bool do_stats = p.stat_sum != nullptr;
-    // 16-byte stores need an aligned, un-remapped destination; otherwise fall back to dword stores
-    const bool vec_out = (p.out_pitch == 0) && (p.ldo % 4 == 0) && (p.co_off % 4 == 0);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * WCOLS + j * 32 + c4;           // first of this lane's 4 channels
+        const bool nok = n + 3 < cout;                         // whole group valid
+        const int nrag = (!nok && n < cout) ? cout - n : 0;    // ragged last group: 1..3 valid channels
         f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias != nullptr) bias4 = *(const f32x4*)(p.bias + n);
-        const bool full = (n + 3) < p.cout;                    // all 4 channels valid
+        if (bias != nullptr) bias4 = *(const f32x4*)(bias + n);
         float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -145,74 +149,64 @@ __device__ __forceinline__ void conv_epilogue_t(const woft_conv_params& p, f32x1
             for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * hh) * STAGE_LD + r32] = acc[i][j][r];
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int pass = 0; pass < 4; ++pass) {
-                const int row = rr + 8 * pass;
+            for (int ps = 0; ps < 4; ++ps) {
+                const int row = rr + 8 * ps;
                 const int64_t m = rowmap(wm * WROWS + i * 32 + row);
                 const f32x4 v = *(const f32x4*)(stage + row * STAGE_LD + c4);
-                if (m < 0 || n >= p.cout) continue;
+                if (m < 0 || !(nok || nrag)) continue;
                 f32x4 y, b4 = bias4;
-                if (p.bias_map != nullptr && n + 3 < p.cout)        // per-pixel bias (a precomputed partial conv)
-                    b4 = *(const f32x4*)(p.bias_map + m * p.ld_bias_map + n);
+                if (bias_map != nullptr && nok) b4 = *(const f32x4*)(bias_map + m * ld_bias_map + n);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) y[e] = p.alpha * v[e] + b4[e];
+                for (int e = 0; e < 4; ++e) y[e] = alpha * v[e] + b4[e];
                 if (do_stats) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (n + e < p.cout) { ssum[e] += y[e]; ssq[e] += y[e] * y[e]; }
+                    for (int e = 0; e < 4; ++e) { ssum[e] += y[e]; ssq[e] += y[e] * y[e]; }
                 }
-                if (full && vec_out && p.epi != WOFT_EPI_CTX) {
-                    bool stored = false;
-                    switch (p.epi) {
-                        case WOFT_EPI_LINEAR: break;
-                        case WOFT_EPI_RELU:
+                bool stored = no_store;
+                switch (epi) {                                 // (scalar branches on a register: a few cycles)
+                    case WOFT_EPI_RELU:
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) y[e] = fmaxf(y[e], 0.f);
-                            break;
-                        case WOFT_EPI_SIGMOID:
+                        for (int e = 0; e < 4; ++e) y[e] = fmaxf(y[e], 0.f);
+                        break;
+                    case WOFT_EPI_SIGMOID:
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) y[e] = sigmoidf_(y[e]);
-                            break;
-                        case WOFT_EPI_TANH:
+                        for (int e = 0; e < 4; ++e) y[e] = sigmoidf_(y[e]);
+                        break;
+                    case WOFT_EPI_TANH:
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) y[e] = tanhf(y[e]);
-                            break;
-                        case WOFT_EPI_RELU_RES_RELU: {
-                            const f32x4 res = *(const f32x4*)(p.e0 + m * p.lde0 + n);
+                        for (int e = 0; e < 4; ++e) y[e] = tanhf(y[e]);
+                        break;
+                    case WOFT_EPI_RELU_RES_RELU: {
+                        const f32x4 res = *(const f32x4*)(e0 + m * lde0 + n);
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) y[e] = fmaxf(res[e] + fmaxf(y[e], 0.f), 0.f);
-                        } break;
-                        case WOFT_EPI_GRU_ZR:
+                        for (int e = 0; e < 4; ++e) y[e] = fmaxf(res[e] + fmaxf(y[e], 0.f), 0.f);
+                    } break;
+                    case WOFT_EPI_GRU_ZR:
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) y[e] = sigmoidf_(y[e]);
-                            if (n >= p.split) {                 // split % 4 == 0 (validated): whole vector is r
-                                const f32x4 hp = *(const f32x4*)(p.e0 + m * p.lde0 + (n - p.split));
+                        for (int e = 0; e < 4; ++e) y[e] = sigmoidf_(y[e]);
+                        if (n >= split) {                      // split % 4 == 0 (validated): whole vector is r
+                            const f32x4 hp = *(const f32x4*)(e0 + m * lde0 + (n - split));
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) y[e] *= hp[e];
-                                *(f32x4*)(p.out1 + m * p.ldo1 + (n - p.split)) = y;
-                                stored = true;
-                            }
-                            break;
-                        case WOFT_EPI_GRU_Q: {
-                            const f32x4 z = *(const f32x4*)(p.e1 + m * p.lde1 + n);
-                            const f32x4 hp = *(const f32x4*)(p.e0 + m * p.lde0 + n);
+                            for (int e = 0; e < 4; ++e) y[e] *= hp[e];
+                            if (!no_store) *(f32x4*)(out1 + m * ldo1 + (n - split)) = y;
+                            stored = true;
+                        }
+                        break;
+                    case WOFT_EPI_GRU_Q: {
+                        const f32x4 z = *(const f32x4*)(e1 + m * lde1 + n);
+                        const f32x4 hp = *(const f32x4*)(e0 + m * lde0 + n);
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) y[e] = (1.f - z[e]) * hp[e] + z[e] * tanhf(y[e]);
-                        } break;
-                        default: break;
-                    }
-                    if (!stored && p.out_w != -12345) *(f32x4*)(p.out + m * p.ldo + p.co_off + n) = y;   // (-12345: debug no-store)
-                } else {
+                        for (int e = 0; e < 4; ++e) y[e] = (1.f - z[e]) * hp[e] + z[e] * tanhf(y[e]);
+                    } break;
+                    default: break;
+                }
+                if (stored) continue;
+                if (nok) {
+                    *(f32x4*)(out + m * ldo + co_off + n) = y;
+                } else {                                       // ragged group (element-wise kinds only)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int ne = n + e;
-                        if (ne >= p.cout) continue;
-                        bool skip;
-                        const float ye = epi_scalar(p, y[e], m, ne, skip);
-                        if (skip) continue;
-                        int64_t col = ne;
-                        if (p.out_pitch != 0) col = (int64_t)(ne / p.out_w) * p.out_pitch + (ne % p.out_w);
-                        p.out[m * p.ldo + p.co_off + col] = ye;
-                    }
+                    for (int e = 0; e < 3; ++e)
+                        if (e < nrag) out[m * ldo + co_off + n + e] = y[e];
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -230,8 +224,8 @@ __device__ __forceinline__ void conv_epilogue_t(const woft_conv_params& p, f32x1
                 const int64_t row = (int64_t)m_tile * 2 + wm;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    p.stat_sum[row * p.cout_pad + n + e] = ssum[e];
-                    p.stat_sq[row * p.cout_pad + n + e] = ssq[e];
+                    stat_sum[row * cout_pad + n + e] = ssum[e];
+                    stat_sq[row * cout_pad + n + e] = ssq[e];
                 }
             }
         }

@@ -1,0 +1,239 @@
+// LDS-halo convolution with the WEIGHT operand streamed global -> registers (no LDS stage, no LDS-DMA, no
+// per-tap barrier).  Same GEMM formulation, arithmetic modes and epilogues as conv_halo_bf16_kernel (conv.hip):
+// stride 1, taps 3x3 / 1x5 / 5x1, split-bf16 operands on v_mfma_f32_32x32x16_bf16, fp32 accumulation.
+//
+// Why: in conv_halo_bf16_kernel every (tap, 32-channel chunk) K step copies a weight tile global -> LDS with LDS-DMA
+// and publishes it with a workgroup barrier; measured per step of a 128 x 128 tile (round-1 in-kernel timeline):
+// 300 cycles of DMA issue + 930 of fragment reads / MFMAs + 260-350 waiting for the DMA + 230 in the barrier, i.e.
+// the matrix pipe idles more than half of a step.  Here a wave owns a 32-column band of the output tile for ALL of
+// the tile's rows, so nobody else needs its weights: they are pre-packed on the host in MFMA-fragment order
+// ([32-column band][chunk][tap][plane hi, lo][k half][64 lanes][8 bf16] -- the wave's whole K loop is ONE contiguous
+// stream, every fragment one fully coalesced 1-KiB global_load_dwordx4) and fetched straight into VGPRs a few steps
+// ahead (a register ring).  What remains in LDS is the input halo (double buffered), what remains of the
+// synchronisation is ONE barrier per 32-channel chunk (= per 5 or 9 K steps), and between barriers the four waves
+// of a workgroup drift freely, so that one wave's memory waits sit beside another's MFMAs on the CU.
+//
+//   WM = 1: 4 waves x (128 rows x 32 columns): BN = 128, weights read once per workgroup.
+//   WM = 2: 2 x 2 waves x (64 rows x 32 columns): BN = 64 (the two row halves fetch the same fragments; L1 serves
+//           the second), for layers with too few 128-wide tiles.
+#include <type_traits>
+
+#include "conv_common.h"
+#include "halo_map.h"
+
+extern int g_regb_dyn_lds;          // conv.hip (woft_set_tuning key 3)
+
+namespace {
+
+using woft::BK;
+
+template <int TY, int TX, int KY, int KX, int WM, int TERMS, int NBUF, int DIST, int AD>
+__global__ __launch_bounds__(256) void conv_regb_kernel(const woft_conv_params p) {
+    constexpr int NWAVES = 4;
+    constexpr int NPIX = TY * TX;
+    constexpr int BM = (NPIX + 31) / 32 * 32;
+    constexpr int WN = NWAVES / WM;
+    constexpr int BN = 32 * WN;
+    constexpr int WROWS = BM / WM;
+    constexpr int TM = WROWS / 32;
+    constexpr int NP = (TERMS == 3) ? 2 : 1;
+    constexpr int TAPS = KY * KX;
+    static_assert(TAPS % NBUF == 0 && DIST >= 1 && DIST < NBUF, "register ring: static slots need TAPS % NBUF == 0");
+    static_assert(BM % (32 * WM) == 0, "bad wave layout");
+    constexpr int HX = TX + KX - 1, HY = TY + KY - 1, HROWS = HX * HY;
+    constexpr int RH = (HROWS + 31) / 32;
+    constexpr int A_PLANE = HROWS * LDB, A_ELEMS = NP * A_PLANE;          // one halo buffer (bf16 elements)
+    constexpr int STAGE_ELEMS = 2 * NWAVES * woft::STAGE_FLOATS;          // epilogue staging (floats -> bf16 units)
+    constexpr int SMEM_ELEMS = (2 * A_ELEMS > STAGE_ELEMS) ? 2 * A_ELEMS : STAGE_ELEMS;
+    constexpr int STEP_ELEMS = NP * 2 * 64 * 8;                           // fragment elements of one K step of a band
+    __shared__ __attribute__((aligned(16))) __bf16 smem[SMEM_ELEMS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int r32 = lane & 31, hh = lane >> 5;
+    const int v = tid & 7, r0 = tid >> 3;
+
+    const int tyn = (p.ho + TY - 1) / TY, txn = (p.wo + TX - 1) / TX;
+    int m_tile, n_tile;
+    woft::tile_of_block(blockIdx.x, p.n_img * tyn * txn, p.cout_pad / BN, m_tile, n_tile);
+    const int img0 = m_tile / (tyn * txn);
+    const int trem = m_tile - img0 * (tyn * txn);
+    const int y0 = (trem / txn) * TY, x0 = (trem % txn) * TX;
+    const int n0 = n_tile * BN;
+    const int nchunk = p.cin_pad / BK;
+    const int nsteps = nchunk * TAPS;
+
+    int hpix[RH];
+    bool hok[RH];
+#pragma unroll
+    for (int j = 0; j < RH; ++j) {
+        const int ht = r0 + 32 * j;
+        const int hy = ht / HX, hx = ht - hy * HX;
+        const int iy = y0 + hy - p.pad_y, ix = x0 + hx - p.pad_x;
+        hok[j] = ht < HROWS && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w;
+        hpix[j] = hok[j] ? (img0 * p.h + iy) * p.w + ix : 0;
+    }
+    f32x4 rh[RH];
+    auto load_halo = [&](int chunk) {
+        const int c0 = chunk * BK;
+        const bool second = (p.in1 != nullptr) && (c0 >= p.c_split);
+        const float* src = (second ? p.in1 + (c0 - p.c_split) : p.in0 + c0) + 4 * v;
+        const int cs = second ? p.cs1 : p.cs0;
+#pragma unroll
+        for (int j = 0; j < RH; ++j) rh[j] = *(const f32x4*)(src + (uint32_t)(hpix[j] * cs));
+    };
+    auto store_halo = [&](__bf16* As) {
+#pragma unroll
+        for (int j = 0; j < RH; ++j) {
+            const int ht = r0 + 32 * j;
+            if (RH * 32 > HROWS && ht >= HROWS) continue;
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 val = hok[j] ? rh[j] : zero;
+            const bf16x4 hi = __builtin_convertvector(val, bf16x4);
+            *(bf16x4*)(As + ht * LDB + 4 * v) = hi;
+            if (NP == 2) {
+                const f32x4 rem = val - __builtin_convertvector(hi, f32x4);
+                *(bf16x4*)(As + A_PLANE + ht * LDB + 4 * v) = __builtin_convertvector(rem, bf16x4);
+            }
+        }
+    };
+
+    // this wave's weight stream: band (n0 / 32 + wn), steps in (chunk, tap) order, STEP_ELEMS per step
+    const __bf16* wstream = (const __bf16*)p.wgt_frag + (int64_t)(n0 / 32 + wn) * nsteps * STEP_ELEMS + lane * 8;
+    bf16x8 bq[NBUF][NP][2];
+    auto fetch_b = [&](int step, auto slot_tag) {
+        constexpr int slot = decltype(slot_tag)::value;
+        const int s = step < nsteps ? step : nsteps - 1;                // (past the end: a harmless repeat)
+        const __bf16* src = wstream + (int64_t)s * STEP_ELEMS;
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) bq[slot][pl][s2] = *(const bf16x8*)(src + (pl * 2 + s2) * 512);
+    };
+
+    f32x16 acc[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    int a_off[TM];                   // element offset of this lane's A row inside a halo buffer (tap (0,0), k half hh)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        bool valid;
+        const int pl = halo_row_pixel<TY, TX>(wm * WROWS + i * 32 + r32, valid);
+        a_off[i] = ((pl / TX) * HX + (pl % TX)) * LDB + hh * 8;
+    }
+
+    // developer probe (tools/regb_probe.py): s_memtime stamps of wave 0 -> in_rstd (unused by this kernel otherwise)
+    unsigned long long* stamps = (p.in_mean == (const float*)1 && wave == 0 && lane == 0)
+                                     ? (unsigned long long*)p.in_rstd + (size_t)blockIdx.x * 16 : nullptr;
+    if (stamps) stamps[0] = __builtin_amdgcn_s_memtime();
+    // ---- prologue: halo of chunk 0, the first DIST steps of the weight stream ---------------------------------
+    load_halo(0);
+    [&]<int... S>(std::integer_sequence<int, S...>) {
+        (fetch_b(S, std::integral_constant<int, S % NBUF>{}), ...);
+    }(std::make_integer_sequence<int, DIST>{});
+    store_halo(smem);
+    __syncthreads();
+
+    // One 32-channel chunk = TAPS K steps, fully unrolled into "pairs": (tap, k half, two row tiles) = 4 (2 in plain
+    // bf16) A-fragment reads + 6 (2) MFMAs, issued term-major so that consecutive MFMAs never chain on one accumulator.
+    // The fragments of pair q + AD are requested BEFORE the MFMAs of pair q (ring of AD + 1 register sets) and
+    // sched_barriers keep it that way: left to itself the compiler sinks every ds_read next to its use and follows it
+    // with s_waitcnt lgkmcnt -- each pair then waits out the full LDS latency (PMC of that version: matrix pipe 55 %
+    // busy while LDS, L1 and L2 were all under 30 % busy).
+    constexpr int PT = TM, NQ = TAPS * PT, AR = AD + 1;                  // pairs per tap / per chunk
+    static_assert(TM % 2 == 0, "row tiles are processed in pairs");
+    auto run_chunk = [&](int chunk, auto more_tag) {
+        constexpr bool more = decltype(more_tag)::value;
+        const __bf16* As = smem + (chunk & 1) * A_ELEMS;
+        bf16x8 aq[AR][2][NP];
+        auto load_a = [&](auto q_tag) {
+            constexpr int q = decltype(q_tag)::value;
+            constexpr int tap = q / PT, r = q % PT, s2 = r / (TM / 2), i0 = 2 * (r % (TM / 2));
+            constexpr int ky = tap / KX, kx = tap - ky * KX;
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl)
+                    aq[q % AR][d][pl] = *(const bf16x8*)(As + a_off[i0 + d] + pl * A_PLANE + (ky * HX + kx) * LDB + s2 * 16);
+        };
+        [&]<int... Q>(std::integer_sequence<int, Q...>) { (load_a(std::integral_constant<int, Q>{}), ...); }
+        (std::make_integer_sequence<int, (AD < NQ ? AD : NQ)>{});
+        __builtin_amdgcn_sched_barrier(0);
+        [&]<int... Q>(std::integer_sequence<int, Q...>) {
+            ([&] {
+                constexpr int q = Q;
+                constexpr int tap = q / PT, r = q % PT, s2 = r / (TM / 2), i0 = 2 * (r % (TM / 2));
+                constexpr int slot = tap % NBUF, as = q % AR;
+                if constexpr (r == 0) {
+                    // weights of step (chunk, tap) + DIST into the slot that step (chunk, tap) - (NBUF - DIST) vacated
+                    fetch_b(chunk * TAPS + tap + DIST, std::integral_constant<int, (tap + DIST) % NBUF>{});
+                    if (tap == 0 && more) load_halo(chunk + 1);
+                }
+                if constexpr (q + AD < NQ) load_a(std::integral_constant<int, q + AD>{});
+                __builtin_amdgcn_sched_barrier(0);
+                if (NP == 2) {
+                    acc[i0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[as][0][NP - 1], bq[slot][0][s2], acc[i0], 0, 0, 0);
+                    acc[i0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[as][1][NP - 1], bq[slot][0][s2], acc[i0 + 1], 0, 0, 0);
+                    acc[i0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[as][0][0], bq[slot][NP - 1][s2], acc[i0], 0, 0, 0);
+                    acc[i0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[as][1][0], bq[slot][NP - 1][s2], acc[i0 + 1], 0, 0, 0);
+                }
+                acc[i0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[as][0][0], bq[slot][0][s2], acc[i0], 0, 0, 0);
+                acc[i0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[as][1][0], bq[slot][0][s2], acc[i0 + 1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                // next chunk's halo -> the other buffer (free since the barrier that ended the previous chunk); late
+                // in the chunk so that its loads had the whole chunk to land
+                if constexpr (q == NQ - 1) {
+                    if (more) store_halo(smem + ((chunk + 1) & 1) * A_ELEMS);
+                }
+            }(), ...);
+        }(std::make_integer_sequence<int, NQ>{});
+        if (more) __syncthreads();
+        if (stamps && chunk < 12) stamps[1 + chunk] = __builtin_amdgcn_s_memtime();
+    };
+    for (int chunk = 0; chunk + 1 < nchunk; ++chunk) run_chunk(chunk, std::true_type{});
+    run_chunk(nchunk - 1, std::false_type{});
+    __syncthreads();                                     // halo buffers are dead: reuse them as epilogue staging
+
+    const HaloRowMap<TY, TX> rowmap{img0, p.n_img, y0, x0, p.ho, p.wo};
+    f32x16 acc2[TM][1];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) acc2[i][0] = acc[i];
+    if (stamps) stamps[14] = __builtin_amdgcn_s_memtime();
+    woft::conv_epilogue_t<TM, 1, WROWS, 32>(p, acc2, (float*)smem + wave * woft::STAGE_FLOATS, rowmap, n0, wm, wn, lane,
+                                            m_tile);
+    if (stamps) stamps[15] = __builtin_amdgcn_s_memtime();
+}
+
+template <int WM>
+int launch_regb(const woft_conv_params& p, hipStream_t s) {
+    constexpr int TY = 8, TX = 16, BN = 128 / WM;
+    const int tyn = (p.ho + TY - 1) / TY, txn = (p.wo + TX - 1) / TX;
+    const int64_t mt = (int64_t)p.n_img * tyn * txn;
+    dim3 grid((unsigned)(mt * (p.cout_pad / BN)));
+#define REGB(KY, KX, T, NB, D) \
+    hipLaunchKernelGGL((conv_regb_kernel<TY, TX, KY, KX, WM, T, NB, D, 2>), grid, dim3(256), (size_t)g_regb_dyn_lds, s, p)
+#define REGB_TAPS(T)                                                     \
+    if (p.taps_y == 3 && p.taps_x == 3) REGB(3, 3, T, 3, 2);             \
+    else if (p.taps_y == 1 && p.taps_x == 5) REGB(1, 5, T, 5, 3);        \
+    else if (p.taps_y == 5 && p.taps_x == 1) REGB(5, 1, T, 5, 3);        \
+    else return WOFT_EINVAL
+    if (p.precision == 1) { REGB_TAPS(3); } else { REGB_TAPS(1); }
+#undef REGB_TAPS
+#undef REGB
+    return woft_launch_status();
+}
+
+}  // namespace
+
+// Called by woft_conv2d for p.halo == 8 (after its argument checks).
+int woft_conv_regb_launch(const woft_conv_params& p, void* stream) {
+    if (p.wgt_frag == nullptr || p.in_norm != 0 || (p.in_mean != nullptr && p.in_mean != (const float*)1) || p.wh0_lookup != nullptr || p.epi == WOFT_EPI_WH_MEAN) return WOFT_EINVAL;
+    if (p.tile_n == 128 && p.cout_pad % 128 == 0) return launch_regb<1>(p, (hipStream_t)stream);
+    if (p.tile_n == 64 && p.cout_pad % 64 == 0) return launch_regb<2>(p, (hipStream_t)stream);
+    return WOFT_EINVAL;
+}

@@ -14,7 +14,8 @@ __device__ __forceinline__ void lds_dma16(const void* gbase, uint32_t lane_off, 
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
                  : "=&s"(saved_m0)
                  : "s"(lds_addr), "v"(lane_off), "s"(gbase)
-                 : "memory");
+                 : "memory", "vcc");                     // (vcc: keeps the 64-bit base out of a register pair the
+                                                         //  instruction's saddr field cannot encode)
 }
 template <int N>
 __device__ __forceinline__ void dma_wait() {             // at most N vector-memory loads still in flight

@@ -79,6 +79,20 @@ class PackedConv:
     kw: int = 0
     wgt_hi: torch.Tensor = None   # bf16 split of wgt: hi = bf16(w), lo = bf16(w - hi)
     wgt_lo: torch.Tensor = None
+    _frag: dict = None            # planes -> weights in MFMA-fragment order (woft_conv_params.wgt_frag), built on demand
+
+    def frag(self, planes):
+        """[cout_pad/32 bands][chunks][taps][planes][2 k halves][64 lanes][8] bf16 (see woft_conv_params.wgt_frag)."""
+        if self._frag is None:
+            self._frag = {}
+        if planes not in self._frag:
+            taps, nchunk = self.taps_y * self.taps_x, self.cin_pad // 32
+            w = self.wgt.detach().cpu().reshape(self.cout_pad // 32, 32, taps, nchunk, 2, 2, 8)
+            w = w.permute(0, 3, 2, 4, 5, 1, 6).contiguous()        # band, chunk, tap, k half, lane half, row, e
+            hi = w.to(torch.bfloat16)
+            pl = [hi] + ([(w - hi.float()).to(torch.bfloat16)] if planes == 2 else [])
+            self._frag[planes] = torch.stack(pl, dim=3).contiguous().to(self.wgt.device)
+        return self._frag[planes]
 
     def __post_init__(self):
         if self.wgt is not None and self.wgt_hi is None and self.wgt.dtype == torch.float32:
@@ -141,7 +155,7 @@ def fold_bn(weight, bias, bn_w, bn_b, mean, var, eps=1e-5):
 
 PRECISION = {"fp32": 0, "bf16x3": 1, "bf16": 2}
 USE_HALO = os.environ.get("WOFT_HALO", "1") != "0"
-HALO_TILES = {1: (8, 16, 1), 2: (9, 9, 1), 4: (4, 16, 1), 6: (6, 16, 1)}     # (TY, TX, images per workgroup)
+HALO_TILES = {1: (8, 16, 1), 2: (9, 9, 1), 4: (4, 16, 1), 6: (6, 16, 1), 8: (8, 16, 1)}     # (TY, TX, images per workgroup)
 HALO_MIN_BLOCKS = int(os.environ.get("WOFT_HALO_MIN_BLOCKS", "400"))
 WH_HALO = int(os.environ.get("WOFT_WH_HALO", "2"))
 
@@ -236,6 +250,15 @@ def conv_params(x, pc, out, co_off=0, epi=_lib.EPI_LINEAR, x2=None, c_split=0, e
                     halo = 1 if b816 * (p.cout_pad // tn) >= HALO_MIN_BLOCKS else 4
                 p.tile_n = tn
     p.halo = halo
+    p.wgt_frag = None
+    if halo == 8:                       # weights streamed to registers in MFMA-fragment order (conv_regb.hip)
+        assert p.precision != 0 and not pc.flat and pc.stride == 1 and not in_norm
+        assert (pc.taps_y, pc.taps_x) in ((3, 3), (1, 5), (5, 1)) and (ho, wo) == (x.h, x.w)
+        frag = pc.frag(2 if p.precision == 1 else 1)
+        p.wgt_frag = ptr(frag)
+        if tiles is None:
+            p.tile_n = tn = 128 if pc.cout_pad % 128 == 0 else 64
+        p.cout_pad = pc.cout_pad if stats is not None else _round_up(p.cout, p.tile_n)
     p.bias_map, p.ld_bias_map = (ptr(bias_map.t), bias_map.cs) if bias_map is not None else (None, 0)
     p.in_norm, p.in_mean, p.in_rstd = 0, None, None
     if in_norm and halo in (1, 4) and (pc.taps_y, pc.taps_x) == (3, 3):      # (instantiated for the 3x3 pixel tiles)
@@ -255,7 +278,7 @@ def conv_params(x, pc, out, co_off=0, epi=_lib.EPI_LINEAR, x2=None, c_split=0, e
         assert halo == 2 and p.precision != 0 and pc.cin_pad == 128, "fused first layer: 9x9 whole-window kernel only"
         p.wh0_lookup, p.wh0_ld, p.wh0_mean = ptr(lk.t), lk.cs, ptr(mean)
         p.wh0_w, p.wh0_bias, p.wh0_index = ptr(frag), ptr(b0), (ptr(index) if index is not None else None)
-    p._keep = (x, x2, pc, out, e0, e1, out1, stats, in_stats, bias_map, wh0)
+    p._keep = (x, x2, pc, out, e0, e1, out1, stats, in_stats, bias_map, wh0, p.wgt_frag and pc._frag)
     p._m = m
     return p
 
