@@ -10,7 +10,7 @@ from pathlib import Path
 
 import torch  # noqa: F401  (must precede the CDLL so both share one HIP runtime)
 
-LIB_PATH = Path(__file__).resolve().parent / "lib" / "libwoft_hip.so"
+LIB_PATH = Path(os.environ.get("WOFT_HIP_LIB") or Path(__file__).resolve().parent / "lib" / "libwoft_hip.so")  # (env: A/B of builds)
 
 EPI_LINEAR, EPI_RELU, EPI_SIGMOID, EPI_TANH, EPI_RELU_RES_RELU, EPI_GRU_ZR, EPI_GRU_Q, EPI_CTX, EPI_WH_MEAN = range(9)
 

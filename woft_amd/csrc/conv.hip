@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256) void conv_mfma_bf16_kernel(const woft_conv_par
 // here, 32 channels at a time, as relu(conv 3x3 (5 -> 128) + bias) of the lookup window of one source pixel (the
 // weight head's first layer, weighted_raft.py:336,363-376) -- see conv0_* below.
 template <int TY, int TX, int KY, int KX, int BN, int TERMS, int WM, int STAGES, bool NORM, bool C0 = false>
-__global__ __launch_bounds__(256, (STAGES == 1 ? 4 : 1)) void conv_halo_bf16_kernel(const woft_conv_params p) {
+__global__ __launch_bounds__(256, (STAGES == 1 ? 4 : (TY == 9 ? 3 : 1))) void conv_halo_bf16_kernel(const woft_conv_params p) {
     static_assert(!C0 || (TY == 9 && TX == 9 && KY == 3 && KX == 3 && !NORM && STAGES == 2), "C0: weight-head windows");
     constexpr int NWAVES = 4;
     constexpr int NPIX = TY * TX;

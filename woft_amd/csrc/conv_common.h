@@ -111,26 +111,32 @@ __device__ __forceinline__ T keep_sgpr(T x) {
     asm volatile("" : "+s"(x));
     return x;
 }
+// (a pointer that went through the asm is no longer known to point to global memory and would be accessed with the slower
+//  flat_* instructions: the laundered value is carried as an integer and re-typed as an address-space-1 pointer per access)
+typedef __attribute__((address_space(1))) f32x4 g_f32x4;
+typedef __attribute__((address_space(1))) float g_f32;
+struct GPtr {
+    uint64_t a;
+    __device__ __forceinline__ bool null() const { return a == 0; }
+    __device__ __forceinline__ f32x4 ld4(int64_t off) const { return *(const g_f32x4*)(a + 4 * (uint64_t)off); }
+    __device__ __forceinline__ void st4(int64_t off, f32x4 v) const { *(g_f32x4*)(a + 4 * (uint64_t)off) = v; }
+    __device__ __forceinline__ void st1(int64_t off, float v) const { *(g_f32*)(a + 4 * (uint64_t)off) = v; }
+};
+__device__ __forceinline__ GPtr keep_gptr(const void* p) { return GPtr{keep_sgpr((uint64_t)(uintptr_t)p)}; }
 
 // Launch-time contract (woft_conv2d validates it): ldo, co_off multiples of 4, no column remap; a ragged last channel
 // group (cout % 4 != 0) only with the element-wise kinds LINEAR / RELU / SIGMOID / TANH and without statistics.
 template <int TM, int TN, int WROWS, int WCOLS, typename RowMap>
 __device__ __forceinline__ void conv_epilogue_t(const woft_conv_params& p, f32x16 (&acc)[TM][TN], float* stage,
                                                 const RowMap& rowmap, int n0, int wm, int wn, int lane, int m_tile) {
-    float* const out = keep_sgpr(p.out);
-    float* const out1 = keep_sgpr(p.out1);
-    const float* const bias = keep_sgpr(p.bias);
-    const float* const bias_map = keep_sgpr(p.bias_map);
-    const float* const e0 = keep_sgpr(p.e0);
-    const float* const e1 = keep_sgpr(p.e1);
-    float* const stat_sum = keep_sgpr(p.stat_sum);
-    float* const stat_sq = keep_sgpr(p.stat_sq);
+    const GPtr out = keep_gptr(p.out), out1 = keep_gptr(p.out1), bias = keep_gptr(p.bias), bias_map = keep_gptr(p.bias_map);
+    const GPtr e0 = keep_gptr(p.e0), e1 = keep_gptr(p.e1), stat_sum = keep_gptr(p.stat_sum), stat_sq = keep_gptr(p.stat_sq);
     const int64_t ldo = keep_sgpr(p.ldo);
     const int ldo1 = keep_sgpr(p.ldo1), lde0 = keep_sgpr(p.lde0), lde1 = keep_sgpr(p.lde1);
     const int ld_bias_map = keep_sgpr(p.ld_bias_map), co_off = keep_sgpr(p.co_off), cout = keep_sgpr(p.cout);
     const int cout_pad = keep_sgpr(p.cout_pad), split = keep_sgpr(p.split), epi = keep_sgpr(p.epi);
     const float alpha = keep_sgpr(p.alpha);
-    const bool do_stats = stat_sum != nullptr;
+    const bool do_stats = !stat_sum.null();
     const bool no_store = p.out_w == -12345;                   // (micro-benchmark ablation, tools/bench_conv.py)
 
     const int r32 = lane & 31, hh = lane >> 5;
@@ -141,7 +147,7 @@ __device__ __forceinline__ void conv_epilogue_t(const woft_conv_params& p, f32x1
         const bool nok = n + 3 < cout;                         // whole group valid
         const int nrag = (!nok && n < cout) ? cout - n : 0;    // ragged last group: 1..3 valid channels
         f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-        if (bias != nullptr) bias4 = *(const f32x4*)(bias + n);
+        if (!bias.null()) bias4 = bias.ld4(n);
         float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -155,7 +161,7 @@ __device__ __forceinline__ void conv_epilogue_t(const woft_conv_params& p, f32x1
                 const f32x4 v = *(const f32x4*)(stage + row * STAGE_LD + c4);
                 if (m < 0 || !(nok || nrag)) continue;
                 f32x4 y, b4 = bias4;
-                if (bias_map != nullptr && nok) b4 = *(const f32x4*)(bias_map + m * ld_bias_map + n);
+                if (!bias_map.null() && nok) b4 = bias_map.ld4(m * ld_bias_map + n);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) y[e] = alpha * v[e] + b4[e];
                 if (do_stats) {
@@ -177,7 +183,7 @@ __device__ __forceinline__ void conv_epilogue_t(const woft_conv_params& p, f32x1
                         for (int e = 0; e < 4; ++e) y[e] = tanhf(y[e]);
                         break;
                     case WOFT_EPI_RELU_RES_RELU: {
-                        const f32x4 res = *(const f32x4*)(e0 + m * lde0 + n);
+                        const f32x4 res = e0.ld4(m * lde0 + n);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) y[e] = fmaxf(res[e] + fmaxf(y[e], 0.f), 0.f);
                     } break;
@@ -185,16 +191,16 @@ __device__ __forceinline__ void conv_epilogue_t(const woft_conv_params& p, f32x1
 #pragma unroll
                         for (int e = 0; e < 4; ++e) y[e] = sigmoidf_(y[e]);
                         if (n >= split) {                      // split % 4 == 0 (validated): whole vector is r
-                            const f32x4 hp = *(const f32x4*)(e0 + m * lde0 + (n - split));
+                            const f32x4 hp = e0.ld4(m * lde0 + (n - split));
 #pragma unroll
                             for (int e = 0; e < 4; ++e) y[e] *= hp[e];
-                            if (!no_store) *(f32x4*)(out1 + m * ldo1 + (n - split)) = y;
+                            if (!no_store) out1.st4(m * ldo1 + (n - split), y);
                             stored = true;
                         }
                         break;
                     case WOFT_EPI_GRU_Q: {
-                        const f32x4 z = *(const f32x4*)(e1 + m * lde1 + n);
-                        const f32x4 hp = *(const f32x4*)(e0 + m * lde0 + n);
+                        const f32x4 z = e1.ld4(m * lde1 + n);
+                        const f32x4 hp = e0.ld4(m * lde0 + n);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) y[e] = (1.f - z[e]) * hp[e] + z[e] * tanhf(y[e]);
                     } break;
@@ -202,11 +208,11 @@ __device__ __forceinline__ void conv_epilogue_t(const woft_conv_params& p, f32x1
                 }
                 if (stored) continue;
                 if (nok) {
-                    *(f32x4*)(out + m * ldo + co_off + n) = y;
+                    out.st4(m * ldo + co_off + n, y);
                 } else {                                       // ragged group (element-wise kinds only)
 #pragma unroll
                     for (int e = 0; e < 3; ++e)
-                        if (e < nrag) out[m * ldo + co_off + n + e] = y[e];
+                        if (e < nrag) out.st1(m * ldo + co_off + n + e, y[e]);
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -224,8 +230,8 @@ __device__ __forceinline__ void conv_epilogue_t(const woft_conv_params& p, f32x1
                 const int64_t row = (int64_t)m_tile * 2 + wm;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    stat_sum[row * cout_pad + n + e] = ssum[e];
-                    stat_sq[row * cout_pad + n + e] = ssq[e];
+                    stat_sum.st1(row * cout_pad + n + e, ssum[e]);
+                    stat_sq.st1(row * cout_pad + n + e, ssq[e]);
                 }
             }
         }
