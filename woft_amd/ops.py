@@ -155,6 +155,7 @@ def fold_bn(weight, bias, bn_w, bn_b, mean, var, eps=1e-5):
 
 PRECISION = {"fp32": 0, "bf16x3": 1, "bf16": 2}
 USE_HALO = os.environ.get("WOFT_HALO", "1") != "0"
+USE_REGB = os.environ.get("WOFT_REGB", "1") != "0"
 HALO_TILES = {1: (8, 16, 1), 2: (9, 9, 1), 4: (4, 16, 1), 6: (6, 16, 1), 8: (8, 16, 1)}     # (TY, TX, images per workgroup)
 HALO_MIN_BLOCKS = int(os.environ.get("WOFT_HALO_MIN_BLOCKS", "400"))
 WH_HALO = int(os.environ.get("WOFT_WH_HALO", "2"))
@@ -249,6 +250,11 @@ def conv_params(x, pc, out, co_off=0, epi=_lib.EPI_LINEAR, x2=None, c_split=0, e
                             p.cout_pad = _round_up(p.cout, 64)
                     halo = 1 if b816 * (p.cout_pad // tn) >= HALO_MIN_BLOCKS else 4
                 p.tile_n = tn
+    # stride-1 multi-tap layers without InstanceNorm plumbing: the kernel that streams the weights global -> registers
+    # (conv_regb.hip, halo 8) -- bit-identical, 1-8 % faster per layer on the update block's shapes (tools/regb_check.py)
+    if USE_REGB and halo in (1, 4) and tiles is None and stats is None and not in_norm and p.precision != 0:
+        p.tile_n = tn = (p.tile_n if halo == 1 else 64)
+        halo = 8
     p.halo = halo
     p.wgt_frag = None
     if halo == 8:                       # weights streamed to registers in MFMA-fragment order (conv_regb.hip)
@@ -256,8 +262,10 @@ def conv_params(x, pc, out, co_off=0, epi=_lib.EPI_LINEAR, x2=None, c_split=0, e
         assert (pc.taps_y, pc.taps_x) in ((3, 3), (1, 5), (5, 1)) and (ho, wo) == (x.h, x.w)
         frag = pc.frag(2 if p.precision == 1 else 1)
         p.wgt_frag = ptr(frag)
-        if tiles is None:
-            p.tile_n = tn = 128 if pc.cout_pad % 128 == 0 else 64
+        if tiles is None and p.tile_n not in (64, 128):
+            p.tile_n = 128 if pc.cout_pad % 128 == 0 else 64
+        if p.tile_n == 128 and pc.cout_pad % 128 != 0:
+            p.tile_n = 64
         p.cout_pad = pc.cout_pad if stats is not None else _round_up(p.cout, p.tile_n)
     p.bias_map, p.ld_bias_map = (ptr(bias_map.t), bias_map.cs) if bias_map is not None else (None, 0)
     p.in_norm, p.in_mean, p.in_rstd = 0, None, None
