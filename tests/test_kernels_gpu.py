@@ -261,7 +261,8 @@ def test_conv_gru_epilogues(ops, kh, kw, precision, tol):
     zb, rh, hn = (ops.new_act(n, h, w, 128, zero=True) for _ in range(3))
     pzr_p = ops.conv_params(ha, pzr, zb, x2=xa, c_split=128, epi=ops._lib.EPI_GRU_ZR, split=128, e0=ha, out1=rh,
                             precision=precision)
-    assert (pzr_p.halo in (1, 4)) == (precision != "fp32")
+    # default choice in the split-bf16 precisions: the kernel that streams the weights global -> registers (conv_regb)
+    assert (pzr_p.halo == 8) == (precision != "fp32")
     ops.run_conv(pzr_p)
     ops.run_conv(ops.conv_params(rh, pq, hn, x2=xa, c_split=128, epi=ops._lib.EPI_GRU_Q, e0=ha, e1=zb,
                                  precision=precision))
@@ -269,6 +270,17 @@ def test_conv_gru_epilogues(ops, kh, kw, precision, tol):
     _close(zb.nchw(), z, 2e-5 * tol, what="z")
     _close(rh.nchw(), r * hprev, 2e-5 * tol, what="r*h")
     _close(hn.nchw(), ref, 3e-5 * tol, what="h")
+    if precision != "fp32":
+        # the LDS-staged-weights halo kernels (8x16 and 4x16 pixel tiles) and both column widths of conv_regb compute the
+        # same products in the same order: bit-identical gate tensors
+        for halo, tiles in ((1, None), (4, None), (8, (128, 64)), (8, (128, 128))):
+            z2, rh2, h2 = (ops.new_act(n, h, w, 128, zero=True) for _ in range(3))
+            ops.run_conv(ops.conv_params(ha, pzr, z2, x2=xa, c_split=128, epi=ops._lib.EPI_GRU_ZR, split=128, e0=ha,
+                                         out1=rh2, precision=precision, halo=halo, tiles=tiles))
+            ops.run_conv(ops.conv_params(rh2, pq, h2, x2=xa, c_split=128, epi=ops._lib.EPI_GRU_Q, e0=ha, e1=z2,
+                                         precision=precision, halo=halo, tiles=tiles))
+            torch.cuda.synchronize()
+            assert torch.equal(z2.t, zb.t) and torch.equal(rh2.t, rh.t) and torch.equal(h2.t, hn.t), (halo, tiles)
 
 
 @pytest.mark.parametrize("precision,tol", [("bf16x3", 2e-4), ("bf16", 5e-2)])
@@ -299,12 +311,14 @@ def test_conv_halo_patches_and_fallback(ops, precision, tol):
     big = ops.new_act(1, 19, 37, 256, zero=True)
     p3 = ops.conv_params(ops.act_from_nchw(x), ops.pack_conv(wt, b), big, co_off=128, epi=ops._lib.EPI_RELU,
                          precision=precision)
-    assert p3.halo in (1, 4)
-    p4 = ops.conv_params(ops.act_from_nchw(x), ops.pack_conv(wt, b), ops.new_act(1, 19, 37, 126, cs=128, zero=True),
-                         epi=ops._lib.EPI_RELU, precision=precision, halo=1 if p3.halo == 4 else 4)
-    ops.run_conv(p4)
-    torch.cuda.synchronize()
-    _close(p4._keep[3].nchw(), ref, tol, what="other halo tile")
+    assert p3.halo == 8
+    for other in (1, 4):
+        p4 = ops.conv_params(ops.act_from_nchw(x), ops.pack_conv(wt, b), ops.new_act(1, 19, 37, 126, cs=128, zero=True),
+                             epi=ops._lib.EPI_RELU, precision=precision, halo=other)
+        assert p4.halo == other
+        ops.run_conv(p4)
+        torch.cuda.synchronize()
+        _close(p4._keep[3].nchw(), ref, tol, what="LDS-staged-weights halo kernel")
     ops.run_conv(p3)
     torch.cuda.synchronize()
     _close(big.nchw()[:, 128:254], ref, tol, what="halo 8x16 ragged")

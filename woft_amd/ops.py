@@ -217,6 +217,7 @@ def conv_params(x, pc, out, co_off=0, epi=_lib.EPI_LINEAR, x2=None, c_split=0, e
         p.cout_pad = _round_up(p.cout, 64)              # column tiles actually launched (convc2: 3 instead of 4 x 64)
     p.tile_m, p.tile_n = tm, tn
     # LDS-halo kernel for the split-bf16 precisions on stride-1 multi-tap convs (see conv.hip)
+    auto_halo = halo is None
     if halo is None:
         halo = 0
         if USE_HALO and p.precision != 0 and not pc.flat and pc.stride == 1 and pc.taps_y * pc.taps_x > 1 \
@@ -252,7 +253,7 @@ def conv_params(x, pc, out, co_off=0, epi=_lib.EPI_LINEAR, x2=None, c_split=0, e
                 p.tile_n = tn
     # stride-1 multi-tap layers without InstanceNorm plumbing: the kernel that streams the weights global -> registers
     # (conv_regb.hip, halo 8) -- bit-identical, 1-8 % faster per layer on the update block's shapes (tools/regb_check.py)
-    if USE_REGB and halo in (1, 4) and tiles is None and stats is None and not in_norm and p.precision != 0:
+    if USE_REGB and auto_halo and halo in (1, 4) and tiles is None and stats is None and not in_norm and p.precision != 0:
         p.tile_n = tn = (p.tile_n if halo == 1 else 64)
         halo = 8
     p.halo = halo
