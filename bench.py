@@ -73,9 +73,10 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(sd, template, mask, frame_np, iters):
-    """The CPU oracle (torch-CPU restatement of the reference path, parity-checked against the
-    imported reference) timed on the host cores for one tracked frame."""
+def cpu_baseline(sd, template, mask, frames_np, iters):
+    """The CPU oracle (torch-CPU restatement of the reference path, parity-checked against the imported reference)
+    timed on the host cores: a short tracked sequence, one wall time per frame (>= 3 frames, median).
+    -> (seconds per frame, dense correspondences of the FIRST frame for the EPE gate)."""
     from oracle import tracker_ref
     ref = tracker_ref.TrackerRef(sd, iters=iters)
     ref.init(template, mask)
@@ -84,13 +85,15 @@ def cpu_baseline(sd, template, mask, frame_np, iters):
 
     def flow(a, b):
         r = orig(a, b)
-        keep["tc"] = r
+        keep.setdefault("tc", r)
         return r
     ref._flow = flow
-    t0 = time.perf_counter()
-    Hr, _ = ref.track(frame_np)
-    dt = time.perf_counter() - t0
-    return dt, Hr, keep["tc"]
+    times = []
+    for f in frames_np:
+        t0 = time.perf_counter()
+        ref.track(f)
+        times.append(time.perf_counter() - t0)
+    return times, keep["tc"]
 
 
 def main():
@@ -107,10 +110,10 @@ def main():
                     help="correlation: volume-free on-the-fly lookup (default in the split-bf16 precisions) or the "
                          "all-pairs volume in HBM whose lookup is the HBM-roofline kernel (bit-identical results; "
                          "fp32 precision always uses the volume)")
-    ap.add_argument("--mask-weight-head", action="store_true",
-                    help="evaluate the weight head only on the template pixels whose weights the tracker reads (its "
-                         "template mask) instead of every pixel as the reference's network does; identical tracks "
-                         "(the default run reports this variant under 'alt_weight_head')")
+    ap.add_argument("--full-weight-head", action="store_true",
+                    help="evaluate the weight head on every template pixel, as the reference's network does, instead of "
+                         "only where the tracker reads the weights (its template mask: the tracker's default; identical "
+                         "tracks).  The default run times this variant too ('alt_weight_head').")
     ap.add_argument("--no-alt-corr", action="store_true",
                     help="skip the short extra run in the other correlation mode (reported under 'alt_corr'; in the "
                          "default mode it also measures the volume lookup for 'roofline_lookup')")
@@ -159,7 +162,7 @@ def main():
 
     def make_tracker(precision, corr=None, mask_wh=None, graph=False):
         conf = load_config(ROOT / "pytracking" / "configs" / (args.tracker_config + ".py"))
-        conf.mask_weight_head = args.mask_weight_head if mask_wh is None else mask_wh
+        conf.mask_weight_head = (not args.full_weight_head) if mask_wh is None else mask_wh
         conf.flow_config.model = sd
         conf.flow_config.iters = args.iters
         conf.flow_config.precision = precision
@@ -187,7 +190,8 @@ def main():
     results = track_all(tracker, 0, Wm)
     wdist.gather_tracks(results[:1])        # untimed: creates the RCCL communicator / warms the collective
     torch.cuda.synchronize()
-    plan.lookup_events, plan.wh_events = [], []
+    ROOF_TAG = "convc2"                  # the launch with the largest share of a frame (profiles/): see mfma_roofline
+    plan.lookup_events, plan.wh_events, plan.conv_events = [], [], {ROOF_TAG: []}
     wdist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -197,59 +201,83 @@ def main():
     wdist.barrier()
     elapsed = time.perf_counter() - t0
     elapsed = wdist.max_over_ranks(elapsed)
-    events, wh_events = plan.lookup_events, plan.wh_events
-    plan.lookup_events = plan.wh_events = None
+    events, wh_events, conv_events = plan.lookup_events, plan.wh_events, plan.conv_events[ROOF_TAG]
+    plan.lookup_events = plan.wh_events = plan.conv_events = None
 
     if rank != 0:
         return
     n_lost = int(tracks[:, :, 9].sum().item())
     peak_gb = torch.cuda.max_memory_allocated() / 2 ** 30        # every device buffer of the path is a torch tensor
 
+    mask_region = not args.full_weight_head
+    terms = {"fp32": 1, "bf16x3": 3, "bf16": 1}[args.precision]
+    mfma_peak = 157.3 if args.precision == "fp32" else 2500.0      # TFLOP/s dense: f32-input MFMA / bf16 MFMA (MI355X_MICROARCH.md)
+
     def lookup_roofline(evs, P):
-        """Correlation lookup in the volume (the named HBM-roofline kernel): algorithmic bytes / live time."""
+        """Correlation lookup in the volume (the named HBM-roofline kernel): algorithmic bytes / live time.
+        `traffic` = HBM bytes per launch from PMC passes (FETCH_SIZE with the guide's gfx950 correction + WRITE_SIZE), which
+        need their own rocprofv3 runs: tools/lookup_pmc.sh regenerates profiles/r02_lookup_pmc.json on the GPU box."""
         lk_ms = [s.elapsed_time(e) for s, e in evs]
         lk_avg = float(np.mean(lk_ms)) if lk_ms else float("nan")
         algo_bytes = LOOKUP_ALGO_BYTES_PER_PIXEL * P
-        traffic = None            # HBM bytes per launch from the committed PMC passes (separate rocprofv3 runs)
-        try:
-            pmc = json.loads((ROOT / "profiles" / "r01_lookup_pmc.json").read_text())
-            if pmc["resolution"] == [H, W]:
-                traffic = pmc["traffic_bytes_per_launch"]
-        except Exception:
-            pass
+        traffic, src = None, None
+        for name in ("r02_lookup_pmc.json", "r01_lookup_pmc.json"):
+            try:
+                pmc = json.loads((ROOT / "profiles" / name).read_text())
+                if pmc["resolution"] == [H, W]:
+                    traffic, src = pmc["traffic_bytes_per_launch"], f"profiles/{name} (tools/lookup_pmc.sh: separate rocprofv3 --pmc passes)"
+                    break
+            except Exception:
+                pass
         achieved = algo_bytes / (lk_avg * 1e-3) / 1e9 if lk_ms else float("nan")
         return {"bound": "hbm", "kernel": "corr_lookup_kernel<4>", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src,
                 "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": lk_avg, "launches_timed": len(lk_ms)}
 
-    def mfma_roofline(evs, layer, P):
-        """The kernel with the largest share of a frame (profiles/): a weight-head 3x3 128->128 layer on the P lookup
-        windows (weighted_raft.py:337-340), matrix-core bound; HIP events around its launches in the timed region."""
+    def conv_roofline(evs, p, tag):
+        """The launch with the largest share of a frame (profiles/r02_bench_kernel_stats_*.csv): the motion encoder's
+        3x3 conv 256 -> 192 on the 1/8-resolution map (update.py:83,91), 12 launches per frame; matrix-core bound.
+        HIP events around its launches in the timed region, on the stream the kernels are enqueued on."""
+        ms = [s.elapsed_time(e) for s, e in evs]
+        t = float(np.mean(ms)) if ms else float("nan")
+        m, k, n = p._m, p.taps_y * p.taps_x * p.cin_pad, p.cout
+        flops = 2.0 * m * k * n
+        rows = p._m_tiles * 128                                       # rows of the launched 8x16-pixel tiles
+        issued = 2.0 * rows * k * p.cout_pad * terms
+        kern = {8: "conv_regb_kernel<8,16,3,3> (weights streamed global -> registers)", 1: "conv_halo_bf16_kernel<8,16,3,3>",
+                4: "conv_halo_bf16_kernel<4,16,3,3>", 0: "conv_mfma_f32_kernel"}.get(p.halo, f"halo {p.halo}")
+        return {"bound": "mfma", "kernel": f"{tag}: conv 3x3 {p.cin_pad}->{n} on {m} pixels, {kern}, tile_n {p.tile_n}",
+                "achieved": flops / (t * 1e-3) / 1e12, "peak": mfma_peak, "unit": "TFLOP/s",
+                "frac": flops / (t * 1e-3) / 1e12 / mfma_peak, "traffic": None,
+                "matrix_core_issue_frac": issued / (t * 1e-3) / 1e12 / mfma_peak,
+                "algorithmic_flops_per_launch": flops, "mfma_terms_per_product": terms, "avg_launch_ms": t,
+                "launches_timed": len(ms),
+                "note": "frac prices the launch's own 2*M*K*N products against the dense peak of the MFMA type used; the "
+                        "issue fraction also counts the 3 bf16 MFMAs per fp32-emulating product and tile padding"}
+
+    def wh_roofline(evs, layer, P):
+        """Weight-head 3x3 128->128 layer on 9x9 lookup windows (weighted_raft.py:337-340; the first 5->128 layer is
+        computed inside the same launch), matrix-core bound; HIP events around its launches in the timed region."""
         ms = [s.elapsed_time(e) for s, e, _ in evs]
         wh_ms = float(np.mean(ms)) if ms else float("nan")
         n = int(layer.h)
         n_win = float(np.mean([k for _, _, k in evs])) if evs else float(P)   # windows per launch (P, or the mask region)
-        flops = 2.0 * n_win * n * n * 9 * 128 * 128                   # the layer's products (algorithmic)
-        terms = {"fp32": 1, "bf16x3": 3, "bf16": 1}[args.precision]
+        flops = 2.0 * n_win * n * n * 9 * 128 * 128
         rows = 96 if (n == 9 and args.precision != "fp32") else n * n  # 81 pixels occupy 3 MFMA row tiles
         issued = flops * terms * rows / (n * n)
-        fused0 = bool(getattr(plan, "wh0_fused", False))             # the 5->128 first layer runs inside this launch
-        if fused0:
+        if bool(getattr(plan, "wh0_fused", False)):
             flops += 2.0 * n_win * n * n * 45 * 128
             issued += 2.0 * n_win * 96 * 48 * 128 * terms            # K 45 -> 48
-        peak = 157.3 if args.precision == "fp32" else 2500.0
-        kname = ("conv_mfma_f32_kernel" if args.precision == "fp32" else
-                 "conv_halo_bf16_kernel<9,9,3,3,128" + (",C0>: the 5->128 first layer is computed in the same launch"
-                                                        if fused0 else ">"))
-        return {"bound": "mfma", "kernel": "weight head conv 3x3 128->128 on P 9x9 windows: " + kname,
-                "achieved": flops / (wh_ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
-                "frac": flops / (wh_ms * 1e-3) / 1e12 / peak, "traffic": None,
-                "matrix_core_issue_frac": issued / (wh_ms * 1e-3) / 1e12 / peak,
+        return {"bound": "mfma", "kernel": "weight head conv 3x3 128->128 (+ fused 5->128 first layer) on 9x9 windows",
+                "achieved": flops / (wh_ms * 1e-3) / 1e12, "peak": mfma_peak, "unit": "TFLOP/s",
+                "frac": flops / (wh_ms * 1e-3) / 1e12 / mfma_peak, "traffic": None,
+                "matrix_core_issue_frac": issued / (wh_ms * 1e-3) / 1e12 / mfma_peak,
                 "algorithmic_flops_per_launch": flops, "windows_per_launch": n_win, "mfma_terms_per_product": terms,
-                "avg_launch_ms": wh_ms, "launches_timed": len(ms),
-                "note": "frac prices the launch's own products against the dense peak of the MFMA type used; the issue "
-                        "fraction also counts the 3 bf16 MFMAs per fp32-emulating product and the 96/81 row padding"}
+                "avg_launch_ms": wh_ms, "launches_timed": len(ms)}
 
+    wh_desc = ("1/8-res pixels of the template mask (N_in = HW/4, SURVEY 8d) + upsampling support: the weights the tracker "
+               "reads (TRK:287-312), the tracker's default; identical tracks to evaluating it everywhere (checked below)"
+               if mask_region else "every template pixel (as the reference's network evaluates it)")
     out = {
         "metric": "tracked frames/sec at 1080p, 12 RAFT iters; flow EPE vs reference",
         "value": world * K / elapsed, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
@@ -261,125 +289,136 @@ def main():
                                 if args.tracker_config == "WOFT" else
                                 "IRLS (Huber) homography on Sobol-500 correspondences (reference config WOFT_IRLS.py)"),
                    "resolution": [H, W], "iters": args.iters, "sequences": world, "correlation": corr_mode,
-                   "weight_head": "every template pixel (as the reference's network)" if not args.mask_weight_head else
-                                  "1/8-res pixels of the template mask (N_in = HW/4, SURVEY 8d) + upsampling support: "
-                                  "the weights the tracker reads (TRK:287-312); identical tracks",
+                   "weight_head": wh_desc,
                    "template_cache": not args.no_template_cache, "weights": "synthetic seed 7 (reference key set)",
                    "frames_resident_in_hbm": True},
         "lost_frames": n_lost, "hbm_allocated_peak_gb": peak_gb,
     }
-    have_wh = bool(getattr(plan, "prog_wh", None)) and wh_events
+    conv_p = next((e[1] for e in plan.prog_iter if len(e) > 2 and e[2] == ROOF_TAG), None)
     if corr_mode == "volume":
         # the lookup reads the volume: the named HBM-roofline kernel, measured live in the timed region
         out["roofline"] = lookup_roofline(events, plan.P)
-        if have_wh:
-            out["roofline_mfma"] = mfma_roofline(wh_events, plan.prog_wh[0], plan.P)
-    elif have_wh:
-        # volume-free correlation: no HBM-bound lookup on the path; the dominant kernel is the matrix-core conv
+        if conv_p is not None and conv_events:
+            out["roofline_mfma"] = conv_roofline(conv_events, conv_p, ROOF_TAG)
+    elif conv_p is not None and conv_events:
+        # volume-free correlation: no HBM-bound lookup on the path; the dominant launch is a matrix-core conv
         # (the volume lookup's HBM roofline is measured in the 'alt_corr' pass below -> 'roofline_lookup')
-        out["roofline"] = mfma_roofline(wh_events, plan.prog_wh[0], plan.P)
+        out["roofline"] = conv_roofline(conv_events, conv_p, ROOF_TAG)
+    if bool(getattr(plan, "prog_wh", None)) and wh_events:
+        out["roofline_weight_head"] = wh_roofline(wh_events, plan.prog_wh[0], plan.P)
     tc_gpu = {}
     if world == 1:
         _, dst, _ = tracker.flower.compute_flow(template, frames[0], mode="TC", do_sigmoid=True)
         tc_gpu[args.precision] = dst.cpu()
-    tracker = plan = None                 # (frees the main engine's buffers before the short extra runs)
+        if corr_mode == "otf":
+            # the volume-free lookup's cost depends on the spread of the flow inside an 8x8 block (its result never does):
+            # the same kernel on this frame's smooth field (live, above) and on a per-pixel scattered field (+-8 px)
+            g = torch.Generator(device="cuda").manual_seed(1)
+            idx = torch.arange(plan.P, device="cuda")
+            grid = torch.stack([idx % plan.wf, idx // plan.wf], 1).float()
+            saved = plan.coords.clone()
+            res = {}
+            for name, field in (("smooth (this sequence)", saved),
+                                ("scattered +-3 px", grid + (torch.rand(plan.P, 2, device="cuda", generator=g) * 2 - 1) * 3.0),
+                                ("scattered +-8 px", grid + (torch.rand(plan.P, 2, device="cuda", generator=g) * 2 - 1) * 8.0)):
+                plan.coords.copy_(field)
+                for _ in range(2):
+                    ops.run_lookup_otf(plan.lookup)
+                evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
+                for s_, e_ in evs:
+                    s_.record()
+                    ops.run_lookup_otf(plan.lookup)
+                    e_.record()
+                torch.cuda.synchronize()
+                res[name] = {"avg_launch_us": 1e3 * float(np.mean([s_.elapsed_time(e_) for s_, e_ in evs]))}
+            plan.coords.copy_(saved)
+            res["in_timed_region_avg_launch_us"] = 1e3 * float(np.mean([s_.elapsed_time(e_) for s_, e_ in events])) if events else None
+            out["lookup_otf_by_flow_field"] = res
+    tracker = plan = None                 # (frees the main engine's buffers before the extra runs)
     gc.collect()
     torch.cuda.empty_cache()
+
+    def side_run(n_steps, check_tracks=False, **kw):
+        """Another tracker on the same sequence with the same history; -> timing (+ track identity with the timed run)."""
+        trk = make_tracker(kw.pop("precision", args.precision), **kw)
+        pl = trk.flower.engine.plan(H, W)
+        pl.lookup_events = [] if kw.get("corr") == "volume" else None
+        track_all(trk, 0, Wm)
+        torch.cuda.synchronize()
+        if pl.lookup_events is not None:
+            pl.lookup_events.clear()
+        t1 = time.perf_counter()
+        res = track_all(trk, Wm, n_steps)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        r = {"frames_per_s": n_steps / dt, "ms_per_step": 1000.0 * dt / n_steps, "steps": n_steps}
+        if check_tracks:
+            r["tracks_identical_to_timed_run"] = bool(all(np.array_equal(a[0], b_[0]) for a, b_ in zip(res, results[Wm:Wm + n_steps])))
+        evs, pl.lookup_events = pl.lookup_events, None
+        return r, trk, pl, evs
+
+    def drop(*objs):
+        gc.collect()
+        torch.cuda.empty_cache()
+
     if world == 1 and not args.no_alt_precisions:
-        # the other two arithmetic modes, same sequence, short runs (each its own engine + buffers)
+        # the other arithmetic modes on the same sequence, each its own engine + buffers.  The STRICT fp32 operating
+        # point (exact fp32 MFMA products, all-pairs volume: the reference's precision class) runs the full K steps.
         alt = {}
         for prec in ("fp32", "bf16x3", "bf16"):
             if prec == args.precision:
                 continue
-            trk = make_tracker(prec)
-            track_all(trk, 0, min(2, Wm))
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            n_alt = min(K, 8)
-            track_all(trk, Wm, n_alt)
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t1
+            r, trk, pl, _ = side_run(K if prec == "fp32" else min(K, 8), precision=prec)
             _, dst, _ = trk.flower.compute_flow(template, frames[0], mode="TC", do_sigmoid=True)
             tc_gpu[prec] = dst.cpu()
-            alt[prec] = {"frames_per_s": n_alt / dt, "ms_per_step": 1000.0 * dt / n_alt, "steps": n_alt}
-            del trk
-            gc.collect()
-            torch.cuda.empty_cache()
+            r["correlation"] = trk.flower.engine.corr
+            alt[prec] = r
+            del trk, pl
+            drop()
         out["alt_precisions"] = alt
+        if "fp32" in alt:
+            out["strict_fp32"] = dict(alt["fp32"], dtype="f32 (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate)",
+                                      note="same workload and step count as the headline, driver-timed in the same run")
     if world == 1 and not args.no_alt_corr and args.precision != "fp32":
-        # the other correlation mode, same sequence, short run; in the default (volume-free) mode this is also where
-        # the volume lookup -- the named HBM-roofline kernel -- is measured live
+        # the other correlation mode, same sequence; in the default (volume-free) mode this is also where the volume
+        # lookup -- the named HBM-roofline kernel -- is measured live
         other = "volume" if corr_mode == "otf" else "otf"
         torch.cuda.reset_peak_memory_stats()
-        trk = make_tracker(args.precision, corr=other)
-        pl = trk.flower.engine.plan(H, W)
-        track_all(trk, 0, min(2, Wm))
-        torch.cuda.synchronize()
-        pl.lookup_events = []
-        t1 = time.perf_counter()
-        n_alt = min(K, 8)
-        track_all(trk, Wm, n_alt)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t1
-        evs, pl.lookup_events = pl.lookup_events, None
-        out["alt_corr"] = {other: {"frames_per_s": n_alt / dt, "ms_per_step": 1000.0 * dt / n_alt, "steps": n_alt,
-                                   "hbm_allocated_peak_gb": torch.cuda.max_memory_allocated() / 2 ** 30}}
+        r, trk, pl, evs = side_run(min(K, 8), check_tracks=True, corr=other)
+        r["hbm_allocated_peak_gb"] = torch.cuda.max_memory_allocated() / 2 ** 30
+        out["alt_corr"] = {other: r}
         if other == "volume":
             out["roofline_lookup"] = lookup_roofline(evs, pl.P)
         del trk, pl
-        gc.collect()
-        torch.cuda.empty_cache()
+        drop()
     if world == 1 and not args.no_alt_corr:
-        # the weight head restricted to the template-mask region (the weights the tracker reads) -- or, with
-        # --mask-weight-head, on every pixel: same tracks, short run
-        trk = make_tracker(args.precision, mask_wh=not args.mask_weight_head)
-        track_all(trk, 0, Wm)                        # (same history as the timed run: the tracks must coincide)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        n_alt = min(K, 8)
-        res_alt = track_all(trk, Wm, n_alt)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t1
-        same = all(np.array_equal(a[0], b_[0]) for a, b_ in zip(res_alt, results[Wm:Wm + n_alt]))
-        out["alt_weight_head"] = {("full" if args.mask_weight_head else "mask_region"): {
-            "frames_per_s": n_alt / dt, "ms_per_step": 1000.0 * dt / n_alt, "steps": n_alt,
-            "tracks_identical_to_timed_run": bool(same)}}
-        del trk
-        gc.collect()
-        torch.cuda.empty_cache()
-    if world == 1 and not args.no_alt_corr:
-        # the same path with each flow's launch list replayed as ONE hipGraph (flow config key `graph`; the timed run
-        # launches eagerly because its per-launch HIP events cannot live inside a graph): same tracks, short run
-        trk = make_tracker(args.precision, graph=True)
-        track_all(trk, 0, Wm)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        n_alt = min(K, 8)
-        res_alt = track_all(trk, Wm, n_alt)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t1
-        same = all(np.array_equal(a[0], b_[0]) for a, b_ in zip(res_alt, results[Wm:Wm + n_alt]))
-        pl = trk.flower.engine.plan(H, W)
-        out["alt_graph"] = {"frames_per_s": n_alt / dt, "ms_per_step": 1000.0 * dt / n_alt, "steps": n_alt,
-                            "graphs_replayed": bool(any(g is not None for g in getattr(pl, "_graphs", {}).values())),
-                            "tracks_identical_to_timed_run": bool(same)}
+        # the weight head on every pixel (or, with --full-weight-head, on the mask region): full K steps, same tracks
+        r, trk, pl, _ = side_run(K, check_tracks=True, mask_wh=not mask_region)
+        out["alt_weight_head"] = {("full" if mask_region else "mask_region"): r}
         del trk, pl
-        gc.collect()
-        torch.cuda.empty_cache()
+        drop()
+        # each flow's launch list replayed as ONE hipGraph (flow config key `graph`; the timed run launches eagerly
+        # because its per-launch HIP events cannot live inside a graph): same tracks, short run
+        r, trk, pl, _ = side_run(min(K, 8), check_tracks=True, graph=True)
+        r["graphs_replayed"] = bool(any(g is not None for g in getattr(pl, "_graphs", {}).values()))
+        out["alt_graph"] = r
+        del trk, pl
+        drop()
     if world == 1 and not args.no_cpu_baseline:
         torch.set_num_threads(usable_cores())
-        f0 = frames[0].cpu().numpy()
-        dt, Hr, tc = cpu_baseline(sd, template, mask, f0, args.iters)
-        # quality gate on the same frame: flow EPE of the HIP path(s) against the CPU oracle
+        n_cpu = 3
+        times, tc = cpu_baseline(sd, template, mask, [frames[i].cpu().numpy() for i in range(n_cpu)], args.iters)
+        med = float(np.median(times))
+        # quality gate on the first frame: flow EPE of the HIP path(s) against the CPU oracle
         epes = {}
         for prec, dst in tc_gpu.items():
             e = torch.sqrt(((dst - tc[1]).reshape(2, -1) ** 2).sum(0))
             epes[prec] = {"mean_px": float(e.mean()), "max_px": float(e.max())}
-        epe = torch.sqrt(((tc_gpu[args.precision] - tc[1]).reshape(2, -1) ** 2).sum(0))
-        out["cpu_baseline"] = {"value": 1.0 / dt, "unit": "frames/s", "cores": torch.get_num_threads(),
-                               "kind": "port", "sample": f"1 tracked frame at {H}x{W}, {args.iters} iters "
-                               f"(oracle/tracker_ref.py, torch-CPU fp32), {dt:.1f} s"}
-        out["flow_epe_vs_cpu_oracle"] = {"mean_px": float(epe.mean()), "max_px": float(epe.max())}
+        out["cpu_baseline"] = {"value": 1.0 / med, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "os_cpu_count": os.cpu_count(), "seconds_per_frame": [round(t, 2) for t in times],
+                               "sample": f"{n_cpu} tracked frames at {H}x{W}, {args.iters} iters (oracle/tracker_ref.py, torch-CPU "
+                                         f"fp32 restatement of the reference path), median {med:.1f} s per frame"}
+        out["flow_epe_vs_cpu_oracle"] = epes[args.precision]
         out["flow_epe_vs_cpu_oracle_by_precision"] = epes
     print(json.dumps(out), flush=True)
 

@@ -212,6 +212,7 @@ def test_weight_head_on_mask_region_only():
         outs[full] = [trk.track(f)[0] for f in frames]
         plan = trk.flower.engine.plan(*[(d + 7) // 8 * 8 for d in (H, W)])
         assert (plan.wh_region is None) == full
+        assert trk._mask_weight_head() == (not full)
         if not full:
             n_sel = int(plan.wh_region[0].numel())
             assert 0 < n_sel < plan.P // 2
@@ -222,6 +223,13 @@ def test_weight_head_on_mask_region_only():
             assert np.array_equal(w_reg[0, sel], w_full[0, sel])
     for a, b in zip(outs[True], outs[False]):
         assert np.array_equal(a, b)
+    # the key's default: on (the tracker never reads the other weights); off when a post-hoc filter of the weight map is set
+    conf = load_config(ROOT / "pytracking" / "configs" / "WOFT.py")
+    conf.flow_config.model, conf.flow_config.iters = sd, 1
+    trk = conf.tracker_class(conf)
+    assert trk._mask_weight_head()
+    conf.post_hoc_weights_postprocessing_fn = lambda w: w
+    assert not conf.tracker_class(conf)._mask_weight_head()
 
 
 @pytest.mark.parametrize("name,cfg", [("woft", "WOFT.py"), ("lost", "WOFT.py"), ("irls", "WOFT_IRLS.py")])

@@ -185,6 +185,7 @@ class _Plan:
         self.source_tag = None
         self.lookup_events = None
         self.wh_events = None      # bench hook: list collecting (start, end) HIP events per lookup launch
+        self.conv_events = None    # bench hook: {tag: [(start, end)]} for the tagged conv launches of the iteration program
         sp = eng.spec
         hf, wf = hp // 8, wp // 8
         self.hf, self.wf, self.P = hf, wf, hf * wf
@@ -424,8 +425,8 @@ class _Plan:
                      ("conv", cp(self.fl1, e.convf2, self.cf, co_off=96, epi=EPI.EPI_RELU)),
                      ("conv", cp(self.cf, e.convm, self.xbuf, co_off=sp.cdim, epi=EPI.EPI_RELU))]
         else:                   # BasicMotionEncoder update.py:89-97: cor(192) | flo(64) -> 126, cat flow
-            prog += [("conv", cp(self.corr, e.convc1, self.c1, epi=EPI.EPI_RELU)),
-                     ("conv", cp(self.c1, e.convc2, self.cf, co_off=0, epi=EPI.EPI_RELU)),
+            prog += [("conv", cp(self.corr, e.convc1, self.c1, epi=EPI.EPI_RELU), "convc1"),
+                     ("conv", cp(self.c1, e.convc2, self.cf, co_off=0, epi=EPI.EPI_RELU), "convc2"),
                      ("conv", cp(self.flow4, e.convf1, self.fl1, epi=EPI.EPI_RELU)),
                      ("conv", cp(self.fl1, e.convf2, self.cf, co_off=192, epi=EPI.EPI_RELU)),
                      ("conv", cp(self.cf, e.convm, self.xbuf, co_off=sp.cdim, epi=EPI.EPI_RELU))]
@@ -438,16 +439,16 @@ class _Plan:
             if self.gate_bias is not None:      # [h | motion] only; the inp term is the per-pixel bias (see RaftEngine)
                 gz, gq = self.gate_bias[k]
                 prog += [("conv", cp(hi, e.zr_dyn[k], self.zbuf, x2=self.xbuf, x2_off=sp.cdim, c_split=hd,
-                                     epi=EPI.EPI_GRU_ZR, split=hd, e0=hi, out1=self.rh, bias_map=gz)),
+                                     epi=EPI.EPI_GRU_ZR, split=hd, e0=hi, out1=self.rh, bias_map=gz), f"gru_zr{k}"),
                          ("conv", cp(self.rh, e.q_dyn[k], ho, x2=self.xbuf, x2_off=sp.cdim, c_split=hd,
-                                     epi=EPI.EPI_GRU_Q, e0=hi, e1=self.zbuf, bias_map=gq))]
+                                     epi=EPI.EPI_GRU_Q, e0=hi, e1=self.zbuf, bias_map=gq), f"gru_q{k}")]
                 continue
             prog += [("conv", cp(hi, zr, self.zbuf, x2=self.xbuf, c_split=hd, epi=EPI.EPI_GRU_ZR, split=hd, e0=hi,
                                  out1=self.rh)),
                      ("conv", cp(self.rh, q, ho, x2=self.xbuf, c_split=hd, epi=EPI.EPI_GRU_Q, e0=hi, e1=self.zbuf))]
         if len(e.zr) == 1 and not first:
             prog.append(("copy", (self.hA.t, self.hB.t)))
-        prog.append(("conv", cp(self.hB, e.fh1, self.fh, epi=EPI.EPI_RELU)))
+        prog.append(("conv", cp(self.hB, e.fh1, self.fh, epi=EPI.EPI_RELU), "fh1"))
         if ops.narrow_ok(self.fh, e.fh2):                # second conv + coords1 += delta in one launch
             prog.append(("fh_update", (self.fh, e.fh2, self.delta)))
         else:
@@ -456,9 +457,18 @@ class _Plan:
 
     # ---- execution ------------------------------------------------------------------------
     def run(self, prog):
-        for kind, a in prog:
+        for ent in prog:
+            kind, a = ent[0], ent[1]
             if kind == "conv":
-                ops.run_conv(a)
+                ev = self.conv_events
+                if ev is not None and len(ent) > 2 and ent[2] in ev:
+                    s, t = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    s.record()
+                    ops.run_conv(a)
+                    t.record()
+                    ev[ent[2]].append((s, t))
+                else:
+                    ops.run_conv(a)
             elif kind == "fin":
                 rows, ld, c, c_pad, count = a
                 ops.inorm_finalize(self.stats, rows, ld, c, count, self.mean, self.rstd, channels_pad=c_pad)

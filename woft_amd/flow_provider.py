@@ -83,7 +83,7 @@ class RAFTWrapper:
         def eager():
             plan.flow(iters, crop, oh, ow, flow_up=o["flow"], dst=o["dst"], wout=o["w"] if weighted else None,
                       do_sigmoid=do_sigmoid)
-        if not self.use_graph or plan.lookup_events is not None or plan.wh_events is not None:
+        if not self.use_graph or plan.lookup_events is not None or plan.wh_events is not None or plan.conv_events is not None:
             return eager()
         graphs = plan.__dict__.setdefault("_graphs", {})
         region = plan.wh_region
