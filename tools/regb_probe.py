@@ -26,6 +26,8 @@ out = ops.new_act(1, hf, wf, cout, cs=ops._round_up(cout, 4), zero=True)
 p = ops.conv_params(x, pc, out, x2=x2, c_split=cin if x2c else 0, epi=_lib.EPI_RELU, precision=prec,
                     halo=halo or None, tiles=(128, tn) if tn else None)
 import os
+if os.environ.get("NOSTORE"):
+    p.out_w = -12345
 stamps = None
 if os.environ.get("STAMPS"):
     stamps = torch.zeros(4096 * 16, dtype=torch.int64, device="cuda")

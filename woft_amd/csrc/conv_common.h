@@ -126,113 +126,204 @@ __device__ __forceinline__ GPtr keep_gptr(const void* p) { return GPtr{keep_sgpr
 
 // Launch-time contract (woft_conv2d validates it): ldo, co_off multiples of 4, no column remap; a ragged last channel
 // group (cout % 4 != 0) only with the element-wise kinds LINEAR / RELU / SIGMOID / TANH and without statistics.
-template <int TM, int TN, int WROWS, int WCOLS, typename RowMap>
+//
+// Code size matters here: the epilogue runs ONCE per workgroup, so every instruction of it is an instruction-cache miss
+// (stamps: the fully unrolled version -- TN x TM x 4 row groups x a 7-way switch, ~1300 instructions on the taken path --
+// took 15 k cycles even with its stores disabled).  The row-group body is therefore a REAL loop (`#pragma unroll 1`) over
+// the ST accumulator tiles that were transposed into the wave's LDS staging area just before: the loop body is fetched
+// once and then runs from the instruction cache.  ST = tiles staged at once (the caller provides ST * STAGE_FLOATS floats
+// per wave); stage ALL of a wave's tiles when the LDS allows, one at a time otherwise.
+// The InstanceNorm statistics variant (encoder layers) keeps per-column-tile accumulators and the unrolled form.
+struct EpiRegs {
+    GPtr out, out1, bias, bias_map, e0, e1;
+    int64_t ldo;
+    int ldo1, lde0, lde1, ld_bias_map, co_off, cout, split, epi;
+    float alpha;
+    bool no_store;
+};
+
+// One row group (8 rows x 32 columns of a transposed tile) in two steps, so that a caller can issue the operand loads of
+// SEVERAL groups before the first store: on gfx9 stores count in vmcnt like loads and may complete out of order with them,
+// so waiting for any load that was issued after a store also waits for that store -- a loop of (load operands, wait,
+// store) serialises on the full store latency every turn (measured: ~1 k cycles per row group, 17 k per epilogue).
+struct EpiOps {
+    f32x4 b4, o0, o1;
+};
+__device__ __forceinline__ EpiOps epi_load(const EpiRegs& a, const int64_t m, const int n, const bool nok, const f32x4 bias4) {
+    EpiOps o;
+    o.b4 = bias4;
+    o.o0 = o.o1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!nok) return o;
+    if (!a.bias_map.null()) o.b4 = a.bias_map.ld4(m * a.ld_bias_map + n);
+    if (a.epi == WOFT_EPI_RELU_RES_RELU || a.epi == WOFT_EPI_GRU_Q) o.o0 = a.e0.ld4(m * a.lde0 + n);
+    if (a.epi == WOFT_EPI_GRU_ZR && n >= a.split) o.o0 = a.e0.ld4(m * a.lde0 + (n - a.split));
+    if (a.epi == WOFT_EPI_GRU_Q) o.o1 = a.e1.ld4(m * a.lde1 + n);
+    return o;
+}
+// v = this lane's 4 consecutive channels of pixel m; returns y = alpha * v + bias (the value the statistics are taken of)
+__device__ __forceinline__ f32x4 epi_finish(const EpiRegs& a, const f32x4 v, const EpiOps& o, const int64_t m, const int n,
+                                            const bool nok, const int nrag) {
+    f32x4 y, ypre;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ypre[e] = y[e] = a.alpha * v[e] + o.b4[e];
+    bool stored = a.no_store;
+    switch (a.epi) {                                   // (scalar branches on a register: a few cycles)
+        case WOFT_EPI_RELU:
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = fmaxf(y[e], 0.f);
+            break;
+        case WOFT_EPI_SIGMOID:
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = sigmoidf_(y[e]);
+            break;
+        case WOFT_EPI_TANH:
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = tanhf(y[e]);
+            break;
+        case WOFT_EPI_RELU_RES_RELU:
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = fmaxf(o.o0[e] + fmaxf(y[e], 0.f), 0.f);
+            break;
+        case WOFT_EPI_GRU_ZR:
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = sigmoidf_(y[e]);
+            if (n >= a.split) {                        // split % 4 == 0 (validated): whole vector is r
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] *= o.o0[e];
+                if (!a.no_store) a.out1.st4(m * a.ldo1 + (n - a.split), y);
+                stored = true;
+            }
+            break;
+        case WOFT_EPI_GRU_Q:
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = (1.f - o.o1[e]) * o.o0[e] + o.o1[e] * tanhf(y[e]);
+            break;
+        default: break;
+    }
+    if (stored) return ypre;
+    if (nok) {
+        a.out.st4(m * a.ldo + a.co_off + n, y);
+    } else {                                           // ragged group (element-wise kinds only)
+#pragma unroll
+        for (int e = 0; e < 3; ++e)
+            if (e < nrag) a.out.st1(m * a.ldo + a.co_off + n + e, y[e]);
+    }
+    return ypre;
+}
+
+template <int TM, int TN, int WROWS, int WCOLS, int ST = 1, typename RowMap>
 __device__ __forceinline__ void conv_epilogue_t(const woft_conv_params& p, f32x16 (&acc)[TM][TN], float* stage,
                                                 const RowMap& rowmap, int n0, int wm, int wn, int lane, int m_tile) {
-    const GPtr out = keep_gptr(p.out), out1 = keep_gptr(p.out1), bias = keep_gptr(p.bias), bias_map = keep_gptr(p.bias_map);
-    const GPtr e0 = keep_gptr(p.e0), e1 = keep_gptr(p.e1), stat_sum = keep_gptr(p.stat_sum), stat_sq = keep_gptr(p.stat_sq);
-    const int64_t ldo = keep_sgpr(p.ldo);
-    const int ldo1 = keep_sgpr(p.ldo1), lde0 = keep_sgpr(p.lde0), lde1 = keep_sgpr(p.lde1);
-    const int ld_bias_map = keep_sgpr(p.ld_bias_map), co_off = keep_sgpr(p.co_off), cout = keep_sgpr(p.cout);
-    const int cout_pad = keep_sgpr(p.cout_pad), split = keep_sgpr(p.split), epi = keep_sgpr(p.epi);
-    const float alpha = keep_sgpr(p.alpha);
+    constexpr int NT = TM * TN;
+    static_assert(NT % ST == 0, "staged tiles must divide the wave's tiles");
+    EpiRegs a;
+    a.out = keep_gptr(p.out); a.out1 = keep_gptr(p.out1); a.bias = keep_gptr(p.bias); a.bias_map = keep_gptr(p.bias_map);
+    a.e0 = keep_gptr(p.e0); a.e1 = keep_gptr(p.e1);
+    a.ldo = keep_sgpr(p.ldo); a.ldo1 = keep_sgpr(p.ldo1); a.lde0 = keep_sgpr(p.lde0); a.lde1 = keep_sgpr(p.lde1);
+    a.ld_bias_map = keep_sgpr(p.ld_bias_map); a.co_off = keep_sgpr(p.co_off); a.cout = keep_sgpr(p.cout);
+    a.split = keep_sgpr(p.split); a.epi = keep_sgpr(p.epi); a.alpha = keep_sgpr(p.alpha);
+    a.no_store = p.out_w == -12345;                            // (micro-benchmark ablation, tools/bench_conv.py)
+    const GPtr stat_sum = keep_gptr(p.stat_sum), stat_sq = keep_gptr(p.stat_sq);
+    const int cout_pad = keep_sgpr(p.cout_pad);
     const bool do_stats = !stat_sum.null();
-    const bool no_store = p.out_w == -12345;                   // (micro-benchmark ablation, tools/bench_conv.py)
 
     const int r32 = lane & 31, hh = lane >> 5;
     const int rr = lane >> 3, c4 = (lane & 7) * 4;
+    const int ncol0 = n0 + wn * WCOLS + c4;
+    if (!do_stats) {
+        // tiles in (column tile j, row tile i) order, t = j * TM + i; ST at a time through the staging area
+#pragma unroll
+        for (int t0 = 0; t0 < NT; t0 += ST) {
+#pragma unroll
+            for (int u = 0; u < ST; ++u) {
+                const int j = (t0 + u) / TM, i = (t0 + u) % TM;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    stage[u * STAGE_FLOATS + ((r & 3) + 8 * (r >> 2) + 4 * hh) * STAGE_LD + r32] = acc[i][j][r];
+            }
+            __builtin_amdgcn_wave_barrier();
+            // LP tiles (= 4 LP row groups) at a time: ALL their operand loads (per-pixel bias, h, z) are issued before the
+            // first store of the batch -- see epi_load.  (One batch of 8 row groups costs two load latencies and at most one
+            // store drain; the row-group-at-a-time loop cost one of each per group.)
+            constexpr int LP = (ST >= 2) ? 2 : 1;
+            static_assert(ST % LP == 0, "tile batches");
+#pragma unroll
+            for (int u0 = 0; u0 < ST; u0 += LP) {
+                int64_t mm[LP][4];
+                EpiOps ops[LP][4];
+                int nn[LP];
+                bool nk[LP];
+#pragma unroll
+                for (int d = 0; d < LP; ++d) {
+                    const int j = (t0 + u0 + d) / TM, i = (t0 + u0 + d) % TM;
+                    const int n = ncol0 + j * 32;
+                    nn[d] = n;
+                    nk[d] = n + 3 < a.cout;
+                    const bool any = nk[d] || n < a.cout;
+                    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+                    if (!a.bias.null() && any) bias4 = a.bias.ld4(n);
+#pragma unroll
+                    for (int ps = 0; ps < 4; ++ps) {
+                        mm[d][ps] = any ? rowmap(wm * WROWS + i * 32 + rr + 8 * ps) : -1;
+                        ops[d][ps] = epi_load(a, mm[d][ps] < 0 ? 0 : mm[d][ps], n, nk[d], bias4);
+                    }
+                }
+#pragma unroll
+                for (int d = 0; d < LP; ++d) {
+                    const int nrag = (!nk[d] && nn[d] < a.cout) ? a.cout - nn[d] : 0;
+#pragma unroll
+                    for (int ps = 0; ps < 4; ++ps) {
+                        const f32x4 v = *(const f32x4*)(stage + (u0 + d) * STAGE_FLOATS + (rr + 8 * ps) * STAGE_LD + c4);
+                        if (mm[d][ps] >= 0) epi_finish(a, v, ops[d][ps], mm[d][ps], nn[d], nk[d], nrag);
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        return;
+    }
+    // ---- with InstanceNorm partial statistics (encoder layers; cout % 4 == 0) -----------------------------------------
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * WCOLS + j * 32 + c4;           // first of this lane's 4 channels
-        const bool nok = n + 3 < cout;                         // whole group valid
-        const int nrag = (!nok && n < cout) ? cout - n : 0;    // ragged last group: 1..3 valid channels
+        const int n = ncol0 + j * 32;
+        const bool nok = n + 3 < a.cout;
         f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-        if (!bias.null()) bias4 = bias.ld4(n);
+        if (!a.bias.null()) bias4 = a.bias.ld4(n);
         float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * hh) * STAGE_LD + r32] = acc[i][j][r];
             __builtin_amdgcn_wave_barrier();
-#pragma unroll
+#pragma unroll 1
             for (int ps = 0; ps < 4; ++ps) {
                 const int row = rr + 8 * ps;
                 const int64_t m = rowmap(wm * WROWS + i * 32 + row);
                 const f32x4 v = *(const f32x4*)(stage + row * STAGE_LD + c4);
-                if (m < 0 || !(nok || nrag)) continue;
-                f32x4 y, b4 = bias4;
-                if (!bias_map.null() && nok) b4 = bias_map.ld4(m * ld_bias_map + n);
+                if (m < 0 || !nok) continue;
+                const f32x4 y = epi_finish(a, v, epi_load(a, m, n, true, bias4), m, n, true, 0);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) y[e] = alpha * v[e] + b4[e];
-                if (do_stats) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { ssum[e] += y[e]; ssq[e] += y[e] * y[e]; }
-                }
-                bool stored = no_store;
-                switch (epi) {                                 // (scalar branches on a register: a few cycles)
-                    case WOFT_EPI_RELU:
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) y[e] = fmaxf(y[e], 0.f);
-                        break;
-                    case WOFT_EPI_SIGMOID:
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) y[e] = sigmoidf_(y[e]);
-                        break;
-                    case WOFT_EPI_TANH:
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) y[e] = tanhf(y[e]);
-                        break;
-                    case WOFT_EPI_RELU_RES_RELU: {
-                        const f32x4 res = e0.ld4(m * lde0 + n);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) y[e] = fmaxf(res[e] + fmaxf(y[e], 0.f), 0.f);
-                    } break;
-                    case WOFT_EPI_GRU_ZR:
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) y[e] = sigmoidf_(y[e]);
-                        if (n >= split) {                      // split % 4 == 0 (validated): whole vector is r
-                            const f32x4 hp = e0.ld4(m * lde0 + (n - split));
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) y[e] *= hp[e];
-                            if (!no_store) out1.st4(m * ldo1 + (n - split), y);
-                            stored = true;
-                        }
-                        break;
-                    case WOFT_EPI_GRU_Q: {
-                        const f32x4 z = e1.ld4(m * lde1 + n);
-                        const f32x4 hp = e0.ld4(m * lde0 + n);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) y[e] = (1.f - z[e]) * hp[e] + z[e] * tanhf(y[e]);
-                    } break;
-                    default: break;
-                }
-                if (stored) continue;
-                if (nok) {
-                    out.st4(m * ldo + co_off + n, y);
-                } else {                                       // ragged group (element-wise kinds only)
-#pragma unroll
-                    for (int e = 0; e < 3; ++e)
-                        if (e < nrag) out.st1(m * ldo + co_off + n + e, y[e]);
+                for (int e = 0; e < 4; ++e) {
+                    ssum[e] += y[e];
+                    ssq[e] += y[e] * y[e];
                 }
             }
             __builtin_amdgcn_wave_barrier();
         }
-        if (do_stats) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+            for (int o = 8; o < 64; o <<= 1) {
+                ssum[e] += __shfl_xor(ssum[e], o);
+                ssq[e] += __shfl_xor(ssq[e], o);
+            }
+        }
+        if (rr == 0) {
+            const int64_t row = (int64_t)m_tile * 2 + wm;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-#pragma unroll
-                for (int o = 8; o < 64; o <<= 1) {
-                    ssum[e] += __shfl_xor(ssum[e], o);
-                    ssq[e] += __shfl_xor(ssq[e], o);
-                }
-            }
-            if (rr == 0) {
-                const int64_t row = (int64_t)m_tile * 2 + wm;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    stat_sum.st1(row * cout_pad + n + e, ssum[e]);
-                    stat_sq.st1(row * cout_pad + n + e, ssq[e]);
-                }
+                stat_sum.st1(row * cout_pad + n + e, ssum[e]);
+                stat_sq.st1(row * cout_pad + n + e, ssq[e]);
             }
         }
     }

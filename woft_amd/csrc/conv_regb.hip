@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void conv_regb_kernel(const woft_conv_params p
     constexpr int HX = TX + KX - 1, HY = TY + KY - 1, HROWS = HX * HY;
     constexpr int RH = (HROWS + 31) / 32;
     constexpr int A_PLANE = HROWS * LDB, A_ELEMS = NP * A_PLANE;          // one halo buffer (bf16 elements)
-    constexpr int STAGE_ELEMS = 2 * NWAVES * woft::STAGE_FLOATS;          // epilogue staging (floats -> bf16 units)
+    constexpr int STAGE_ELEMS = 2 * NWAVES * TM * woft::STAGE_FLOATS;     // epilogue staging: all TM tiles of every wave
     constexpr int SMEM_ELEMS = (2 * A_ELEMS > STAGE_ELEMS) ? 2 * A_ELEMS : STAGE_ELEMS;
     constexpr int STEP_ELEMS = NP * 2 * 64 * 8;                           // fragment elements of one K step of a band
     __shared__ __attribute__((aligned(16))) __bf16 smem[SMEM_ELEMS];
@@ -204,8 +204,8 @@ __global__ __launch_bounds__(256) void conv_regb_kernel(const woft_conv_params p
 #pragma unroll
     for (int i = 0; i < TM; ++i) acc2[i][0] = acc[i];
     if (stamps) stamps[14] = __builtin_amdgcn_s_memtime();
-    woft::conv_epilogue_t<TM, 1, WROWS, 32>(p, acc2, (float*)smem + wave * woft::STAGE_FLOATS, rowmap, n0, wm, wn, lane,
-                                            m_tile);
+    woft::conv_epilogue_t<TM, 1, WROWS, 32, TM>(p, acc2, (float*)smem + wave * TM * woft::STAGE_FLOATS, rowmap, n0, wm, wn,
+                                                lane, m_tile);
     if (stamps) stamps[15] = __builtin_amdgcn_s_memtime();
 }
 
