@@ -703,3 +703,51 @@ def test_abi_rejects_bad_arguments(ops):
     assert _lib.load().woft_conv2d(C.byref(p), None) == -1
     lp = _lib.LookupParams()
     assert _lib.load().woft_corr_lookup(C.byref(lp), None) == -1
+
+
+# ------------------------------------------------------------------------------------------
+# how far the "fp32-emulating" claim of the split-bf16 mode carries
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", ["large_activations", "cancelling_weights", "wide_dynamic_range", "tiny_values"])
+def test_bf16x3_stress_against_fp64(ops, case):
+    """bf16x3 = hi*hi + hi*lo + lo*hi with fp32 accumulation: every product carries ~2^-16 relative error (the lo*lo term
+    is dropped, and hi/lo are 8-bit mantissas), so the error of a sum is bounded by ~2^-16 * sum |a_k b_k| -- like fp32's
+    2^-24 * sum |a_k b_k| (accumulation order aside), with a 2^8 larger constant.  The test pins that bound where trained
+    weights could hurt: activations x1e3, weights that cancel to 1e-3 of their magnitude, operands spanning
+    eight decades, operands near the bf16 denormal range -- against an fp64 convolution, side by side with the exact-fp32
+    MFMA mode."""
+    g = torch.Generator().manual_seed(11)
+    n, cin, cout, h, w = 1, 256, 128, 24, 32
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
+    if case == "large_activations":
+        x = x * 1.0e3 + 2.0e3                               # large offset + spread: post-ReLU features of a hot layer
+    elif case == "cancelling_weights":
+        x = x.abs() + 5.0                                   # all-positive activations ...
+        wt = wt - wt.mean(dim=(1, 2, 3), keepdim=True)       # ... against zero-sum filters: the output is the small residue
+        wt = wt + 1e-3 * wt.abs().mean()
+    elif case == "wide_dynamic_range":
+        x = x * torch.pow(10.0, torch.randint(-4, 5, (1, cin, 1, 1), generator=g).float())
+        wt = wt * torch.pow(10.0, -torch.randint(-4, 5, (1, cin, 1, 1), generator=g).float())
+    elif case == "tiny_values":
+        x, wt = x * 1e-18, wt * 1e-12                       # products ~1e-30: lo parts fall into bf16's subnormal range
+    ref = F.conv2d(x.double(), wt.double(), padding=1)
+    mag = F.conv2d(x.double().abs(), wt.double().abs(), padding=1)          # sum |a_k b_k| per output
+    pc = ops.pack_conv(wt, torch.zeros(cout))
+    xa = ops.act_from_nchw(x)
+    errs = {}
+    for prec in ("fp32", "bf16x3"):
+        out = ops.conv2d(xa, pc, precision=prec)
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(out.t).all())
+        errs[prec] = float(((out.nchw().double().cpu() - ref).abs() / mag).max())
+    print(f"{case}: max |err| / sum|a b|   fp32 {errs['fp32']:.2e}   bf16x3 {errs['bf16x3']:.2e}")
+    assert errs["fp32"] < 2.0 ** -18                        # fp32 accumulation of 2304 exact products (8 decades apart in one case)
+    if case == "tiny_values":
+        # the lo planes underflow (bf16 has fp32's exponent range but the residue x - hi is 2^-8 smaller): the mode
+        # degrades gracefully to plain-bf16 accuracy there, it does not blow up
+        assert errs["bf16x3"] < 2.0 ** -7
+    else:
+        assert errs["bf16x3"] < 2.0 ** -14, "split-bf16 products lost more than the dropped lo*lo term explains"
+        # relative to the OUTPUT the error is amplified by the cancellation ratio, exactly as in fp32 (256 x smaller there)
+        assert errs["bf16x3"] < 600 * max(errs["fp32"], 2.0 ** -26)
