@@ -190,8 +190,10 @@ def main():
     results = track_all(tracker, 0, Wm)
     wdist.gather_tracks(results[:1])        # untimed: creates the RCCL communicator / warms the collective
     torch.cuda.synchronize()
-    ROOF_TAG = "convc2"                  # the launch with the largest share of a frame (profiles/): see mfma_roofline
-    plan.lookup_events, plan.wh_events, plan.conv_events = [], [], {ROOF_TAG: []}
+    # the kernel with the largest share of a frame (profiles/r02_bench_kernel_stats_bf16x3.csv): the 3x3 / 64-column
+    # instance of the register-streamed-weights conv kernel = the motion encoder's three 3x3 layers (update.py:83,85,86)
+    ROOF_TAGS = ("convc2", "convf2", "convm")
+    plan.lookup_events, plan.wh_events, plan.conv_events = [], [], {t: [] for t in ROOF_TAGS}
     wdist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -201,7 +203,7 @@ def main():
     wdist.barrier()
     elapsed = time.perf_counter() - t0
     elapsed = wdist.max_over_ranks(elapsed)
-    events, wh_events, conv_events = plan.lookup_events, plan.wh_events, plan.conv_events[ROOF_TAG]
+    events, wh_events, conv_events = plan.lookup_events, plan.wh_events, plan.conv_events
     plan.lookup_events = plan.wh_events = plan.conv_events = None
 
     if rank != 0:
@@ -234,25 +236,35 @@ def main():
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src,
                 "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": lk_avg, "launches_timed": len(lk_ms)}
 
-    def conv_roofline(evs, p, tag):
-        """The launch with the largest share of a frame (profiles/r02_bench_kernel_stats_*.csv): the motion encoder's
-        3x3 conv 256 -> 192 on the 1/8-resolution map (update.py:83,91), 12 launches per frame; matrix-core bound.
-        HIP events around its launches in the timed region, on the stream the kernels are enqueued on."""
-        ms = [s.elapsed_time(e) for s, e in evs]
-        t = float(np.mean(ms)) if ms else float("nan")
-        m, k, n = p._m, p.taps_y * p.taps_x * p.cin_pad, p.cout
-        flops = 2.0 * m * k * n
-        rows = p._m_tiles * 128                                       # rows of the launched 8x16-pixel tiles
-        issued = 2.0 * rows * k * p.cout_pad * terms
+    def conv_roofline(evs_by_tag, layers):
+        """The kernel symbol with the largest share of a frame: conv_regb_kernel<8,16,3,3, 2 x 2 waves> (64-column tiles),
+        i.e. the motion encoder's 3x3 convs on the 1/8-resolution map -- convc2 256->192, convf2 128->64, conv 256->126
+        (update.py:83,85,86,91-96), 36 launches per frame; matrix-core bound.  HIP events around ALL its launches in the timed
+        region (on the stream the kernels are enqueued on): achieved = sum of the launches' 2*M*K*N / sum of their times, so
+        that avg_launch_ms is comparable with the rocprofv3 average of the same symbol."""
+        tot_ms, tot_fl, tot_issued, n_l, per = 0.0, 0.0, 0.0, 0, {}
+        for tag, p in layers.items():
+            ms = [s.elapsed_time(e) for s, e in evs_by_tag.get(tag, [])]
+            if not ms:
+                continue
+            k = p.taps_y * p.taps_x * p.cin_pad
+            fl = 2.0 * p._m * k * p.cout
+            tot_ms += float(np.sum(ms))
+            tot_fl += fl * len(ms)
+            tot_issued += 2.0 * (p._m_tiles * 128) * k * p.cout_pad * terms * len(ms)
+            n_l += len(ms)
+            per[tag] = {"conv": f"3x3 {p.cin_pad}->{p.cout}", "avg_launch_us": 1e3 * float(np.mean(ms)),
+                        "algorithmic_flops_per_launch": fl}
+        p0 = next(iter(layers.values()))
         kern = {8: "conv_regb_kernel<8,16,3,3> (weights streamed global -> registers)", 1: "conv_halo_bf16_kernel<8,16,3,3>",
-                4: "conv_halo_bf16_kernel<4,16,3,3>", 0: "conv_mfma_f32_kernel"}.get(p.halo, f"halo {p.halo}")
-        return {"bound": "mfma", "kernel": f"{tag}: conv 3x3 {p.cin_pad}->{n} on {m} pixels, {kern}, tile_n {p.tile_n}",
-                "achieved": flops / (t * 1e-3) / 1e12, "peak": mfma_peak, "unit": "TFLOP/s",
-                "frac": flops / (t * 1e-3) / 1e12 / mfma_peak, "traffic": None,
-                "matrix_core_issue_frac": issued / (t * 1e-3) / 1e12 / mfma_peak,
-                "algorithmic_flops_per_launch": flops, "mfma_terms_per_product": terms, "avg_launch_ms": t,
-                "launches_timed": len(ms),
-                "note": "frac prices the launch's own 2*M*K*N products against the dense peak of the MFMA type used; the "
+                4: "conv_halo_bf16_kernel<4,16,3,3>", 0: "conv_mfma_f32_kernel"}.get(p0.halo, f"halo {p0.halo}")
+        t = tot_ms * 1e-3
+        return {"bound": "mfma", "kernel": f"{kern}, tile_n {p0.tile_n}: motion-encoder 3x3 convs on {p0._m} pixels",
+                "achieved": tot_fl / t / 1e12, "peak": mfma_peak, "unit": "TFLOP/s", "frac": tot_fl / t / 1e12 / mfma_peak,
+                "traffic": None, "matrix_core_issue_frac": tot_issued / t / 1e12 / mfma_peak,
+                "algorithmic_flops_per_launch": tot_fl / max(n_l, 1), "mfma_terms_per_product": terms,
+                "avg_launch_ms": tot_ms / max(n_l, 1), "launches_timed": n_l, "layers": per,
+                "note": "frac prices the launches' own 2*M*K*N products against the dense peak of the MFMA type used; the "
                         "issue fraction also counts the 3 bf16 MFMAs per fp32-emulating product and tile padding"}
 
     def wh_roofline(evs, layer, P):
@@ -294,23 +306,27 @@ def main():
                    "frames_resident_in_hbm": True},
         "lost_frames": n_lost, "hbm_allocated_peak_gb": peak_gb,
     }
-    conv_p = next((e[1] for e in plan.prog_iter if len(e) > 2 and e[2] == ROOF_TAG), None)
+    layers = {e[2]: e[1] for e in plan.prog_iter if len(e) > 2 and e[2] in ROOF_TAGS}
+    same = {(p_.halo, p_.tile_n, p_.taps_y, p_.taps_x) for p_ in layers.values()}
+    if len(same) > 1:                    # (another resolution / precision picked different kernels: keep the largest layer)
+        layers = {"convc2": layers["convc2"]}
+    have_conv = bool(layers) and any(conv_events.get(t) for t in layers)
     if corr_mode == "volume":
         # the lookup reads the volume: the named HBM-roofline kernel, measured live in the timed region
         out["roofline"] = lookup_roofline(events, plan.P)
-        if conv_p is not None and conv_events:
-            out["roofline_mfma"] = conv_roofline(conv_events, conv_p, ROOF_TAG)
-    elif conv_p is not None and conv_events:
-        # volume-free correlation: no HBM-bound lookup on the path; the dominant launch is a matrix-core conv
+        if have_conv:
+            out["roofline_mfma"] = conv_roofline(conv_events, layers)
+    elif have_conv:
+        # volume-free correlation: no HBM-bound lookup on the path; the dominant kernel is a matrix-core conv
         # (the volume lookup's HBM roofline is measured in the 'alt_corr' pass below -> 'roofline_lookup')
-        out["roofline"] = conv_roofline(conv_events, conv_p, ROOF_TAG)
+        out["roofline"] = conv_roofline(conv_events, layers)
     if bool(getattr(plan, "prog_wh", None)) and wh_events:
         out["roofline_weight_head"] = wh_roofline(wh_events, plan.prog_wh[0], plan.P)
     tc_gpu = {}
     if world == 1:
         _, dst, _ = tracker.flower.compute_flow(template, frames[0], mode="TC", do_sigmoid=True)
         tc_gpu[args.precision] = dst.cpu()
-        if corr_mode == "otf":
+        if corr_mode == "otf" and not args.no_alt_corr:
             # the volume-free lookup's cost depends on the spread of the flow inside an 8x8 block (its result never does):
             # the same kernel on this frame's smooth field (live, above) and on a per-pixel scattered field (+-8 px)
             g = torch.Generator(device="cuda").manual_seed(1)

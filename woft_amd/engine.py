@@ -427,9 +427,9 @@ class _Plan:
         else:                   # BasicMotionEncoder update.py:89-97: cor(192) | flo(64) -> 126, cat flow
             prog += [("conv", cp(self.corr, e.convc1, self.c1, epi=EPI.EPI_RELU), "convc1"),
                      ("conv", cp(self.c1, e.convc2, self.cf, co_off=0, epi=EPI.EPI_RELU), "convc2"),
-                     ("conv", cp(self.flow4, e.convf1, self.fl1, epi=EPI.EPI_RELU)),
-                     ("conv", cp(self.fl1, e.convf2, self.cf, co_off=192, epi=EPI.EPI_RELU)),
-                     ("conv", cp(self.cf, e.convm, self.xbuf, co_off=sp.cdim, epi=EPI.EPI_RELU))]
+                     ("conv", cp(self.flow4, e.convf1, self.fl1, epi=EPI.EPI_RELU), "convf1"),
+                     ("conv", cp(self.fl1, e.convf2, self.cf, co_off=192, epi=EPI.EPI_RELU), "convf2"),
+                     ("conv", cp(self.cf, e.convm, self.xbuf, co_off=sp.cdim, epi=EPI.EPI_RELU), "convm")]
         # GRU half steps: z|r conv (sigmoid, r*h fused), q conv (tanh + state blend fused)
         states = [h_in, self.hA, self.hB] if len(e.zr) == 2 else [h_in, self.hB]
         if len(e.zr) == 1 and not first:
