@@ -30,7 +30,7 @@ if os.environ.get("NOSTORE"):
     p.out_w = -12345
 stamps = None
 if os.environ.get("STAMPS"):
-    stamps = torch.zeros(4096 * 16, dtype=torch.int64, device="cuda")
+    stamps = torch.zeros(4096 * 32, dtype=torch.int64, device="cuda")
     p.in_mean, p.in_rstd = 1, stamps.data_ptr()
 _lib.load().woft_set_tuning(3, int(os.environ.get("DYN_LDS", "0")))
 import time
@@ -50,7 +50,7 @@ print("done", p.halo, p.tile_n)
 if stamps is not None:
     import numpy as np
     nb = p._m_tiles * (p.cout_pad // p.tile_n)
-    st = stamps.cpu().numpy().reshape(-1, 16)[:nb]
+    st = stamps.cpu().numpy().reshape(-1, 32)[:nb]
     t0 = st[:, 0].min()
     start, pro, end = st[:, 0] - t0, st[:, 1] - st[:, 0], st[:, 15] - t0
     nch = p.cin_pad // 32
@@ -61,3 +61,6 @@ if stamps is not None:
     print(f"  first chunk (incl. prologue) med {int(np.median(pro))}; later chunks med {int(np.median(chunks))} "
           f"p10 {int(np.percentile(chunks,10))} p90 {int(np.percentile(chunks,90))}; epilogue med {int(np.median(epi))}")
     print(f"  ticks per us: {end.max() / (ts[6]*1e3):.1f}")
+    ep = st[:, 16:26]
+    d = np.diff(np.concatenate([st[:, 14:15], ep], axis=1), axis=1)
+    print("  epilogue phases (median cycles): entry->", [int(np.median(d[:, k])) for k in range(d.shape[1]) if ep[:, k].max() > 0])

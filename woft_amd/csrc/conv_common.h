@@ -3,6 +3,8 @@
 // fused epilogue.  See conv.hip for the GEMM formulation.
 #pragma once
 #include "common.h"
+#include <utility>
+#include <type_traits>
 
 namespace woft {
 
@@ -149,25 +151,27 @@ struct EpiRegs {
 struct EpiOps {
     f32x4 b4, o0, o1;
 };
+template <int EPI>
 __device__ __forceinline__ EpiOps epi_load(const EpiRegs& a, const int64_t m, const int n, const bool nok, const f32x4 bias4) {
     EpiOps o;
     o.b4 = bias4;
     o.o0 = o.o1 = f32x4{0.f, 0.f, 0.f, 0.f};
     if (!nok) return o;
     if (!a.bias_map.null()) o.b4 = a.bias_map.ld4(m * a.ld_bias_map + n);
-    if (a.epi == WOFT_EPI_RELU_RES_RELU || a.epi == WOFT_EPI_GRU_Q) o.o0 = a.e0.ld4(m * a.lde0 + n);
-    if (a.epi == WOFT_EPI_GRU_ZR && n >= a.split) o.o0 = a.e0.ld4(m * a.lde0 + (n - a.split));
-    if (a.epi == WOFT_EPI_GRU_Q) o.o1 = a.e1.ld4(m * a.lde1 + n);
+    if (EPI == WOFT_EPI_RELU_RES_RELU || EPI == WOFT_EPI_GRU_Q) o.o0 = a.e0.ld4(m * a.lde0 + n);
+    if (EPI == WOFT_EPI_GRU_ZR && n >= a.split) o.o0 = a.e0.ld4(m * a.lde0 + (n - a.split));
+    if (EPI == WOFT_EPI_GRU_Q) o.o1 = a.e1.ld4(m * a.lde1 + n);
     return o;
 }
 // v = this lane's 4 consecutive channels of pixel m; returns y = alpha * v + bias (the value the statistics are taken of)
+template <int EPI>
 __device__ __forceinline__ f32x4 epi_finish(const EpiRegs& a, const f32x4 v, const EpiOps& o, const int64_t m, const int n,
                                             const bool nok, const int nrag) {
     f32x4 y, ypre;
 #pragma unroll
     for (int e = 0; e < 4; ++e) ypre[e] = y[e] = a.alpha * v[e] + o.b4[e];
     bool stored = a.no_store;
-    switch (a.epi) {                                   // (scalar branches on a register: a few cycles)
+    switch (EPI) {                                     // (compile time: the taken path is straight-line and small)
         case WOFT_EPI_RELU:
 #pragma unroll
             for (int e = 0; e < 4; ++e) y[e] = fmaxf(y[e], 0.f);
@@ -211,11 +215,83 @@ __device__ __forceinline__ f32x4 epi_finish(const EpiRegs& a, const f32x4 v, con
     return ypre;
 }
 
+// The row groups of `nst` staged tiles (tile t = t_first + u; column tile j = t / TM, row tile i = t % TM) for ONE epilogue
+// kind.  A real loop over batches of LP tiles: the body is fetched once and then runs from the instruction cache.  (With a
+// run-time `switch (epi)` inside eight unrolled row groups, every group jumped over the unused kinds' sigmoid / tanh
+// expansions -- two or three instruction-cache misses per group: 660 cycles per group of pure ALU work, stamped.)
+// Inside a batch ALL operand loads are issued before the first store (see epi_load).
+template <int EPI, int TM, int WROWS, int LP, typename RowMap>
+__device__ __forceinline__ void epi_tiles(const EpiRegs& a, const float* stage, const RowMap& rowmap, const int t_first,
+                                          const int nst, const int ncol0, const int wm, const int rr, const int c4,
+                                          const bool stats, float (&ssum)[4], float (&ssq)[4]) {
+#pragma unroll 1
+    for (int u0 = 0; u0 < nst; u0 += LP) {
+        int64_t mm[LP][4];
+        EpiOps ops[LP][4];
+        int nn[LP];
+        bool nk[LP];
+#pragma unroll
+        for (int d = 0; d < LP; ++d) {
+            const int t = t_first + u0 + d;
+            const int j = t / TM, i = t - j * TM;
+            const int n = ncol0 + j * 32;
+            nn[d] = n;
+            nk[d] = n + 3 < a.cout;
+            const bool any = nk[d] || n < a.cout;
+            f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+            if (!a.bias.null() && any) bias4 = a.bias.ld4(n);
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                mm[d][ps] = any ? rowmap(wm * WROWS + i * 32 + rr + 8 * ps) : -1;
+                ops[d][ps] = epi_load<EPI>(a, mm[d][ps] < 0 ? 0 : mm[d][ps], n, nk[d], bias4);
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < LP; ++d) {
+            const int nrag = (!nk[d] && nn[d] < a.cout) ? a.cout - nn[d] : 0;
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                const f32x4 v = *(const f32x4*)(stage + (u0 + d) * STAGE_FLOATS + (rr + 8 * ps) * STAGE_LD + c4);
+                if (mm[d][ps] < 0) continue;
+                const f32x4 y = epi_finish<EPI>(a, v, ops[d][ps], mm[d][ps], nn[d], nk[d], nrag);
+                if (stats) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { ssum[e] += y[e]; ssq[e] += y[e] * y[e]; }
+                }
+            }
+        }
+    }
+}
+
+template <int TM, int WROWS, int LP, typename RowMap>
+__device__ __forceinline__ void epi_dispatch(const EpiRegs& a, const float* stage, const RowMap& rowmap, int t_first, int nst,
+                                             int ncol0, int wm, int rr, int c4, bool stats, float (&ssum)[4], float (&ssq)[4]) {
+#define WOFT_EPI_CASE(E) \
+    case E: epi_tiles<E, TM, WROWS, LP>(a, stage, rowmap, t_first, nst, ncol0, wm, rr, c4, stats, ssum, ssq); break
+    switch (a.epi) {
+        WOFT_EPI_CASE(WOFT_EPI_LINEAR);
+        WOFT_EPI_CASE(WOFT_EPI_RELU);
+        WOFT_EPI_CASE(WOFT_EPI_SIGMOID);
+        WOFT_EPI_CASE(WOFT_EPI_TANH);
+        WOFT_EPI_CASE(WOFT_EPI_RELU_RES_RELU);
+        WOFT_EPI_CASE(WOFT_EPI_GRU_ZR);
+        WOFT_EPI_CASE(WOFT_EPI_GRU_Q);
+        default: break;
+    }
+#undef WOFT_EPI_CASE
+}
+
+// ST = accumulator tiles transposed into the wave's LDS staging area at once (the caller provides ST * STAGE_FLOATS floats
+// per wave): all of a wave's tiles when the LDS allows, one at a time otherwise.
 template <int TM, int TN, int WROWS, int WCOLS, int ST = 1, typename RowMap>
 __device__ __forceinline__ void conv_epilogue_t(const woft_conv_params& p, f32x16 (&acc)[TM][TN], float* stage,
-                                                const RowMap& rowmap, int n0, int wm, int wn, int lane, int m_tile) {
+                                                const RowMap& rowmap, int n0, int wm, int wn, int lane, int m_tile,
+                                                unsigned long long* dbg = nullptr) {
     constexpr int NT = TM * TN;
     static_assert(NT % ST == 0, "staged tiles must divide the wave's tiles");
+    int dbg_i = 0;                                             // developer probe: s_memtime stamps of the phases below
+    auto stamp = [&]() { if (dbg) dbg[dbg_i++] = __builtin_amdgcn_s_memtime(); };
+    stamp();
     EpiRegs a;
     a.out = keep_gptr(p.out); a.out1 = keep_gptr(p.out1); a.bias = keep_gptr(p.bias); a.bias_map = keep_gptr(p.bias_map);
     a.e0 = keep_gptr(p.e0); a.e1 = keep_gptr(p.e1);
@@ -230,86 +306,52 @@ __device__ __forceinline__ void conv_epilogue_t(const woft_conv_params& p, f32x1
     const int r32 = lane & 31, hh = lane >> 5;
     const int rr = lane >> 3, c4 = (lane & 7) * 4;
     const int ncol0 = n0 + wn * WCOLS + c4;
+    float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+    stamp();
+    // (compile-time recursion, not `#pragma unroll`: if the optimizer declines to unroll a loop around the seven inlined
+    //  kind instantiations, acc[i][j] becomes a run-time index and the accumulators move to scratch memory -- the 9x9
+    //  weight-head kernel ran 4x slower that way)
+    auto stage_tile = [&](auto t_tag, auto u_tag) {
+        constexpr int t = decltype(t_tag)::value, u = decltype(u_tag)::value;
+        constexpr int j = t / TM, i = t % TM;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            stage[u * STAGE_FLOATS + ((r & 3) + 8 * (r >> 2) + 4 * hh) * STAGE_LD + r32] = acc[i][j][r];
+    };
     if (!do_stats) {
         // tiles in (column tile j, row tile i) order, t = j * TM + i; ST at a time through the staging area
-#pragma unroll
-        for (int t0 = 0; t0 < NT; t0 += ST) {
-#pragma unroll
-            for (int u = 0; u < ST; ++u) {
-                const int j = (t0 + u) / TM, i = (t0 + u) % TM;
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    stage[u * STAGE_FLOATS + ((r & 3) + 8 * (r >> 2) + 4 * hh) * STAGE_LD + r32] = acc[i][j][r];
-            }
-            __builtin_amdgcn_wave_barrier();
-            // LP tiles (= 4 LP row groups) at a time: ALL their operand loads (per-pixel bias, h, z) are issued before the
-            // first store of the batch -- see epi_load.  (One batch of 8 row groups costs two load latencies and at most one
-            // store drain; the row-group-at-a-time loop cost one of each per group.)
-            constexpr int LP = (ST >= 2) ? 2 : 1;
-            static_assert(ST % LP == 0, "tile batches");
-#pragma unroll
-            for (int u0 = 0; u0 < ST; u0 += LP) {
-                int64_t mm[LP][4];
-                EpiOps ops[LP][4];
-                int nn[LP];
-                bool nk[LP];
-#pragma unroll
-                for (int d = 0; d < LP; ++d) {
-                    const int j = (t0 + u0 + d) / TM, i = (t0 + u0 + d) % TM;
-                    const int n = ncol0 + j * 32;
-                    nn[d] = n;
-                    nk[d] = n + 3 < a.cout;
-                    const bool any = nk[d] || n < a.cout;
-                    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-                    if (!a.bias.null() && any) bias4 = a.bias.ld4(n);
-#pragma unroll
-                    for (int ps = 0; ps < 4; ++ps) {
-                        mm[d][ps] = any ? rowmap(wm * WROWS + i * 32 + rr + 8 * ps) : -1;
-                        ops[d][ps] = epi_load(a, mm[d][ps] < 0 ? 0 : mm[d][ps], n, nk[d], bias4);
-                    }
-                }
-#pragma unroll
-                for (int d = 0; d < LP; ++d) {
-                    const int nrag = (!nk[d] && nn[d] < a.cout) ? a.cout - nn[d] : 0;
-#pragma unroll
-                    for (int ps = 0; ps < 4; ++ps) {
-                        const f32x4 v = *(const f32x4*)(stage + (u0 + d) * STAGE_FLOATS + (rr + 8 * ps) * STAGE_LD + c4);
-                        if (mm[d][ps] >= 0) epi_finish(a, v, ops[d][ps], mm[d][ps], nn[d], nk[d], nrag);
-                    }
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
+        constexpr int LP = (ST % 2 == 0) ? 2 : 1;
+        [&]<int... B>(std::integer_sequence<int, B...>) {
+            ([&] {
+                constexpr int t0 = B * ST;
+                [&]<int... U>(std::integer_sequence<int, U...>) {
+                    (stage_tile(std::integral_constant<int, t0 + U>{}, std::integral_constant<int, U>{}), ...);
+                }(std::make_integer_sequence<int, ST>{});
+                __builtin_amdgcn_wave_barrier();
+                stamp();
+                epi_dispatch<TM, WROWS, LP>(a, stage, rowmap, t0, ST, ncol0, wm, rr, c4, false, ssum, ssq);
+                stamp();
+                __builtin_amdgcn_wave_barrier();
+            }(), ...);
+        }(std::make_integer_sequence<int, NT / ST>{});
         return;
     }
-    // ---- with InstanceNorm partial statistics (encoder layers; cout % 4 == 0) -----------------------------------------
+    // ---- with InstanceNorm partial statistics (encoder layers; cout % 4 == 0): per column tile j, the statistics of
+    //      y = alpha * acc + bias over this wave's rows
+    [&]<int... J>(std::integer_sequence<int, J...>) {
+    ([&] {
+        constexpr int j = J;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
+        for (int e = 0; e < 4; ++e) ssum[e] = ssq[e] = 0.f;
+        [&]<int... I>(std::integer_sequence<int, I...>) {
+            ([&] {
+                stage_tile(std::integral_constant<int, j * TM + I>{}, std::integral_constant<int, 0>{});
+                __builtin_amdgcn_wave_barrier();
+                epi_dispatch<TM, WROWS, 1>(a, stage, rowmap, j * TM + I, 1, ncol0, wm, rr, c4, true, ssum, ssq);
+                __builtin_amdgcn_wave_barrier();
+            }(), ...);
+        }(std::make_integer_sequence<int, TM>{});
         const int n = ncol0 + j * 32;
-        const bool nok = n + 3 < a.cout;
-        f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-        if (!a.bias.null()) bias4 = a.bias.ld4(n);
-        float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * hh) * STAGE_LD + r32] = acc[i][j][r];
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll 1
-            for (int ps = 0; ps < 4; ++ps) {
-                const int row = rr + 8 * ps;
-                const int64_t m = rowmap(wm * WROWS + i * 32 + row);
-                const f32x4 v = *(const f32x4*)(stage + row * STAGE_LD + c4);
-                if (m < 0 || !nok) continue;
-                const f32x4 y = epi_finish(a, v, epi_load(a, m, n, true, bias4), m, n, true, 0);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    ssum[e] += y[e];
-                    ssq[e] += y[e] * y[e];
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
 #pragma unroll
@@ -326,7 +368,8 @@ __device__ __forceinline__ void conv_epilogue_t(const woft_conv_params& p, f32x1
                 stat_sq.st1(row * cout_pad + n + e, ssq[e]);
             }
         }
-    }
+    }(), ...);
+    }(std::make_integer_sequence<int, TN>{});
 }
 
 template <int BM, int BN>

@@ -28,7 +28,7 @@ namespace {
 using woft::BK;
 
 template <int TY, int TX, int KY, int KX, int WM, int TERMS, int NBUF, int DIST, int AD>
-__global__ __launch_bounds__(256) void conv_regb_kernel(const woft_conv_params p) {
+__global__ __launch_bounds__(256, 2) void conv_regb_kernel(const woft_conv_params p) {
     constexpr int NWAVES = 4;
     constexpr int NPIX = TY * TX;
     constexpr int BM = (NPIX + 31) / 32 * 32;
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void conv_regb_kernel(const woft_conv_params p
 
     // developer probe (tools/regb_probe.py): s_memtime stamps of wave 0 -> in_rstd (unused by this kernel otherwise)
     unsigned long long* stamps = (p.in_mean == (const float*)1 && wave == 0 && lane == 0)
-                                     ? (unsigned long long*)p.in_rstd + (size_t)blockIdx.x * 16 : nullptr;
+                                     ? (unsigned long long*)p.in_rstd + (size_t)blockIdx.x * 32 : nullptr;
     if (stamps) stamps[0] = __builtin_amdgcn_s_memtime();
     // ---- prologue: halo of chunk 0, the first DIST steps of the weight stream ---------------------------------
     load_halo(0);
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void conv_regb_kernel(const woft_conv_params p
     for (int i = 0; i < TM; ++i) acc2[i][0] = acc[i];
     if (stamps) stamps[14] = __builtin_amdgcn_s_memtime();
     woft::conv_epilogue_t<TM, 1, WROWS, 32, TM>(p, acc2, (float*)smem + wave * TM * woft::STAGE_FLOATS, rowmap, n0, wm, wn,
-                                                lane, m_tile);
+                                                lane, m_tile, stamps ? stamps + 16 : nullptr);
     if (stamps) stamps[15] = __builtin_amdgcn_s_memtime();
 }
 
