@@ -64,3 +64,9 @@ if stamps is not None:
     ep = st[:, 16:26]
     d = np.diff(np.concatenate([st[:, 14:15], ep], axis=1), axis=1)
     print("  epilogue phases (median cycles): entry->", [int(np.median(d[:, k])) for k in range(d.shape[1]) if ep[:, k].max() > 0])
+    rt = (st[:, 31] - st[:, 30]).astype(np.float64)          # s_memrealtime: constant 100 MHz
+    cyc = (st[:, 15] - st[:, 0]).astype(np.float64)
+    ok = rt > 0
+    print(f"  shader clock while the workgroups ran: {np.median(cyc[ok] / rt[ok]) * 100:.0f} MHz (s_memtime / s_memrealtime); "
+          f"median workgroup {np.median(rt[ok]) / 100:.1f} us of a {ts[6]*1e3:.1f} us launch; "
+          f"first start -> last end {(st[:,31].max() - st[:,30].min()) / 100:.1f} us")

@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256, 2) void conv_regb_kernel(const woft_conv_param
     // developer probe (tools/regb_probe.py): s_memtime stamps of wave 0 -> in_rstd (unused by this kernel otherwise)
     unsigned long long* stamps = (p.in_mean == (const float*)1 && wave == 0 && lane == 0)
                                      ? (unsigned long long*)p.in_rstd + (size_t)blockIdx.x * 32 : nullptr;
-    if (stamps) stamps[0] = __builtin_amdgcn_s_memtime();
+    if (stamps) { stamps[0] = __builtin_amdgcn_s_memtime(); stamps[30] = __builtin_amdgcn_s_memrealtime(); }
     // ---- prologue: halo of chunk 0, the first DIST steps of the weight stream ---------------------------------
     load_halo(0);
     [&]<int... S>(std::integer_sequence<int, S...>) {
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void conv_regb_kernel(const woft_conv_param
     if (stamps) stamps[14] = __builtin_amdgcn_s_memtime();
     woft::conv_epilogue_t<TM, 1, WROWS, 32, TM>(p, acc2, (float*)smem + wave * TM * woft::STAGE_FLOATS, rowmap, n0, wm, wn,
                                                 lane, m_tile, stamps ? stamps + 16 : nullptr);
-    if (stamps) stamps[15] = __builtin_amdgcn_s_memtime();
+    if (stamps) { stamps[15] = __builtin_amdgcn_s_memtime(); stamps[31] = __builtin_amdgcn_s_memrealtime(); }
 }
 
 template <int WM>
