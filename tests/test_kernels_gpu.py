@@ -751,3 +751,31 @@ def test_bf16x3_stress_against_fp64(ops, case):
         assert errs["bf16x3"] < 2.0 ** -14, "split-bf16 products lost more than the dropped lo*lo term explains"
         # relative to the OUTPUT the error is amplified by the cancellation ratio, exactly as in fp32 (256 x smaller there)
         assert errs["bf16x3"] < 600 * max(errs["fp32"], 2.0 ** -26)
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("cin,cout,h,w,epi", [(352, 256, 19, 37, "relu"), (256, 576, 17, 25, "linear"), (128, 126, 9, 16, "relu")])
+def test_conv_1x1_register_streamed(ops, precision, cin, cout, h, w, epi):
+    """1x1 stride-1 layers (update.py:82 convc1, :124 mask head; extractor.py:147 conv2) on conv_regb_kernel with the tap
+    dimension collapsed (three 32-channel chunks per unrolled group): against fp64 torch and against the per-tap gather
+    kernel (halo 0), incl. a ragged channel count and a K that is not a multiple of three chunks."""
+    x = F.relu(_rand(1, cin, h, w, seed=70)) + 0.1
+    wt = _rand(cout, cin, 1, 1, seed=71, scale=1 / math.sqrt(cin))
+    b = _rand(cout, seed=72, scale=0.1)
+    ref = F.conv2d(x.double(), wt.double(), b.double()).float()
+    if epi == "relu":
+        ref = F.relu(ref)
+    code = ops._lib.EPI_RELU if epi == "relu" else ops._lib.EPI_LINEAR
+    pc = ops.pack_conv(wt, b)
+    xa = ops.act_from_nchw(x, cs=ops._round_up(cin, 32))
+    outs = {}
+    for halo in (8, 0):
+        out = ops.new_act(1, h, w, cout, cs=ops._round_up(cout, 4) + 8, zero=True)
+        p = ops.conv_params(xa, pc, out, epi=code, precision=precision, halo=halo)
+        assert p.halo == halo and (halo == 0 or p.tile_n == 64)
+        ops.run_conv(p)
+        torch.cuda.synchronize()
+        outs[halo] = out
+        _close(out.nchw(), ref, 1e-4 if precision == "bf16x3" else 3e-2, what=f"1x1 halo {p.halo}")
+        assert float(out.t[:, cout:].abs().max()) == 0.0
+    assert float((outs[8].t - outs[0].t).abs().max()) < 2e-5

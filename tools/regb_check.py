@@ -17,7 +17,8 @@ def main():
         for name, cin, x2c, cout, kh, kw, epi in (
                 ("gru zr 1x5", 128, 128, 256, 1, 5, _lib.EPI_RELU), ("gru q 5x1", 128, 128, 128, 5, 1, _lib.EPI_TANH),
                 ("convc2 3x3", 256, 0, 192, 3, 3, _lib.EPI_RELU), ("fh1 3x3", 128, 0, 256, 3, 3, _lib.EPI_RELU),
-                ("conv 3x3 256->126", 256, 0, 126, 3, 3, _lib.EPI_RELU), ("convf2 3x3 128->64", 128, 0, 64, 3, 3, _lib.EPI_RELU)):
+                ("conv 3x3 256->126", 256, 0, 126, 3, 3, _lib.EPI_RELU), ("convf2 3x3 128->64", 128, 0, 64, 3, 3, _lib.EPI_RELU),
+                ("convc1 1x1 352->256", 352, 0, 256, 1, 1, _lib.EPI_RELU), ("mask 1x1 256->576", 256, 0, 576, 1, 1, _lib.EPI_LINEAR)):
             wt = torch.randn(cout, cin + x2c, kh, kw) * 0.05
             pc = ops.pack_conv(wt, torch.randn(cout) * 0.1, padding=(kh // 2, kw // 2))
             x = ops.new_act(1, hf, wf, cin)
@@ -27,7 +28,7 @@ def main():
                 x2 = ops.new_act(1, hf, wf, x2c)
                 x2.t.normal_()
             outs, ts, tl = [], [], []
-            for halo, tiles in ((None, None), (8, None), (8, (128, 64))):
+            for halo, tiles in (((0 if kh * kw == 1 else 1), None), (8, None), (8, (128, 64))):
                 out = ops.new_act(1, hf, wf, cout, cs=ops._round_up(cout, 4), zero=True)
                 p = ops.conv_params(x, pc, out, x2=x2, c_split=cin if x2c else 0, epi=epi, precision=prec, halo=halo,
                                     tiles=tiles)

@@ -27,7 +27,7 @@ namespace {
 
 using woft::BK;
 
-template <int TY, int TX, int KY, int KX, int WM, int TERMS, int NBUF, int DIST, int AD>
+template <int TY, int TX, int KY, int KX, int WM, int TERMS, int NBUF, int DIST, int AD, int CU = 1, int HD = 1>
 __global__ __launch_bounds__(256, 2) void conv_regb_kernel(const woft_conv_params p) {
     constexpr int NWAVES = 4;
     constexpr int NPIX = TY * TX;
@@ -38,7 +38,10 @@ __global__ __launch_bounds__(256, 2) void conv_regb_kernel(const woft_conv_param
     constexpr int TM = WROWS / 32;
     constexpr int NP = (TERMS == 3) ? 2 : 1;
     constexpr int TAPS = KY * KX;
-    static_assert(TAPS % NBUF == 0 && DIST >= 1 && DIST < NBUF, "register ring: static slots need TAPS % NBUF == 0");
+    // CU: chunks per unrolled group (the ring slot of step s = chunk * TAPS + tap must be a compile-time constant:
+    // (CU * TAPS) % NBUF == 0; multi-tap layers: CU = 1, TAPS % NBUF == 0; 1x1 layers: TAPS = 1, CU = NBUF).
+    // HD: how many chunks ahead the input tile is requested (1x1: a chunk is a single K step, too short to cover HBM latency)
+    static_assert((CU * TAPS) % NBUF == 0 && DIST >= 1 && DIST < NBUF && CU % HD == 0, "register ring: static slots");
     static_assert(BM % (32 * WM) == 0, "bad wave layout");
     constexpr int HX = TX + KX - 1, HY = TY + KY - 1, HROWS = HX * HY;
     constexpr int RH = (HROWS + 31) / 32;
@@ -75,22 +78,24 @@ __global__ __launch_bounds__(256, 2) void conv_regb_kernel(const woft_conv_param
         hok[j] = ht < HROWS && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w;
         hpix[j] = hok[j] ? (img0 * p.h + iy) * p.w + ix : 0;
     }
-    f32x4 rh[RH];
-    auto load_halo = [&](int chunk) {
+    f32x4 rh[HD][RH];                                    // ring: the input tile of chunk c waits in rh[c % HD]
+    auto load_halo = [&](int chunk, auto slot_tag) {
+        constexpr int hs = decltype(slot_tag)::value;
         const int c0 = chunk * BK;
         const bool second = (p.in1 != nullptr) && (c0 >= p.c_split);
         const float* src = (second ? p.in1 + (c0 - p.c_split) : p.in0 + c0) + 4 * v;
         const int cs = second ? p.cs1 : p.cs0;
 #pragma unroll
-        for (int j = 0; j < RH; ++j) rh[j] = *(const f32x4*)(src + (uint32_t)(hpix[j] * cs));
+        for (int j = 0; j < RH; ++j) rh[hs][j] = *(const f32x4*)(src + (uint32_t)(hpix[j] * cs));
     };
-    auto store_halo = [&](__bf16* As) {
+    auto store_halo = [&](__bf16* As, auto slot_tag) {
+        constexpr int hs = decltype(slot_tag)::value;
 #pragma unroll
         for (int j = 0; j < RH; ++j) {
             const int ht = r0 + 32 * j;
             if (RH * 32 > HROWS && ht >= HROWS) continue;
             const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-            const f32x4 val = hok[j] ? rh[j] : zero;
+            const f32x4 val = hok[j] ? rh[hs][j] : zero;
             const bf16x4 hi = __builtin_convertvector(val, bf16x4);
             *(bf16x4*)(As + ht * LDB + 4 * v) = hi;
             if (NP == 2) {
@@ -132,11 +137,13 @@ __global__ __launch_bounds__(256, 2) void conv_regb_kernel(const woft_conv_param
                                      ? (unsigned long long*)p.in_rstd + (size_t)blockIdx.x * 32 : nullptr;
     if (stamps) { stamps[0] = __builtin_amdgcn_s_memtime(); stamps[30] = __builtin_amdgcn_s_memrealtime(); }
     // ---- prologue: halo of chunk 0, the first DIST steps of the weight stream ---------------------------------
-    load_halo(0);
+    [&]<int... C>(std::integer_sequence<int, C...>) {
+        ((C < nchunk ? load_halo(C, std::integral_constant<int, C % HD>{}) : (void)0), ...);
+    }(std::make_integer_sequence<int, HD>{});
     [&]<int... S>(std::integer_sequence<int, S...>) {
         (fetch_b(S, std::integral_constant<int, S % NBUF>{}), ...);
     }(std::make_integer_sequence<int, DIST>{});
-    store_halo(smem);
+    store_halo(smem, std::integral_constant<int, 0>{});
     __syncthreads();
 
     // One 32-channel chunk = TAPS K steps, fully unrolled into "pairs": (tap, k half, two row tiles) = 4 (2 in plain
@@ -147,8 +154,9 @@ __global__ __launch_bounds__(256, 2) void conv_regb_kernel(const woft_conv_param
     // busy while LDS, L1 and L2 were all under 30 % busy).
     constexpr int PT = TM, NQ = TAPS * PT, AR = AD + 1;                  // pairs per tap / per chunk
     static_assert(TM % 2 == 0, "row tiles are processed in pairs");
-    auto run_chunk = [&](int chunk, auto more_tag) {
+    auto run_chunk = [&](int chunk, auto more_tag, auto phase_tag) {
         constexpr bool more = decltype(more_tag)::value;
+        constexpr int phase = decltype(phase_tag)::value;                // chunk % CU
         const __bf16* As = smem + (chunk & 1) * A_ELEMS;
         bf16x8 aq[AR][2][NP];
         auto load_a = [&](auto q_tag) {
@@ -168,11 +176,12 @@ __global__ __launch_bounds__(256, 2) void conv_regb_kernel(const woft_conv_param
             ([&] {
                 constexpr int q = Q;
                 constexpr int tap = q / PT, r = q % PT, s2 = r / (TM / 2), i0 = 2 * (r % (TM / 2));
-                constexpr int slot = tap % NBUF, as = q % AR;
+                constexpr int slot = (phase * TAPS + tap) % NBUF, as = q % AR;
                 if constexpr (r == 0) {
                     // weights of step (chunk, tap) + DIST into the slot that step (chunk, tap) - (NBUF - DIST) vacated
-                    fetch_b(chunk * TAPS + tap + DIST, std::integral_constant<int, (tap + DIST) % NBUF>{});
-                    if (tap == 0 && more) load_halo(chunk + 1);
+                    fetch_b(chunk * TAPS + tap + DIST, std::integral_constant<int, (phase * TAPS + tap + DIST) % NBUF>{});
+                    // input tile of chunk + HD into the ring slot chunk's own tile left at the end of the previous chunk
+                    if (tap == 0 && chunk + HD < nchunk) load_halo(chunk + HD, std::integral_constant<int, phase % HD>{});
                 }
                 if constexpr (q + AD < NQ) load_a(std::integral_constant<int, q + AD>{});
                 __builtin_amdgcn_sched_barrier(0);
@@ -188,15 +197,25 @@ __global__ __launch_bounds__(256, 2) void conv_regb_kernel(const woft_conv_param
                 // next chunk's halo -> the other buffer (free since the barrier that ended the previous chunk); late
                 // in the chunk so that its loads had the whole chunk to land
                 if constexpr (q == NQ - 1) {
-                    if (more) store_halo(smem + ((chunk + 1) & 1) * A_ELEMS);
+                    if (more) store_halo(smem + ((chunk + 1) & 1) * A_ELEMS, std::integral_constant<int, (phase + 1) % HD>{});
                 }
             }(), ...);
         }(std::make_integer_sequence<int, NQ>{});
         if (more) __syncthreads();
         if (stamps && chunk < 12) stamps[1 + chunk] = __builtin_amdgcn_s_memtime();
     };
-    for (int chunk = 0; chunk + 1 < nchunk; ++chunk) run_chunk(chunk, std::true_type{});
-    run_chunk(nchunk - 1, std::false_type{});
+    auto run_phase = [&](int chunk, auto more_tag) {     // chunk % CU selects the unrolled body with the right ring slots
+        if constexpr (CU == 1) {
+            run_chunk(chunk, more_tag, std::integral_constant<int, 0>{});
+        } else {
+            const int ph = chunk % CU;
+            [&]<int... P>(std::integer_sequence<int, P...>) {
+                ((ph == P ? run_chunk(chunk, more_tag, std::integral_constant<int, P>{}) : (void)0), ...);
+            }(std::make_integer_sequence<int, CU>{});
+        }
+    };
+    for (int chunk = 0; chunk + 1 < nchunk; ++chunk) run_phase(chunk, std::true_type{});
+    run_phase(nchunk - 1, std::false_type{});
     __syncthreads();                                     // halo buffers are dead: reuse them as epilogue staging
 
     const HaloRowMap<TY, TX> rowmap{img0, p.n_img, y0, x0, p.ho, p.wo};
@@ -221,7 +240,12 @@ int launch_regb(const woft_conv_params& p, hipStream_t s) {
     if (p.taps_y == 3 && p.taps_x == 3) REGB(3, 3, T, 3, 2);             \
     else if (p.taps_y == 1 && p.taps_x == 5) REGB(1, 5, T, 5, 3);        \
     else if (p.taps_y == 5 && p.taps_x == 1) REGB(5, 1, T, 5, 3);        \
-    else return WOFT_EINVAL
+    else if (p.taps_y == 1 && p.taps_x == 1) {    /* 1x1: three chunks per unrolled group, input tile three chunks ahead; \
+                                                     64-column tiles only (the 128-column layout does not fit 256 registers) */ \
+        if constexpr (WM == 2)                                                                                                  \
+            hipLaunchKernelGGL((conv_regb_kernel<TY, TX, 1, 1, WM, T, 3, 2, 1, 3, 3>), grid, dim3(256), (size_t)g_regb_dyn_lds, s, p); \
+        else return WOFT_EINVAL;                                                                                                \
+    } else return WOFT_EINVAL
     if (p.precision == 1) { REGB_TAPS(3); } else { REGB_TAPS(1); }
 #undef REGB_TAPS
 #undef REGB

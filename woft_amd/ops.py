@@ -156,6 +156,7 @@ def fold_bn(weight, bias, bn_w, bn_b, mean, var, eps=1e-5):
 PRECISION = {"fp32": 0, "bf16x3": 1, "bf16": 2}
 USE_HALO = os.environ.get("WOFT_HALO", "1") != "0"
 USE_REGB = os.environ.get("WOFT_REGB", "1") != "0"
+USE_REGB1 = os.environ.get("WOFT_REGB1", "0") != "0"      # (measured: 45 vs 37 us on convc1 -- the 64 x 64 gather tiles win)
 HALO_TILES = {1: (8, 16, 1), 2: (9, 9, 1), 4: (4, 16, 1), 6: (6, 16, 1), 8: (8, 16, 1)}     # (TY, TX, images per workgroup)
 HALO_MIN_BLOCKS = int(os.environ.get("WOFT_HALO_MIN_BLOCKS", "400"))
 WH_HALO = int(os.environ.get("WOFT_WH_HALO", "2"))
@@ -256,15 +257,25 @@ def conv_params(x, pc, out, co_off=0, epi=_lib.EPI_LINEAR, x2=None, c_split=0, e
     if USE_REGB and auto_halo and halo in (1, 4) and tiles is None and stats is None and not in_norm and p.precision != 0:
         p.tile_n = tn = (p.tile_n if halo == 1 else 64)
         halo = 8
+    # 1x1 stride-1 layers (motion encoder convc1, mask head, encoder outputs) CAN run on the same kernel with the "taps"
+    # dimension collapsed -- three chunks per unrolled group, 64-column tiles (halo=8 explicitly, or WOFT_REGB1=1); bit-identical
+    # but 10-20 % slower than the gather kernel's 64 x 64 tiles on these short-K layers, so it is not the default
+    if USE_REGB1 and auto_halo and halo == 0 and tiles is None and stats is None and not in_norm and p.precision != 0 \
+            and not pc.flat and pc.stride == 1 and (pc.taps_y, pc.taps_x) == (1, 1) and (ho, wo) == (x.h, x.w) \
+            and x.h >= 8 and x.w >= 16 and x2 is None:
+        p.tile_n = tn = 64
+        halo = 8
     p.halo = halo
     p.wgt_frag = None
     if halo == 8:                       # weights streamed to registers in MFMA-fragment order (conv_regb.hip)
         assert p.precision != 0 and not pc.flat and pc.stride == 1 and not in_norm
-        assert (pc.taps_y, pc.taps_x) in ((3, 3), (1, 5), (5, 1)) and (ho, wo) == (x.h, x.w)
+        assert (pc.taps_y, pc.taps_x) in ((3, 3), (1, 5), (5, 1), (1, 1)) and (ho, wo) == (x.h, x.w)
         frag = pc.frag(2 if p.precision == 1 else 1)
         p.wgt_frag = ptr(frag)
         if tiles is None and p.tile_n not in (64, 128):
             p.tile_n = 128 if pc.cout_pad % 128 == 0 else 64
+        if pc.taps_y * pc.taps_x == 1:
+            p.tile_n = 64
         if p.tile_n == 128 and pc.cout_pad % 128 != 0:
             p.tile_n = 64
         p.cout_pad = pc.cout_pad if stats is not None else _round_up(p.cout, p.tile_n)
