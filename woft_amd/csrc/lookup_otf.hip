@@ -33,7 +33,12 @@ __global__ __launch_bounds__(TW * 32, 2) void corr_lookup_otf_kernel(const woft_
     constexpr int LD = (TERMS == 3) ? 2 * K : K;        // elements per operand row
     constexpr int NK = LD / 64;                         // K steps (one 128-byte line each)
     constexpr int NSUB = (TERMS == 3) ? 2 : 4;          // MFMA k sub-steps per line
-    constexpr int NST = 6, DEPTH = 5;                   // LDS ring: DEPTH steps of B rows in flight (latency from beyond L2)
+    // LDS ring of B rows: NST stages of one K step each, consumed GS steps per workgroup barrier, DEPTH groups in flight
+    // beyond the one being computed (latency from beyond L2).  (Round 1 synchronised after every step, 6 MFMAs per wave;
+    // halving the barriers changed nothing measurable -- 95.2 vs 95.4 fps in one call: the kernel is paced by the stream
+    // of target rows from beyond L2, not by its barriers.)
+    constexpr int GS = 2, NGRP = 3, NST = GS * NGRP, DEPTH = NGRP - 1;
+    static_assert(NK % GS == 0, "K steps per chunk must be a multiple of the steps per barrier");
     __shared__ __attribute__((aligned(16))) __bf16 stage[NST * 64 * 64];    // NST stages of 64 B rows, 128 B each
     constexpr int WS = NW + 1, WLD = WS * WS + 1;       // (2r+2)^2 window of a pixel (+1: spreads the LDS banks)
     __shared__ float Wn[NPX * WLD];                     // the windows of the source pixels at the current level
@@ -142,7 +147,7 @@ __global__ __launch_bounds__(TW * 32, 2) void corr_lookup_otf_kernel(const woft_
 
         const char* f2 = (const char*)p.f2[l];
         // ---- K steps of all 64-column chunks of the box as ONE stream through an LDS ring: the B rows of step
-        //      s + DEPTH are requested while step s computes (one workgroup barrier per step) ----
+        //      of group g + DEPTH are requested while group g computes (one workgroup barrier per GS steps) ----
         const int nchunk = (N + 63) / 64;
         const int S = nchunk * nk;
         uint32_t b_off[2] = {0u, 0u};
@@ -162,41 +167,49 @@ __global__ __launch_bounds__(TW * 32, 2) void corr_lookup_otf_kernel(const woft_
             for (int t = 0; t < QPW; ++t) lds_dma16(f2 + is_k * 128, b_off[t], st + (uint32_t)(wave + NWV * t) * 1024u);
             if (++is_k == nk) { is_k = 0; ++is_c; }
         };
-        for (int s_idx = 0; s_idx < DEPTH && s_idx < S; ++s_idx) issue(s_idx);
+        const int G = S / GS;                            // groups of GS steps (S = nchunk * NK, NK % GS == 0)
+        for (int g = 0; g < DEPTH && g < G; ++g)
+#pragma unroll
+            for (int e = 0; e < GS; ++e) issue(g * GS + e);
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         int c0 = 0;
         for (int s0 = 0; s0 < S; s0 += NK) {             // one 64-column chunk per iteration, K steps unrolled
 #pragma unroll
-            for (int ks = 0; ks < NK; ++ks) {
-                const int s_idx = s0 + ks;
-                // this step's two pieces have landed; those of the following (up to DEPTH - 1) steps may still fly
-                const int rem = S - 1 - s_idx;
-                if (rem >= 4) dma_wait<4 * QPW>();
-                else if (rem == 3) dma_wait<3 * QPW>();
-                else if (rem == 2) dma_wait<2 * QPW>();
-                else if (rem == 1) dma_wait<QPW>();
+            for (int kg = 0; kg < NK / GS; ++kg) {
+                const int g = s0 / GS + kg;
+                // this group's pieces have landed; those of the following (up to DEPTH - 1) groups may still fly
+                const int rem = G - 1 - g;
+                if (rem >= DEPTH - 1) dma_wait<(DEPTH - 1) * GS * QPW>();
                 else dma_wait<0>();
-                __syncthreads();                         // ... for every wave; and step s - 1 is fully consumed
-                if (s_idx + DEPTH < S) issue(s_idx + DEPTH);     // into the stage of step s - 1
-                const __bf16* br = b_rows + (s_idx % NST) * 4096;
-                if (TERMS == 3) {
+                __syncthreads();                         // ... for every wave; and group g - 1 is fully consumed
+                if (g + DEPTH < G) {                     // into the stages of group g - 1
 #pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2) {
-                        const int ch = ((s2 * 2 + hh) ^ sw) * 8, cl = ((4 + s2 * 2 + hh) ^ sw) * 8;
-                        const bf16x8 bh = *(const bf16x8*)(br + ch), bl = *(const bf16x8*)(br + cl);
-                        const bf16x8 ah = afr[ks][s2][0], al = afr[ks][s2][TERMS == 3 ? 1 : 0];
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);   // (order of corr_gemm_bf16_kernel)
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
-                    }
-                } else {
+                    for (int e = 0; e < GS; ++e) issue((g + DEPTH) * GS + e);
+                }
 #pragma unroll
-                    for (int s2 = 0; s2 < 4; ++s2) {
-                        const int ch = ((s2 * 2 + hh) ^ sw) * 8;
-                        const bf16x8 bh = *(const bf16x8*)(br + ch);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks][s2][0], bh, acc, 0, 0, 0);
+                for (int e = 0; e < GS; ++e) {
+                    const int ks = kg * GS + e;
+                    const int s_idx = s0 + ks;
+                    const __bf16* br = b_rows + (s_idx % NST) * 4096;
+                    if (TERMS == 3) {
+#pragma unroll
+                        for (int s2 = 0; s2 < 2; ++s2) {
+                            const int ch = ((s2 * 2 + hh) ^ sw) * 8, cl = ((4 + s2 * 2 + hh) ^ sw) * 8;
+                            const bf16x8 bh = *(const bf16x8*)(br + ch), bl = *(const bf16x8*)(br + cl);
+                            const bf16x8 ah = afr[ks][s2][0], al = afr[ks][s2][TERMS == 3 ? 1 : 0];
+                            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);   // (order of corr_gemm_bf16_kernel)
+                            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+                        }
+                    } else {
+#pragma unroll
+                        for (int s2 = 0; s2 < 4; ++s2) {
+                            const int ch = ((s2 * 2 + hh) ^ sw) * 8;
+                            const bf16x8 bh = *(const bf16x8*)(br + ch);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks][s2][0], bh, acc, 0, 0, 0);
+                        }
                     }
                 }
             }
@@ -255,7 +268,8 @@ extern "C" int woft_corr_lookup_otf(const woft_lookup_otf_params* pp, void* stre
     if (p.ldo < nout) return WOFT_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     // 8 x 8 source pixels per workgroup.  (TW = 16: 40 % less target-row traffic, but one 8-wave workgroup per CU and
-    // 20 % more steps per workgroup: measured 110 vs 98 us at 1080p -- the per-workgroup chain of K steps binds.)
+    // 20 % more steps per workgroup: measured 110 vs 98 us at 1080p in round 1, -1.7 % frames/s in round 2 with two steps
+    // per barrier -- the per-workgroup chain of K steps binds.)
     dim3 grid((unsigned)(((p.wf + 7) / 8) * ((p.hf + 7) / 8)));
 #define OTF(T, RR, KK) hipLaunchKernelGGL((corr_lookup_otf_kernel<T, RR, KK, 8>), grid, dim3(256), 0, s, p)
     if (p.k == 256 && p.radius == 4) { if (p.terms == 3) OTF(3, 4, 256); else OTF(1, 4, 256); }       /* full model  */
