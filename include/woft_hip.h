@@ -299,7 +299,7 @@ int woft_tc_flags(const float* dst, const uint8_t* tmask, const uint8_t* pwmask,
  * ws: NULL, or woft_hfit_ws_bytes() bytes of device scratch: with it, fits of more than WOFT_HFIT_SINGLE_MAX
  * correspondences (configs without a subsampler: up to H*W) run as a streaming multi-workgroup pipeline instead of
  * in one workgroup; same arithmetic (fp32 rows, fp64 Gram matrix on the fp64 matrix cores, fp64 Cholesky). */
-#define WOFT_HFIT_SINGLE_MAX 8192
+#define WOFT_HFIT_SINGLE_MAX 2048
 int64_t woft_hfit_ws_bytes(void);
 int woft_hfit(const float* pa, const float* pb, const float* w, int32_t n_max, const int32_t* count,
               int32_t reweight, float huber_k, int32_t n_irls, void* ws, float* Hout, int32_t* status, void* stream);

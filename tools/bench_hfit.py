@@ -13,7 +13,7 @@ from tools.bench_conv import bench
 
 def main():
     lib = _lib.load()
-    for (H, W) in ((1080, 1920), (2160, 3840), (128, 160)):
+    for (H, W) in ((1080, 1920), (2160, 3840), (128, 160), (64, 64), (32, 64)):
         n = H * W
         idx = torch.arange(n, device="cuda")
         a = torch.stack([idx % W, idx // W], 1).float().contiguous()

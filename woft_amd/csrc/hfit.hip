@@ -12,8 +12,9 @@
 // (A[i][k] = B[k][i] = R_k[i]).  One workgroup does the whole fit in a single launch (N <= 500 after
 // the Sobol subsampler of the default configs).  Configs without a subsampler fit up to H*W = 2 M (1080p) / 8.3 M
 // (4K) correspondences: with a workspace the same arithmetic runs as a streaming multi-workgroup pipeline
-// (`hfit_sum` -> `hfit_dist` -> per solve `hfit_gram` + `hfit_solve`; 20 B per correspondence per pass, partial
-// Gram matrices reduced in a fixed order -> deterministic).  The same pipeline, one solve per call, serves
+// (`hfit_sum` -> `hfit_dist` -> per solve `hfit_gram` + `hfit_solve`; 20 B per correspondence per pass, one
+// correspondence per lane with fp64 accumulators on the vector ALUs -- see hfit_gram_kernel --, partial Gram matrices
+// reduced in a fixed order -> deterministic).  The same pipeline, one solve per call, serves
 // ARBITRARY re-weighting callables (least_squares_H.py:280,337): `woft_hfit_step` takes the per-row re-weights the
 // host computed from the residuals of the previous call and returns the residuals A x - b of its own solution.
 #include "common.h"
@@ -310,13 +311,38 @@ __global__ __launch_bounds__(MT) void hfit_sum_kernel(const float* __restrict__ 
     block_sum_m<4>(v, red, s.psum + blockIdx.x * 4);
 }
 
-// means from the partial sums (fixed order); every workgroup repeats the small reduction
-__device__ __forceinline__ void fit_means(const MWs& s, int n, double* sh /* [4] */) {
-    if (threadIdx.x < 4) {
-        double t = 0.0;
-        for (int g = 0; g < (int)gridDim.x; ++g) t += s.psum[g * 4 + threadIdx.x];
-        sh[threadIdx.x] = t / n;
+// total of per-workgroup partials part[G][CNT] -> out[CNT] (LDS), by the whole workgroup in a fixed order: lane t sums
+// the groups t, t + MT, ... , then the usual wave / workgroup tree.  Every workgroup repeats it (G x CNT doubles out of
+// L2) and gets the same bits.  (A serial loop in CNT lanes is G dependent L2 round trips: it WAS the streaming fit's
+// whole cost, ~250 us per kernel at G = 1024.)
+template <int CNT>
+__device__ __forceinline__ void partial_total(const double* __restrict__ part, int G, double* out /* LDS [CNT] */) {
+    __shared__ double tred[(MT / 64) * CNT];
+    double acc[CNT];
+#pragma unroll
+    for (int c = 0; c < CNT; ++c) acc[c] = 0.0;
+    for (int g = threadIdx.x; g < G; g += MT)
+#pragma unroll
+        for (int c = 0; c < CNT; ++c) acc[c] += part[(int64_t)g * CNT + c];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < CNT; ++c) {
+        const double t = wave_sum(acc[c]);
+        if (lane == 0) tred[wave * CNT + c] = t;
     }
+    __syncthreads();
+    if ((int)threadIdx.x < CNT) {
+        double t = 0.0;
+        for (int wv = 0; wv < MT / 64; ++wv) t += tred[wv * CNT + threadIdx.x];
+        out[threadIdx.x] = t;
+    }
+    __syncthreads();
+}
+
+// means from the partial sums
+__device__ __forceinline__ void fit_means(const MWs& s, int n, double* sh /* [4] */) {
+    partial_total<4>(s.psum, (int)gridDim.x, sh);
+    if (threadIdx.x < 4) sh[threadIdx.x] /= n;
     __syncthreads();
 }
 
@@ -342,13 +368,10 @@ __global__ __launch_bounds__(MT) void hfit_dist_kernel(const float* __restrict__
 // normalisation parameters from the partials -> shared nf[6] (same formulas as the single-workgroup kernel)
 __device__ __forceinline__ void fit_norm(const MWs& s, int n, double* mean /* [4] */, double* dist /* [2] */, float* nf) {
     fit_means(s, n, mean);
-    if (threadIdx.x < 2) {
-        double t = 0.0;
-        for (int g = 0; g < (int)gridDim.x; ++g) t += s.pdist[g * 2 + threadIdx.x];
-        dist[threadIdx.x] = t / n;
-    }
-    __syncthreads();
+    partial_total<2>(s.pdist, (int)gridDim.x, dist);
     if (threadIdx.x == 0) {
+        dist[0] /= n;
+        dist[1] /= n;
         const float m1x = (float)mean[0], m1y = (float)mean[1], m2x = (float)mean[2], m2y = (float)mean[3];
         const float s1 = sqrtf(2.0f) / ((float)dist[0] + 1e-8f), s2 = sqrtf(2.0f) / ((float)dist[1] + 1e-8f);
         nf[0] = s1; nf[1] = -s1 * m1x; nf[2] = -s1 * m1y; nf[3] = s2; nf[4] = -s2 * m2x; nf[5] = -s2 * m2y;
@@ -358,6 +381,13 @@ __device__ __forceinline__ void fit_norm(const MWs& s, int n, double* mean /* [4
 
 // partial Gram matrix of this workgroup's share of the rows.  Row re-weights: `rew` (2 per correspondence, external)
 // or, when use_sol, sqrt(reweight_fn(residual of `sol`)) of the built-in losses.
+//
+// Streaming form: ONE correspondence per lane per turn, the 36 structurally non-zero entries of the symmetric 9x9 matrix as
+// fp64 accumulators on the vector ALUs (rows x: columns 3..8, rows y: columns 0..2, 6..8 -> 2 x 21 fp64 FMAs per
+// correspondence).  The fp64 matrix-core form of the one-workgroup kernel spends a whole wave instruction on TWO
+// correspondences (K = 4 system rows per v_mfma_f64_16x16x4, 81 of 256 outputs live) with every lane rebuilding both rows;
+// this is HBM-bound streaming work, not a GEMM (profiles/r02_hfit_fullframe.txt: 3.2 TB/s algorithmic at N = 8.3 M).
+// Same fp32 rows, same (double)(row * q) operands, fp64 products and sums: only the summation order differs.
 __global__ __launch_bounds__(MT) void hfit_gram_kernel(const float* __restrict__ pa, const float* __restrict__ pb,
                                                        const float* __restrict__ w, int n_max,
                                                        const int* __restrict__ count, const float* __restrict__ rew,
@@ -374,49 +404,70 @@ __global__ __launch_bounds__(MT) void hfit_gram_kernel(const float* __restrict__
     float sol[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) sol[k] = use_sol ? s.sol[k] : 0.f;
-    typedef double f64x4 __attribute__((ext_vector_type(4)));
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int ec = lane & 15, ek = lane >> 4;
-    f64x4 g4 = {0.0, 0.0, 0.0, 0.0};
-    const int64_t stride = (int64_t)gridDim.x * (MT / 64) * 2;
-    for (int64_t base = ((int64_t)blockIdx.x * (MT / 64) + wave) * 2; base < n; base += stride) {
-        const int64_t i = base + (ek >> 1);
-        double val = 0.0;
-        if (i < n && ec < 9) {
-            const float2 a = ((const float2*)pa)[i], b = ((const float2*)pb)[i];
-            const float x1 = s1 * a.x + t1x, y1 = s1 * a.y + t1y, x2 = s2 * b.x + t2x, y2 = s2 * b.y + t2y;
-            const float wv = (w != nullptr) ? w[i] : 1.f;
-            float rx[9], ry[9];
-            build_rows(x1, y1, x2, y2, wv, rx, ry);
-            float q = 1.f;
-            if (rew != nullptr) {
-                q = rew[2 * i + (ek & 1)];
-            } else if (use_sol && reweight != 0) {
-                float resx = -rx[8], resy = -ry[8];
+    // columns touched by an x row / a y row, and the accumulators of their pairwise products (upper triangle)
+    constexpr int CX[6] = {3, 4, 5, 6, 7, 8}, CY[6] = {0, 1, 2, 6, 7, 8};
+    double gx[21], gy[21];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    resx += rx[k] * sol[k];
-                    resy += ry[k] * sol[k];
-                }
-                q = sqrtf(reweight_fn((ek & 1) ? resy : resx, reweight, huber_k));
+    for (int k = 0; k < 21; ++k) gx[k] = gy[k] = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * MT + threadIdx.x; i < n; i += (int64_t)gridDim.x * MT) {
+        const float2 a = ((const float2*)pa)[i], b = ((const float2*)pb)[i];
+        const float x1 = s1 * a.x + t1x, y1 = s1 * a.y + t1y, x2 = s2 * b.x + t2x, y2 = s2 * b.y + t2y;
+        const float wv = (w != nullptr) ? w[i] : 1.f;
+        float rx[9], ry[9];
+        build_rows(x1, y1, x2, y2, wv, rx, ry);
+        float qx = 1.f, qy = 1.f;
+        if (rew != nullptr) {
+            const float2 q2 = ((const float2*)rew)[i];
+            qx = q2.x;
+            qy = q2.y;
+        } else if (use_sol && reweight != 0) {
+            float resx = -rx[8], resy = -ry[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                resx += rx[k] * sol[k];
+                resy += ry[k] * sol[k];
             }
-            float e = 0.f;
-#pragma unroll
-            for (int k = 0; k < 9; ++k)
-                if (k == ec) e = (ek & 1) ? ry[k] : rx[k];
-            val = (double)(e * q);
+            qx = sqrtf(reweight_fn(resx, reweight, huber_k));
+            qy = sqrtf(reweight_fn(resy, reweight, huber_k));
         }
-        g4 = __builtin_amdgcn_mfma_f64_16x16x4f64(val, val, g4, 0, 0, 0);
-    }
+        double ex[6], ey[6];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int row = ek + 4 * r;
-        if (row < 9 && ec < 9) red[wave * 81 + row * 9 + ec] = g4[r];
+        for (int k = 0; k < 6; ++k) {
+            ex[k] = (double)(rx[CX[k]] * qx);
+            ey[k] = (double)(ry[CY[k]] * qy);
+        }
+        int t = 0;
+#pragma unroll
+        for (int p0 = 0; p0 < 6; ++p0)
+#pragma unroll
+            for (int p1 = p0; p1 < 6; ++p1, ++t) {
+                gx[t] += ex[p0] * ex[p1];
+                gy[t] += ey[p0] * ey[p1];
+            }
+    }
+    // workgroup reduction -> the full symmetric 9x9 partial matrix (zeros where no row has both columns)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int k = threadIdx.x; k < (MT / 64) * 81; k += MT) red[k] = 0.0;
+    __syncthreads();
+    {
+        int t = 0;
+#pragma unroll
+        for (int p0 = 0; p0 < 6; ++p0)
+#pragma unroll
+            for (int p1 = p0; p1 < 6; ++p1, ++t) {
+                const double sx = wave_sum(gx[t]), sy = wave_sum(gy[t]);
+                if (lane == 0) {
+                    red[wave * 81 + CX[p0] * 9 + CX[p1]] += sx;
+                    red[wave * 81 + CY[p0] * 9 + CY[p1]] += sy;     // (x and y rows share the columns 6..8: same cell, two adds)
+                }
+            }
     }
     __syncthreads();
     if (threadIdx.x < 81) {
+        const int r = threadIdx.x / 9, c = threadIdx.x % 9;
+        const int idx = (r <= c) ? r * 9 + c : c * 9 + r;              // mirror the upper triangle
         double sacc = 0.0;
-        for (int wv = 0; wv < MT / 64; ++wv) sacc += red[wv * 81 + threadIdx.x];
+        for (int wv = 0; wv < MT / 64; ++wv) sacc += red[wv * 81 + idx];
         s.pgram[(int64_t)blockIdx.x * 81 + threadIdx.x] = sacc;
     }
 }
@@ -473,7 +524,8 @@ __device__ void denormalise(const float* sol, float s1, float t1x, float t1y, fl
 }
 
 // one workgroup: reduce the partial Gram matrices (fixed order), solve, publish sol (and H / status)
-__global__ __launch_bounds__(128) void hfit_solve_kernel(int n_max, const int* __restrict__ count, int groups, void* ws,
+constexpr int ST = 1024;           // threads of the solve kernel: 16 waves share the partial matrices
+__global__ __launch_bounds__(ST) void hfit_solve_kernel(int n_max, const int* __restrict__ count, int groups, void* ws,
                                                          float* __restrict__ Hout, int* __restrict__ status) {
     __shared__ double gram[81];
     const MWs s = mws_layout(ws);
@@ -485,12 +537,25 @@ __global__ __launch_bounds__(128) void hfit_solve_kernel(int n_max, const int* _
         }
         return;
     }
-    if (threadIdx.x < 81) {
-        double t = 0.0;
-        for (int g = 0; g < groups; ++g) t += s.pgram[(int64_t)g * 81 + threadIdx.x];
-        gram[threadIdx.x] = t;
+    {   // wave v sums the groups v, v + 16, ... (lanes = matrix entries, 81 = 64 + 17), then the waves in order
+        __shared__ double part[(ST / 64) * 81];
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        double t0 = 0.0, t1 = 0.0;
+#pragma unroll 4
+        for (int g = wave; g < groups; g += ST / 64) {
+            t0 += s.pgram[(int64_t)g * 81 + lane];
+            if (lane < 17) t1 += s.pgram[(int64_t)g * 81 + 64 + lane];
+        }
+        part[wave * 81 + lane] = t0;
+        if (lane < 17) part[wave * 81 + 64 + lane] = t1;
+        __syncthreads();
+        if (threadIdx.x < 81) {
+            double t = 0.0;
+            for (int wv = 0; wv < ST / 64; ++wv) t += part[wv * 81 + threadIdx.x];
+            gram[threadIdx.x] = t;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     if (threadIdx.x == 0) {
         if (status[0] == 2) return;                       // an earlier solve of this fit was singular
         float sol[8];
@@ -549,7 +614,7 @@ extern "C" int woft_hfit(const float* pa, const float* pb, const float* w, int32
     for (int it = 0; it < solves; ++it) {
         hipLaunchKernelGGL(hfit_gram_kernel, dim3(G), dim3(MT), 0, st, pa, pb, w, n_max, count, (const float*)nullptr,
                            reweight, huber_k, it > 0 ? 1 : 0, ws);
-        hipLaunchKernelGGL(hfit_solve_kernel, dim3(1), dim3(128), 0, st, n_max, count, G, ws, Hout, status);
+        hipLaunchKernelGGL(hfit_solve_kernel, dim3(1), dim3(ST), 0, st, n_max, count, G, ws, Hout, status);
     }
     return woft_launch_status();
 }
@@ -565,7 +630,7 @@ extern "C" int woft_hfit_step(const float* pa, const float* pb, const float* w, 
         hipLaunchKernelGGL(hfit_dist_kernel, dim3(G), dim3(MT), 0, st, pa, pb, n, (const int*)nullptr, ws);
     }
     hipLaunchKernelGGL(hfit_gram_kernel, dim3(G), dim3(MT), 0, st, pa, pb, w, n, (const int*)nullptr, rew, 0, 0.f, 0, ws);
-    hipLaunchKernelGGL(hfit_solve_kernel, dim3(1), dim3(128), 0, st, n, (const int*)nullptr, G, ws, Hout, status);
+    hipLaunchKernelGGL(hfit_solve_kernel, dim3(1), dim3(ST), 0, st, n, (const int*)nullptr, G, ws, Hout, status);
     if (res != nullptr && n >= 4)
         hipLaunchKernelGGL(hfit_resid_kernel, dim3((n + MT - 1) / MT), dim3(MT), 0, st, pa, pb, w, n, (const int*)nullptr,
                            (const void*)ws, res);

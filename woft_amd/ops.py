@@ -549,7 +549,7 @@ def hfit_ws(device=None):
     return _HFIT_WS[key]
 
 
-HFIT_SINGLE_MAX = 8192
+HFIT_SINGLE_MAX = 2048
 
 
 def hfit(pa, pb, w, Hout, status, count=None, reweight=0, huber_k=1.0, n_irls=0, ws=None):
