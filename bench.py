@@ -215,15 +215,18 @@ def main():
     terms = {"fp32": 1, "bf16x3": 3, "bf16": 1}[args.precision]
     mfma_peak = 157.3 if args.precision == "fp32" else 2500.0      # TFLOP/s dense: f32-input MFMA / bf16 MFMA (MI355X_MICROARCH.md)
 
-    def lookup_roofline(evs, P):
+    def lookup_roofline(evs, P, storage="fp32"):
         """Correlation lookup in the volume (the named HBM-roofline kernel): algorithmic bytes / live time.
         `traffic` = HBM bytes per launch from PMC passes (FETCH_SIZE with the guide's gfx950 correction + WRITE_SIZE), which
         need their own rocprofv3 runs: tools/lookup_pmc.sh regenerates profiles/r02_lookup_pmc.json on the GPU box."""
         lk_ms = [s.elapsed_time(e) for s, e in evs]
         lk_avg = float(np.mean(lk_ms)) if lk_ms else float("nan")
-        algo_bytes = LOOKUP_ALGO_BYTES_PER_PIXEL * P
+        # (2r+2)^2 volume elements in, (2r+1)^2 fp32 samples out, per level: 2896 B with the fp32 volume, 2096 B with the
+        # bf16-storage volume of the plain-bf16 operating point (SURVEY 8d)
+        algo_bytes = (LOOKUP_ALGO_BYTES_PER_PIXEL if storage == "fp32" else 4 * (10 * 10 * 2 + 9 * 9 * 4)) * P
         traffic, src = None, None
-        for name in ("r02_lookup_pmc.json", "r01_lookup_pmc.json"):
+        for name in (("r02_lookup_pmc.json", "r01_lookup_pmc.json") if storage == "fp32" else ()):   # (PMC passes: fp32 volume;
+                                                        # FETCH_SIZE is uncalibrated for the bf16 volume's 8-B-per-lane loads)
             try:
                 pmc = json.loads((ROOT / "profiles" / name).read_text())
                 if pmc["resolution"] == [H, W]:
@@ -232,7 +235,8 @@ def main():
             except Exception:
                 pass
         achieved = algo_bytes / (lk_avg * 1e-3) / 1e9 if lk_ms else float("nan")
-        return {"bound": "hbm", "kernel": "corr_lookup_kernel<4>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+        return {"bound": "hbm", "kernel": "corr_lookup_kernel<4>" if storage == "fp32" else "corr_lookup_kernel<4, bf16 volume>",
+                "volume_storage": storage, "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src,
                 "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": lk_avg, "launches_timed": len(lk_ms)}
 
@@ -313,7 +317,7 @@ def main():
     have_conv = bool(layers) and any(conv_events.get(t) for t in layers)
     if corr_mode == "volume":
         # the lookup reads the volume: the named HBM-roofline kernel, measured live in the timed region
-        out["roofline"] = lookup_roofline(events, plan.P)
+        out["roofline"] = lookup_roofline(events, plan.P, tracker.flower.engine.volume_storage)
         if have_conv:
             out["roofline_mfma"] = conv_roofline(conv_events, layers)
     elif have_conv:
@@ -404,9 +408,18 @@ def main():
         r["hbm_allocated_peak_gb"] = torch.cuda.max_memory_allocated() / 2 ** 30
         out["alt_corr"] = {other: r}
         if other == "volume":
-            out["roofline_lookup"] = lookup_roofline(evs, pl.P)
+            out["roofline_lookup"] = lookup_roofline(evs, pl.P, trk.flower.engine.volume_storage)
         del trk, pl
         drop()
+        if other == "volume" and args.precision != "bf16":
+            # the plain-bf16 operating point with its bf16-STORAGE volume (BASELINE config 3's arithmetic; SURVEY 8d:
+            # 2096 B per pixel and lookup): the same HBM-roofline kernel on half-size volume elements
+            r, trk, pl, evs = side_run(min(K, 8), precision="bf16", corr="volume")
+            r["volume_storage"] = trk.flower.engine.volume_storage
+            out["alt_corr"]["volume, precision bf16"] = r
+            out["roofline_lookup_bf16_storage"] = lookup_roofline(evs, pl.P, trk.flower.engine.volume_storage)
+            del trk, pl
+            drop()
     if world == 1 and not args.no_alt_corr:
         # the weight head on every pixel (or, with --full-weight-head, on the mask region): full K steps, same tracks
         r, trk, pl, _ = side_run(K, check_tracks=True, mask_wh=not mask_region)

@@ -150,9 +150,11 @@ int woft_split_bf16_lines(const float* x, int64_t n, void* out, void* stream);
 /* All-pairs correlation (corr.py:62-69) on pre-split operands: out[i][j] = alpha * <A[i], B[j]>, i < m, j < n.
  * terms = 3 (hi*hi + hi*lo + lo*hi, fp32-emulating): a / b = woft_split_bf16_lines of fmap1 [rows_a][k] /
  * of woft_tile_rows(fmap2) [rows_b][k]; terms = 1: a / b = their plain bf16 planes (woft_split_bf16 hi), k % 64 == 0.
- * rows_a, rows_b: allocated rows, multiples of 128 (rows beyond m / n are read, their products never stored). */
+ * rows_a, rows_b: allocated rows, multiples of 128 (rows beyond m / n are read, their products never stored).
+ * out: fp32 [m][ldo], or -- out_bf16 != 0 -- bf16 [m][ldo] (fp32 accumulators rounded to nearest even once, at the
+ * store): the bf16-storage volume of the plain-bf16 operating point (2096 B per pixel and lookup). */
 int woft_corr_gemm_bf16(const void* a, const void* b, int64_t m, int64_t n, int64_t rows_a, int64_t rows_b, int32_t k,
-                        float alpha, float* out, int64_t ldo, int32_t terms, void* stream);
+                        float alpha, void* out, int64_t ldo, int32_t terms, int32_t out_bf16, void* stream);
 
 /* InstanceNorm (extractor.py:28-32,129-130; nn.InstanceNorm2d eps=1e-5, biased variance):
  * finalize per-channel statistics from the conv epilogue's partial sums ... */
@@ -179,14 +181,17 @@ int woft_avgpool2_nhwc(const float* in, int32_t h, int32_t w, int32_t c, float* 
  * producer is the correlation GEMM run against woft_tile_rows(fmap2_l).  coords: [P][2] (x,y) at level 0.
  * out: [P][ldo] with channel l*(2r+1)^2 + i*(2r+1) + j  <-  sample at (x/2^l + i - r, y/2^l + j - r). */
 typedef struct woft_lookup_params {
-    const float* vol[4];
+    const void* vol[4];     /* fp32, or bf16 when vol_bf16 (woft_corr_gemm_bf16 with out_bf16) */
     int32_t ht[4], wt[4];   /* tiles per column / row at level l */
-    int64_t plane[4];       /* floats per source pixel at level l (>= ht*wt*16) */
+    int64_t plane[4];       /* elements per source pixel at level l (>= ht*wt*16) */
     int32_t levels, radius;
     const float* coords;
     int64_t n_pix;
     float* out;
     int32_t ldo;
+    int32_t vol_bf16;       /* 0: fp32 volume (2896 B per pixel and call, r = 4), 1: bf16 storage (2096 B), fp32 out */
+    int32_t tile_w;         /* columns of a tile (tiles are 4 rows x tile_w): 4 (0 = 4) or 8; plane >= ht*wt*4*tile_w */
+    int32_t ablate;         /* developer knob of tools/bench_lookup.py (1: no volume reads, 2: no output); 0 in production */
 } woft_lookup_params;
 int woft_corr_lookup(const woft_lookup_params* p, void* stream);
 /* Volume-free correlation lookup (the reference's alternate_corr path: corr.py:72-100 and its alt_cuda_corr
@@ -208,9 +213,9 @@ typedef struct woft_lookup_otf_params {
     int32_t ldo;
 } woft_lookup_otf_params;
 int woft_corr_lookup_otf(const woft_lookup_otf_params* p, void* stream);
-/* NHWC map [h][w][c] -> its rows in 4x4-tile order [(ceil(h/4)*ceil(w/4)*16)][c], zero rows outside the map:
- * the B operand of the correlation GEMM that yields the tiled volume layout above. */
-int woft_tile_rows(const float* in, int32_t h, int32_t w, int32_t c, float* out, void* stream);
+/* NHWC map [h][w][c] -> its rows in (4 x tile_w)-tile order [(ceil(h/4)*ceil(w/tile_w)*4*tile_w)][c], zero rows outside
+ * the map: the B operand of the correlation GEMM that yields the tiled volume layout above.  tile_w: 4 or 8. */
+int woft_tile_rows(const float* in, int32_t h, int32_t w, int32_t c, int32_t tile_w, float* out, void* stream);
 
 /* coords1 += delta; flow = coords1 - coords0 (weighted_raft.py:232,237).
  * delta: [P][ld_delta] (first two channels); flow4: [P][4] = (fx, fy, 0, 0);
@@ -298,7 +303,7 @@ int woft_tc_flags(const float* dst, const uint8_t* tmask, const uint8_t* pwmask,
  * status[0] (device) = 0 ok, 1 fewer than 4 points, 2 singular system.
  * ws: NULL, or woft_hfit_ws_bytes() bytes of device scratch: with it, fits of more than WOFT_HFIT_SINGLE_MAX
  * correspondences (configs without a subsampler: up to H*W) run as a streaming multi-workgroup pipeline instead of
- * in one workgroup; same arithmetic (fp32 rows, fp64 Gram matrix on the fp64 matrix cores, fp64 Cholesky). */
+ * in one workgroup; same arithmetic (fp32 rows, fp64 Gram matrix, fp64 Cholesky; only the summation order differs). */
 #define WOFT_HFIT_SINGLE_MAX 2048
 int64_t woft_hfit_ws_bytes(void);
 int woft_hfit(const float* pa, const float* pb, const float* w, int32_t n_max, const int32_t* count,

@@ -249,6 +249,7 @@ def test_volume_free_correlation_matches_volume(precision, small):
     for corr in ("volume", "otf"):
         c = _flow_config(sd, 5, raft_type=rt, padding_mode="RAFT", small=small, precision=precision)
         c.corr = corr
+        c.volume_storage = "fp32"       # (plain bf16 stores its volume in bf16 by default: one more rounding -- below)
         prov = c.of_class(c)
         assert prov.engine.corr == corr
         fl, wt = prov.compute_flow(a, b, mode="flow", numpy_out=True)
@@ -260,6 +261,18 @@ def test_volume_free_correlation_matches_volume(precision, small):
     # it is the default in these precisions; fp32 keeps the volume
     c = _flow_config(sd, 5, raft_type=rt, padding_mode="RAFT", small=small, precision=precision)
     assert c.of_class(c).engine.corr == "otf"
+    if precision == "bf16":
+        # the bf16-storage volume (default of precision "bf16" + corr "volume"): correlation values rounded to bf16 once
+        # more -- a different, still bf16-class flow (budget vs the reference: test_32_iterations_vs_reference_golden)
+        c = _flow_config(sd, 5, raft_type=rt, padding_mode="RAFT", small=small, precision=precision)
+        c.corr = "volume"
+        prov = c.of_class(c)
+        fl, _ = prov.compute_flow(a, b, mode="flow", numpy_out=True)
+        assert prov.engine.volume_storage == "bf16"
+        assert all(v.dtype == torch.bfloat16 for pl in prov.engine._plans.values() for v in pl.vol)
+        d = np.sqrt(((fl - outs["volume"][0]) ** 2).sum(0))
+        print(f"bf16-storage volume vs fp32-storage volume: EPE mean {d.mean():.2e} max {d.max():.2e}")
+        assert 0 < d.mean() < 0.05
     c = _flow_config(sd, 5, raft_type=rt, padding_mode="RAFT", small=small, precision="fp32")
     assert c.of_class(c).engine.corr == "volume"
 

@@ -420,7 +420,7 @@ def test_preprocess_and_pool(ops):
 # ------------------------------------------------------------------------------------------
 # correlation volume + lookup
 # ------------------------------------------------------------------------------------------
-def _build_pyramid_gpu(ops, f1, f2, precision="fp32", presplit=False):
+def _build_pyramid_gpu(ops, f1, f2, precision="fp32", presplit=False, vol_dtype=torch.float32):
     """f1, f2: (1, C, H, W) cpu tensors -> tiled volumes [P][ht*wt*16] on the GPU via tile_rows + conv/GEMM."""
     _, c, h, w = f1.shape
     a1, a2 = ops.act_from_nchw(f1), ops.act_from_nchw(f2)
@@ -431,7 +431,7 @@ def _build_pyramid_gpu(ops, f1, f2, precision="fp32", presplit=False):
         n = ops.tiled_dims(hl, wl)[2]
         rows = torch.zeros(ops._round_up(n, 128), c, device="cuda")
         ops.tile_rows(cur, rows)
-        vol = torch.zeros(h * w, n, device="cuda")
+        vol = torch.zeros(h * w, n, device="cuda", dtype=vol_dtype)
         hi, lo = torch.zeros_like(rows, dtype=torch.bfloat16), torch.zeros_like(rows, dtype=torch.bfloat16)
         if precision != "fp32":
             ops.split_bf16(rows, hi, lo)
@@ -502,6 +502,78 @@ def test_corr_gemm_presplit(ops, h, w, precision, tol):
         hl, wl = dims[l]
         _close(ops.untile_planes(vols[l], hl, wl), pyr[l][:, 0], tol, what=f"volume level {l}")
         _close(vols[l], ref[l], tol * 0.1, what=f"level {l}: pre-split GEMM vs the conv kernel")
+
+
+@pytest.mark.parametrize("h,w,dtype", [(17, 25, torch.float32), (24, 40, torch.float32), (33, 47, torch.bfloat16),
+                                       (8, 9, torch.bfloat16)])
+def test_lookup_tile_shapes(ops, h, w, dtype):
+    """The volume layout's tile shape (4 x 4 or 4 x 8 elements) is invisible in the result: the same planes tiled either way
+    give bit-identical lookups (smooth, scattered and out-of-map coordinates), and woft_tile_rows orders the GEMM's B rows
+    the way tile_planes orders a plane."""
+    P = h * w
+    g = torch.Generator().manual_seed(7)
+    dims, planes = [], []
+    hl, wl = h, w
+    for l in range(4):
+        dims.append((hl, wl))
+        planes.append(torch.randn(P, hl, wl, generator=g).to(dtype).cuda())
+        hl, wl = max(hl // 2, 1), max(wl // 2, 1)
+    coords = raft_ref.coords_grid(1, h, w) + _rand(1, 2, h, w, seed=71, scale=9.0)
+    coords[0, :, 0, 0] = torch.tensor([-7.3, 2.2])
+    coords[0, :, h - 1, w - 1] = torch.tensor([w + 9.5, h + 3.0])
+    coords[0, :, 1, 1] = torch.tensor([-30.0, -30.0])
+    cg = coords[0].permute(1, 2, 0).reshape(P, 2).contiguous().cuda()
+    outs = {}
+    for tw in (4, 8):
+        vols = [ops.tile_planes(pl, tw) for pl in planes]
+        for v, pl, (a, b) in zip(vols, planes, dims):
+            assert torch.equal(ops.untile_planes(v, a, b, tw), pl)
+        out = torch.zeros(P, 352, device="cuda")
+        ops.run_lookup(ops.make_lookup_params(vols, dims, cg, out, 4, tw=tw))
+        outs[tw] = out
+    torch.cuda.synchronize()
+    assert torch.equal(outs[4], outs[8])
+    assert float(outs[8][:, :324].abs().max()) > 0
+    # woft_tile_rows: row (tile, dy, dx) of the output = pixel (4 ty + dy, tw tx + dx) of the map, zero rows outside
+    x = ops.new_act(1, h, w, 8)
+    x.t.normal_()
+    for tw in (4, 8):
+        ht, wt, n = ops.tiled_dims(h, w, tw)
+        rows = torch.full((n, 8), 7.0, device="cuda")
+        ops.tile_rows(x, rows, tw)
+        want = ops.tile_planes(x.t.reshape(h, w, 8).permute(2, 0, 1).contiguous(), tw)      # (8, n)
+        assert torch.equal(rows.t().contiguous(), want)
+
+
+@pytest.mark.parametrize("h,w,precision", [(17, 25, "bf16"), (24, 40, "bf16"), (16, 20, "bf16x3")])
+def test_bf16_storage_volume(ops, h, w, precision):
+    """bf16-STORAGE volume (the plain-bf16 operating point, SURVEY 8d: 2096 B per pixel and lookup): the correlation GEMM
+    with a bf16 output == its fp32 output rounded to nearest even once (bit for bit, padding zeros included), and the lookup
+    in the bf16 volume == the lookup in that volume widened back to fp32 (same interpolation, fp32 output), bit for bit;
+    against the oracle within bf16 rounding of the correlation values."""
+    f1, f2 = _rand(1, 256, h, w, seed=61), _rand(1, 256, h, w, seed=62)
+    v32, dims = _build_pyramid_gpu(ops, f1, f2, precision, presplit=True)
+    v16, _ = _build_pyramid_gpu(ops, f1, f2, precision, presplit=True, vol_dtype=torch.bfloat16)
+    for l in range(4):
+        assert v16[l].dtype == torch.bfloat16
+        assert torch.equal(v16[l], v32[l].to(torch.bfloat16)), f"level {l}"
+    coords = raft_ref.coords_grid(1, h, w) + _rand(1, 2, h, w, seed=63, scale=6.0)
+    coords[0, :, 0, 0] = torch.tensor([-7.3, 2.2])
+    coords[0, :, 0, 1] = torch.tensor([w + 9.5, h + 3.0])
+    cg = coords[0].permute(1, 2, 0).reshape(h * w, 2).contiguous().cuda()
+    got, wide = torch.zeros(h * w, 352, device="cuda"), torch.zeros(h * w, 352, device="cuda")
+    p16 = ops.make_lookup_params(v16, dims, cg, got, 4)
+    assert p16.vol_bf16 == 1
+    ops.run_lookup(p16)
+    ops.run_lookup(ops.make_lookup_params([v.float() for v in v16], dims, cg, wide, 4))
+    torch.cuda.synchronize()
+    assert torch.equal(got, wide)
+    assert float(got[:, 324:].abs().max()) == 0.0
+    ref = raft_ref.corr_lookup(raft_ref.corr_pyramid(f1, f2), coords, 4)
+    tol = 2.0 ** -8 * float(ref.abs().max()) + (5e-2 if precision == "bf16" else 2e-4)
+    _close(got[:, :324].reshape(1, h, w, 324).permute(0, 3, 1, 2), ref, tol, what="lookup in the bf16 volume")
+    with pytest.raises(AssertionError):     # mixed storage types are refused
+        ops.make_lookup_params([v16[0], v32[1], v32[2], v32[3]], dims, cg, got, 4)
 
 
 @pytest.mark.parametrize("h,w,precision,spread", [(17, 25, "bf16x3", 2.0), (24, 40, "bf16x3", 30.0), (16, 20, "bf16", 3.0),

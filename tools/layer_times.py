@@ -50,7 +50,8 @@ def main():
             _lib.stream_ptr()), "wh_reduce"))], 1))
     for name, prog, mult in progs:
         sub = 0.0
-        for idx, (kind, arg) in enumerate(prog):
+        for idx, ent in enumerate(prog):
+            kind, arg = ent[0], ent[1]
             ts = []
             for _ in range(5):
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -1,5 +1,6 @@
 """One update-block layer, one kernel variant, a few launches -- the target of PMC passes.
   python tools/regb_probe.py <case: zr|fh1|q> <halo: 0 (default choice) | 8> [tile_n]"""
+import os
 import sys
 from pathlib import Path
 
@@ -11,7 +12,7 @@ from woft_amd import ops, _lib
 case, halo = sys.argv[1], int(sys.argv[2])
 tn = int(sys.argv[3]) if len(sys.argv) > 3 else None
 prec = sys.argv[4] if len(sys.argv) > 4 else "bf16x3"
-hf, wf = 135, 240
+hf, wf = int(os.environ.get("HF", 135)), int(os.environ.get("WF", 240))
 cin, x2c, cout, kh, kw = {"zr": (128, 128, 256, 1, 5), "q": (128, 128, 128, 5, 1), "fh1": (128, 0, 256, 3, 3),
                           "c2": (256, 0, 192, 3, 3)}[case]
 wt = torch.randn(cout, cin + x2c, kh, kw) * 0.05
@@ -37,7 +38,10 @@ import time
 ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(12)]
 for _ in range(3):
     ops.run_conv(p)
+cold = torch.zeros(int(os.environ.get("COLD", "0")) * 2**18, device="cuda") if os.environ.get("COLD") else None   # MiB
 for s_, e_ in ev:
+    if cold is not None:
+        cold.add_(1.0)          # evicts the L2s (weights stay in the 256-MiB memory-side cache, as inside a frame)
     s_.record(); ops.run_conv(p); e_.record()
 torch.cuda.synchronize()
 ts = sorted(s_.elapsed_time(e_) for s_, e_ in ev)

@@ -39,6 +39,7 @@ class LookupParams(C.Structure):
     _fields_ = [
         ("vol", vp * 4), ("ht", i32 * 4), ("wt", i32 * 4), ("plane", i64 * 4),
         ("levels", i32), ("radius", i32), ("coords", vp), ("n_pix", i64), ("out", vp), ("ldo", i32),
+        ("vol_bf16", i32), ("tile_w", i32), ("ablate", i32),
     ]
 
 
@@ -61,13 +62,13 @@ _SIGS = {
     "woft_corr_lookup_otf": (i32, [C.POINTER(LookupOtfParams), vp]),
     "woft_conv3x3_narrow": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, i64, i32, vp]),
     "woft_flow_head_update": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, i64, vp, vp, vp, i32, vp]),
-    "woft_corr_gemm_bf16": (i32, [vp, vp, i64, i64, i64, i64, i32, f32, vp, i64, i32, vp]),
+    "woft_corr_gemm_bf16": (i32, [vp, vp, i64, i64, i64, i64, i32, f32, vp, i64, i32, i32, vp]),
     "woft_inorm_finalize": (i32, [vp, vp, i32, i32, i32, i32, i64, f32, vp, vp, vp]),
     "woft_inorm_apply": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, vp]),
     "woft_preprocess_bgr_u8": (i32, [vp, i32, i32, vp, i32, i32, i32, i32, vp]),
     "woft_avgpool2_nhwc": (i32, [vp, i32, i32, i32, vp, vp]),
     "woft_corr_lookup": (i32, [C.POINTER(LookupParams), vp]),
-    "woft_tile_rows": (i32, [vp, i32, i32, i32, vp, vp]),
+    "woft_tile_rows": (i32, [vp, i32, i32, i32, i32, vp, vp]),
     "woft_coords_update": (i32, [vp, vp, i32, i32, i64, vp, vp, i32, vp]),
     "woft_coords_init": (i32, [vp, i32, i32, vp, vp, i32, vp]),
     "woft_colsum": (i32, [vp, i64, i32, vp, i32, vp, vp]),

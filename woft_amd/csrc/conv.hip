@@ -752,7 +752,7 @@ int launch_halo(const woft_conv_params& p, hipStream_t s) {
 // service group holds 8 even and 8 odd rows whose (r >> 1) & 7 are all different).
 // One stage only (32 KiB): four workgroups per CU overlap each other's load, MFMA and store-drain phases,
 // which measured faster than two stages with two workgroups (tools/bench_cgemm.py).
-template <int TERMS, int WM, int WN, int STAGES>
+template <int TERMS, int WM, int WN, int STAGES, bool OUT16 = false>
 __global__ __launch_bounds__(WM * WN * 64, 4)
 void corr_gemm_bf16_kernel(const __bf16* __restrict__ a, const __bf16* __restrict__ b, int line_elems_per_row,
                            const woft_conv_params p, int abl) {
@@ -901,7 +901,8 @@ void corr_gemm_bf16_kernel(const __bf16* __restrict__ a, const __bf16* __restric
                 if (m >= M || n >= p.cout || (abl & 1)) continue;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
-                if (abl & 16) __builtin_nontemporal_store(v, (f32x4*)(p.out + m * p.ldo + n));
+                if (OUT16) *(bf16x4*)((__bf16*)p.out + m * p.ldo + n) = __builtin_convertvector(v, bf16x4);   // 8 lanes x 8 B per row
+                else if (abl & 16) __builtin_nontemporal_store(v, (f32x4*)(p.out + m * p.ldo + n));
                 else *(f32x4*)(p.out + m * p.ldo + n) = v;
             }
             __builtin_amdgcn_wave_barrier();
@@ -1014,7 +1015,8 @@ extern "C" int woft_conv2d(const woft_conv_params* pp, void* stream) {
 }
 
 extern "C" int woft_corr_gemm_bf16(const void* a, const void* b, int64_t m, int64_t n, int64_t rows_a, int64_t rows_b,
-                                   int32_t k, float alpha, float* out, int64_t ldo, int32_t terms, void* stream) {
+                                   int32_t k, float alpha, void* out, int64_t ldo, int32_t terms, int32_t out_bf16,
+                                   void* stream) {
     if (!a || !b || !out || m <= 0 || n <= 0 || k <= 0 || ldo < n || n % 4 != 0 || ldo % 4 != 0) return WOFT_EINVAL;
     if (terms != 1 && terms != 3) return WOFT_EINVAL;
     if (k % (terms == 3 ? 32 : 64) != 0) return WOFT_EINVAL;
@@ -1023,7 +1025,7 @@ extern "C" int woft_corr_gemm_bf16(const void* a, const void* b, int64_t m, int6
     p.n_img = 1; p.ho = 1; p.wo = (int32_t)m;            // M = m rows
     p.alpha = alpha;
     p.cout = (int32_t)n; p.cout_pad = (int32_t)rows_b;
-    p.out = out; p.ldo = ldo;
+    p.out = (float*)out; p.ldo = ldo;                    // (bf16 storage: the kernel re-types the pointer)
     p.epi = WOFT_EPI_LINEAR;
     const int abl = g_tuning[2];                         // ablation bits (tools/bench_cgemm.py); 0 in production
     hipStream_t s = (hipStream_t)stream;
@@ -1031,12 +1033,18 @@ extern "C" int woft_corr_gemm_bf16(const void* a, const void* b, int64_t m, int6
     // (half the operand traffic) were measured at the same 2.05-2.17 ms for level 0: see DESIGN.md section 4.
     if (rows_a % 128 != 0 || rows_b % 128 != 0) return WOFT_EINVAL;
     dim3 grid((unsigned)(ceil_div64(m, 128) * (rows_b / 128)));
-    if (terms == 3)
+    if (terms == 3 && !out_bf16)
         hipLaunchKernelGGL((corr_gemm_bf16_kernel<3, 2, 2, 1>), grid, dim3(256), 0, s, (const __bf16*)a, (const __bf16*)b,
                            2 * k, p, abl);
-    else
+    else if (terms == 3)
+        hipLaunchKernelGGL((corr_gemm_bf16_kernel<3, 2, 2, 1, true>), grid, dim3(256), 0, s, (const __bf16*)a,
+                           (const __bf16*)b, 2 * k, p, abl);
+    else if (!out_bf16)
         hipLaunchKernelGGL((corr_gemm_bf16_kernel<1, 2, 2, 1>), grid, dim3(256), 0, s, (const __bf16*)a, (const __bf16*)b,
                            k, p, abl);
+    else
+        hipLaunchKernelGGL((corr_gemm_bf16_kernel<1, 2, 2, 1, true>), grid, dim3(256), 0, s, (const __bf16*)a,
+                           (const __bf16*)b, k, p, abl);
     return woft_launch_status();
 }
 

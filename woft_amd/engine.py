@@ -25,6 +25,8 @@ from . import _lib, ops
 from .ops import Act, new_act
 
 EPI = _lib
+# the motion encoder's flow branch on a second HIP stream, beside the lookup and the correlation branch (off: one stream)
+SIDE_STREAM = os.environ.get("WOFT_SIDE_STREAM", "0") != "0"
 
 
 def _ru(x, m):
@@ -87,10 +89,13 @@ class _Enc:
 
 
 class RaftEngine:
-    def __init__(self, state_dict, small=False, weighted=True, precision="fp32", corr="volume"):
+    def __init__(self, state_dict, small=False, weighted=True, precision="fp32", corr="volume", volume_storage=None):
         """precision: "fp32" (exact fp32 MFMA), "bf16x3" (split-bf16, fp32-emulating) or "bf16".
         corr: "volume" (all-pairs volume + pyramid in HBM, corr.py:13-69) or "otf" (volume-free lookup from the
-        feature maps, the reference's alternate_corr idea, corr.py:72-100; split-bf16 precisions only)."""
+        feature maps, the reference's alternate_corr idea, corr.py:72-100; split-bf16 precisions only).
+        volume_storage: element type of the volume in HBM, "fp32" or "bf16" (fp32 accumulators rounded once at the GEMM's
+        store; lookup interpolation and output stay fp32).  Default: "bf16" in the plain-bf16 precision -- its operating
+        point, half the store stream and the lookup's reads, SURVEY 8d -- else "fp32"."""
         if precision not in ops.PRECISION:
             raise ValueError(f"precision must be one of {sorted(ops.PRECISION)}")
         if corr not in ("volume", "otf"):
@@ -99,6 +104,9 @@ class RaftEngine:
             raise ValueError("corr='otf' runs on the split-bf16 matrix-core path: precision 'bf16x3' or 'bf16'")
         self.precision = precision
         self.corr = corr
+        self.volume_storage = volume_storage or ("bf16" if precision == "bf16" else "fp32")
+        if self.volume_storage not in ("fp32", "bf16") or (self.volume_storage == "bf16" and precision == "fp32"):
+            raise ValueError("volume_storage: 'fp32', or 'bf16' with the split-bf16 precisions (their GEMM packs it)")
         _lib.load()
         if not torch.cuda.is_available():
             raise _lib.WoftHipError("woft_amd needs a HIP device: there is no CPU fallback")
@@ -185,6 +193,7 @@ class _Plan:
         self.source_tag = None
         self.lookup_events = None
         self.wh_events = None      # bench hook: list collecting (start, end) HIP events per lookup launch
+        self._side, self._fork_ev, self._join_ev = torch.cuda.Stream(), torch.cuda.Event(), torch.cuda.Event()
         self.conv_events = None    # bench hook: {tag: [(start, end)]} for the tagged conv launches of the iteration program
         sp = eng.spec
         hf, wf = hp // 8, wp // 8
@@ -220,7 +229,8 @@ class _Plan:
                 rows = z(_ru(n, 128), sp.fdim)
                 self.f2rows.append(rows)
                 self.f2s.append(bf(rows))
-                self.vol.append(z(P, n))
+                vdt = torch.bfloat16 if eng.volume_storage == "bf16" else torch.float32
+                self.vol.append(torch.zeros(P, n, dtype=vdt, device=dev))
             h, w = h // 2, w // 2
         # context: GRU state and the GRU input buffer [inp | motion | flow | pad]
         self.net0 = new_act(1, hf, wf, sp.hdim, zero=True)
@@ -425,11 +435,15 @@ class _Plan:
                      ("conv", cp(self.fl1, e.convf2, self.cf, co_off=96, epi=EPI.EPI_RELU)),
                      ("conv", cp(self.cf, e.convm, self.xbuf, co_off=sp.cdim, epi=EPI.EPI_RELU))]
         else:                   # BasicMotionEncoder update.py:89-97: cor(192) | flo(64) -> 126, cat flow
-            prog += [("conv", cp(self.corr, e.convc1, self.c1, epi=EPI.EPI_RELU), "convc1"),
-                     ("conv", cp(self.c1, e.convc2, self.cf, co_off=0, epi=EPI.EPI_RELU), "convc2"),
-                     ("conv", cp(self.flow4, e.convf1, self.fl1, epi=EPI.EPI_RELU), "convf1"),
-                     ("conv", cp(self.fl1, e.convf2, self.cf, co_off=192, epi=EPI.EPI_RELU), "convf2"),
-                     ("conv", cp(self.cf, e.convm, self.xbuf, co_off=sp.cdim, epi=EPI.EPI_RELU), "convm")]
+            flo = [("conv", cp(self.flow4, e.convf1, self.fl1, epi=EPI.EPI_RELU), "convf1"),
+                   ("conv", cp(self.fl1, e.convf2, self.cf, co_off=192, epi=EPI.EPI_RELU), "convf2")]
+            cor = [("conv", cp(self.corr, e.convc1, self.c1, epi=EPI.EPI_RELU), "convc1"),
+                   ("conv", cp(self.c1, e.convc2, self.cf, co_off=0, epi=EPI.EPI_RELU), "convc2")]
+            if SIDE_STREAM:     # the flow branch (reads flow4, writes fl1 and cf[:, 192:]) beside lookup + correlation branch
+                prog = [("fork", flo)] + prog + cor + [("join", None)]
+            else:
+                prog += cor + flo
+            prog.append(("conv", cp(self.cf, e.convm, self.xbuf, co_off=sp.cdim, epi=EPI.EPI_RELU), "convm"))
         # GRU half steps: z|r conv (sigmoid, r*h fused), q conv (tanh + state blend fused)
         states = [h_in, self.hA, self.hB] if len(e.zr) == 2 else [h_in, self.hB]
         if len(e.zr) == 1 and not first:
@@ -475,6 +489,14 @@ class _Plan:
             elif kind == "apply":
                 raw, out, mode, res = a
                 ops.inorm_apply(raw, self.mean, self.rstd, out, mode, res=res)
+            elif kind == "fork":
+                self._fork_ev.record()
+                self._side.wait_event(self._fork_ev)
+                with torch.cuda.stream(self._side):
+                    self.run(a)
+                    self._join_ev.record()
+            elif kind == "join":
+                torch.cuda.current_stream().wait_event(self._join_ev)
             elif kind == "pool":
                 ops.avgpool2(a[0], a[1])
             elif kind == "split":

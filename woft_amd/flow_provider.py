@@ -67,7 +67,9 @@ class RAFTWrapper:
         if self.corr == "otf" and self.precision == "fp32":
             raise ValueError("alternate_corr / corr='otf' runs on the split-bf16 matrix-core path: set precision "
                              "'bf16x3' (fp32-emulating) or 'bf16'")
-        self.engine = RaftEngine(state_dict, small=small, weighted=weighted, precision=self.precision, corr=self.corr)
+        # flow config key `volume_storage` ("fp32" | "bf16"): element type of the correlation volume (corr = "volume")
+        self.engine = RaftEngine(state_dict, small=small, weighted=weighted, precision=self.precision, corr=self.corr,
+                                 volume_storage=getattr(self.C, "volume_storage", None))
         # opt-in (flow config key `graph`, env WOFT_GRAPH=1): the ~330 launches of a flow -- a static list per
         # resolution, fixed buffers, no allocation -- are captured once into a hipGraph and replayed per frame
         self.use_graph = (os.environ.get("WOFT_GRAPH") or str(int(bool(getattr(self.C, "graph", False))))) == "1"

@@ -398,10 +398,13 @@ def split_bf16_lines(x, out):
 
 
 def corr_gemm_bf16(a, b, m, n, alpha, out, terms):
-    """out[:m, :n] = alpha * A B^T on pre-split bf16 operands (rows padded to 128); see woft_corr_gemm_bf16."""
+    """out[:m, :n] = alpha * A B^T on pre-split bf16 operands (rows padded to 128); see woft_corr_gemm_bf16.
+    out: float32, or bfloat16 for the bf16-storage volume."""
     k = a.shape[1] // 2 if terms == 3 else a.shape[1]
+    assert out.dtype in (torch.float32, torch.bfloat16)
     check(_lib.load().woft_corr_gemm_bf16(ptr(a), ptr(b), m, n, a.shape[0], b.shape[0], k, float(alpha), ptr(out),
-                                          out.shape[1], terms, stream_ptr()), "woft_corr_gemm_bf16")
+                                          out.shape[1], terms, int(out.dtype == torch.bfloat16), stream_ptr()),
+          "woft_corr_gemm_bf16")
 
 
 def corr_volume(f1, f2_rows, n_q, out, alpha, precision=0, f2_hi=None, f2_lo=None):
@@ -425,39 +428,42 @@ def corr_volume(f1, f2_rows, n_q, out, alpha, precision=0, f2_hi=None, f2_lo=Non
     return p
 
 
-def tiled_dims(h, w):
-    """(tile rows, tile cols, floats per plane) of an h x w map in the 4x4-tiled volume layout."""
-    ht, wt = (h + 3) // 4, (w + 3) // 4
-    return ht, wt, ht * wt * 16
+def tiled_dims(h, w, tw=4):
+    """(tile rows, tile cols, elements per plane) of an h x w map in the volume layout of 4-row x tw-column tiles."""
+    ht, wt = (h + 3) // 4, (w + tw - 1) // tw
+    return ht, wt, ht * wt * 4 * tw
 
 
-def tile_rows(x, out):
-    """x: Act (1, h, w, c) -> out rows in 4x4-tile order (first ht*wt*16 rows of `out`)."""
-    check(_lib.load().woft_tile_rows(ptr(x.t), x.h, x.w, x.cs, ptr(out), stream_ptr()), "woft_tile_rows")
+def tile_rows(x, out, tw=4):
+    """x: Act (1, h, w, c) -> out rows in (4 x tw)-tile order (first ht*wt*4*tw rows of `out`)."""
+    check(_lib.load().woft_tile_rows(ptr(x.t), x.h, x.w, x.cs, tw, ptr(out), stream_ptr()), "woft_tile_rows")
 
 
-def tile_planes(planes):
-    """(P, h, w) tensor of per-source-pixel planes -> (P, ht*wt*16) in the tiled layout (test helper)."""
+def tile_planes(planes, tw=4):
+    """(P, h, w) tensor of per-source-pixel planes -> (P, ht*wt*4*tw) in the tiled layout (test helper)."""
     P, h, w = planes.shape
-    ht, wt, n = tiled_dims(h, w)
-    pad = torch.zeros(P, ht * 4, wt * 4, dtype=planes.dtype, device=planes.device)
+    ht, wt, n = tiled_dims(h, w, tw)
+    pad = torch.zeros(P, ht * 4, wt * tw, dtype=planes.dtype, device=planes.device)
     pad[:, :h, :w] = planes
-    return pad.reshape(P, ht, 4, wt, 4).permute(0, 1, 3, 2, 4).reshape(P, n).contiguous()
+    return pad.reshape(P, ht, 4, wt, tw).permute(0, 1, 3, 2, 4).reshape(P, n).contiguous()
 
 
-def untile_planes(vol, h, w):
-    """inverse of tile_planes: (P, >= ht*wt*16) -> (P, h, w)."""
-    ht, wt, n = tiled_dims(h, w)
+def untile_planes(vol, h, w, tw=4):
+    """inverse of tile_planes: (P, >= ht*wt*4*tw) -> (P, h, w)."""
+    ht, wt, n = tiled_dims(h, w, tw)
     P = vol.shape[0]
-    return vol[:, :n].reshape(P, ht, wt, 4, 4).permute(0, 1, 3, 2, 4).reshape(P, ht * 4, wt * 4)[:, :h, :w]
+    return vol[:, :n].reshape(P, ht, wt, 4, tw).permute(0, 1, 3, 2, 4).reshape(P, ht * 4, wt * tw)[:, :h, :w]
 
 
-def make_lookup_params(vols, dims, coords, out, radius):
-    """vols[l]: (P, plane_l) tiled volumes; dims[l] = (H_l, W_l)."""
+def make_lookup_params(vols, dims, coords, out, radius, tw=4):
+    """vols[l]: (P, plane_l) tiled volumes (4 x tw tiles), all float32 or all bfloat16; dims[l] = (H_l, W_l)."""
     p = LookupParams()
+    assert len({v.dtype for v in vols}) == 1 and vols[0].dtype in (torch.float32, torch.bfloat16)
+    p.vol_bf16 = int(vols[0].dtype == torch.bfloat16)
+    p.tile_w = tw
     for l, v in enumerate(vols):
         p.vol[l] = ptr(v)
-        p.ht[l], p.wt[l], n = tiled_dims(*dims[l])
+        p.ht[l], p.wt[l], n = tiled_dims(*dims[l], tw)
         assert v.shape[1] >= n
         p.plane[l] = v.shape[1]
     p.levels, p.radius = len(vols), radius
