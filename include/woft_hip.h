@@ -211,6 +211,8 @@ typedef struct woft_lookup_otf_params {
     const float* coords;    /* [hf*wf][2]                                                           */
     float* out;             /* [hf*wf][ldo], channel order of woft_corr_lookup                      */
     int32_t ldo;
+    int32_t ablate;         /* developer knob of tools/bench_lookup_otf.py (1: no target-row stream after the first steps,
+                               2: no MFMAs, 4: no window scatter, 8: no interpolation / output); 0 in production */
 } woft_lookup_otf_params;
 int woft_corr_lookup_otf(const woft_lookup_otf_params* p, void* stream);
 /* NHWC map [h][w][c] -> its rows in (4 x tile_w)-tile order [(ceil(h/4)*ceil(w/tile_w)*4*tile_w)][c], zero rows outside

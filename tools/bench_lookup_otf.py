@@ -34,8 +34,19 @@ def main():
     coords = (base + flow + noise).contiguous()
     out = torch.zeros(P, 352, device="cuda")
     lp = ops.make_lookup_otf_params(f1s, f2s, dims, hf, wf, c, coords, out, 4, 3)
+    lp.ablate = int(os.environ.get("OTF_ABL", "0"))     # developer ablation bits (include/woft_hip.h)
     ms = bench(lambda: ops.run_lookup_otf(lp), reps=20)
-    print(f"volume-free lookup {hf}x{wf}, flow {flow}: {ms * 1e3:8.1f} us")
+    print(f"volume-free lookup {hf}x{wf}, flow {flow}, ablate {lp.ablate}: {ms * 1e3:8.1f} us")
+    if lp.ablate & 16:      # per-workgroup timeline: [start | per level: coords written, synced, stream primed, chunks done, samples written]
+        import numpy as np
+        torch.cuda.synchronize()
+        rows = out.view(hf, wf, 352)[::8, ::8, 324:348].contiguous().view(torch.int32).cpu().numpy().astype(np.int64).reshape(-1, 24)
+        d = np.diff(rows[:, :21], axis=1) & 0xffffffff
+        names = ["coords", "sync", "bbox+zero+prime", "chunks", "samples"]
+        print("  A fragments + setup -> first level: included in level 0 'coords'")
+        for l in range(4):
+            print(f"  level {l}: " + ", ".join(f"{n} {int(np.median(d[:, 5 * l + k]))}" for k, n in enumerate(names)))
+        print(f"  workgroup total (median cycles): {int(np.median((rows[:, 20] - rows[:, 0]) & 0xffffffff))}")
 
 
 if __name__ == "__main__":

@@ -14,6 +14,9 @@
 // chunks): always correct, fast when the flow is locally smooth.
 //
 // Sampling rule, channel order and zero padding: as corr_lookup_kernel (lookup.hip).
+#include <type_traits>
+#include <utility>
+
 #include "common.h"
 #include "dma.h"
 
@@ -29,20 +32,22 @@ __global__ __launch_bounds__(TW * 32, 2) void corr_lookup_otf_kernel(const woft_
     constexpr int NWV = NT / 64;                        // waves: NPX / 32 row groups x 2 column halves
     constexpr int TSH = (TW == 16) ? 4 : 3;             // log2(TW)
     constexpr int NW = 2 * R + 1, N2 = NW * NW;
-    constexpr int NS = (N2 + 3) / 4;                    // samples per thread (4 threads per pixel)
     constexpr int LD = (TERMS == 3) ? 2 * K : K;        // elements per operand row
     constexpr int NK = LD / 64;                         // K steps (one 128-byte line each)
     constexpr int NSUB = (TERMS == 3) ? 2 : 4;          // MFMA k sub-steps per line
     // LDS ring of B rows: NST stages of one K step each, consumed GS steps per workgroup barrier, DEPTH groups in flight
-    // beyond the one being computed (latency from beyond L2).  (Round 1 synchronised after every step, 6 MFMAs per wave;
-    // halving the barriers changed nothing measurable -- 95.2 vs 95.4 fps in one call: the kernel is paced by the stream
-    // of target rows from beyond L2, not by its barriers.)
+    // beyond the one being computed.  Where the time goes (round-2 ablation, tools/bench_lookup_otf.py OTF_ABL bits +
+    // s_memtime stamps, 1080p, 89 us): without the target-row stream -6 us, without MFMAs -21 us, without both
+    // and without window drops / output still 51 us -- the skeleton: per level ~9 k cycles of coordinates, box, window
+    // zeroing and sampling, per 64-column chunk ~4.6 k cycles of which ~2.5 k were the window drop fetching each pixel's
+    // window origin from LDS one read at a time (fixed below), and LDS-latency waits before every MFMA triple (fixed
+    // below: B fragments one sub-step ahead).  89.2 -> 85.0 us, +1.4 % frames/s.
     constexpr int GS = 2, NGRP = 3, NST = GS * NGRP, DEPTH = NGRP - 1;
     static_assert(NK % GS == 0, "K steps per chunk must be a multiple of the steps per barrier");
     __shared__ __attribute__((aligned(16))) __bf16 stage[NST * 64 * 64];    // NST stages of 64 B rows, 128 B each
     constexpr int WS = NW + 1, WLD = WS * WS + 1;       // (2r+2)^2 window of a pixel (+1: spreads the LDS banks)
-    __shared__ float Wn[NPX * WLD];                     // the windows of the source pixels at the current level
-    __shared__ int s_wx0[NPX], s_wy0[NPX];
+    __shared__ __attribute__((aligned(16))) float Wn[NPX * WLD];                     // the windows of the source pixels at the current level
+    __shared__ int2 s_w0[NPX];                          // window origin (x, y) of every source pixel at the current level
     __shared__ float s_fx[NPX], s_fy[NPX];
 
     const int tid = threadIdx.x;
@@ -89,19 +94,37 @@ __global__ __launch_bounds__(TW * 32, 2) void corr_lookup_otf_kernel(const woft_
     const int sw = (r32 >> 1) & 7;
     const __bf16* b_rows = stage + (wn * 32 + r32) * 64;
 
-    const int mypix = tid >> 2, part = tid & 3;         // gather: 4 threads per source pixel
+    // developer probe (ablate & 16): s_memtime stamps of thread 0 -> the padding columns of the tile's first output row
+    uint32_t* stamps = ((p.ablate & 16) && tid == 0 && p.ldo >= 4 * N2 + 24)
+                           ? (uint32_t*)(p.out + ((int64_t)py0 * p.wf + px0) * p.ldo + 4 * N2) : nullptr;
+    int n_stamp = 0;
+    auto stamp = [&]() { if (stamps && n_stamp < 24) stamps[n_stamp++] = (uint32_t)__builtin_amdgcn_s_memtime(); };
+    stamp();
+    const int mypix = tid >> 2, part = tid & 3;         // sampling: 4 threads per source pixel
     const int gy = py0 + (mypix >> TSH), gx = px0 + (mypix & (TW - 1));
     const bool pvalid = gy < p.hf && gx < p.wf;
+    constexpr int NS = (N2 + 3) / 4;                    // samples per thread
+
+    // lookup centre of source pixel `tid` (threads < NPX), read once: it is the same at every level
+    float ccx = 0.f, ccy = 0.f;
+    bool cvalid = false;
+    if (tid < NPX) {
+        const int y = py0 + (tid >> TSH), x = px0 + (tid & (TW - 1));
+        cvalid = y < p.hf && x < p.wf;
+        if (cvalid) {
+            ccx = p.coords[((int64_t)y * p.wf + x) * 2];
+            ccy = p.coords[((int64_t)y * p.wf + x) * 2 + 1];
+        }
+    }
 
     for (int l = 0; l < p.levels; ++l) {
         const int W = p.w[l], H = p.h[l];
         if (tid < NPX) {
-            const int y = py0 + (tid >> TSH), x = px0 + (tid & (TW - 1));
             int wx0 = 0x3fffffff, wy0 = 0x3fffffff;     // (outside the grid: excluded from the box)
             float fx = 0.f, fy = 0.f;
-            if (y < p.hf && x < p.wf) {
+            if (cvalid) {
                 const float sc = 1.0f / (float)(1 << l);
-                const float xs = p.coords[((int64_t)y * p.wf + x) * 2] * sc, ys = p.coords[((int64_t)y * p.wf + x) * 2 + 1] * sc;
+                const float xs = ccx * sc, ys = ccy * sc;
                 float flx = floorf(xs), fly = floorf(ys);
                 fx = xs - flx;
                 fy = ys - fly;
@@ -110,16 +133,18 @@ __global__ __launch_bounds__(TW * 32, 2) void corr_lookup_otf_kernel(const woft_
                 wx0 = (int)flx - R;
                 wy0 = (int)fly - R;
             }
-            s_wx0[tid] = wx0; s_wy0[tid] = wy0; s_fx[tid] = fx; s_fy[tid] = fy;
+            s_w0[tid] = make_int2(wx0, wy0); s_fx[tid] = fx; s_fy[tid] = fy;
         }
+        stamp();
         __syncthreads();
+        stamp();
         // bounding box of the valid windows: butterfly over the 64 lanes of every wave (all waves hold the result)
         int bx0, bx1, by0, by1;
         {
             bx0 = 0x3fffffff; bx1 = -0x3fffffff; by0 = 0x3fffffff; by1 = -0x3fffffff;
 #pragma unroll
             for (int e = lane; e < NPX; e += 64) {
-                const int vx = s_wx0[e], vy = s_wy0[e];
+                const int vx = s_w0[e].x, vy = s_w0[e].y;
                 if (vx != 0x3fffffff) {
                     bx0 = vx < bx0 ? vx : bx0; bx1 = vx > bx1 ? vx : bx1;
                     by0 = vy < by0 ? vy : by0; by1 = vy > by1 ? vy : by1;
@@ -142,7 +167,11 @@ __global__ __launch_bounds__(TW * 32, 2) void corr_lookup_otf_kernel(const woft_
         const int bw = bx1 - bx0 + 1, bh = by1 - by0 + 1;
         const int N = (bw > 0 && bh > 0) ? bw * bh : 0;
 
-        for (int i = tid; i < NPX * WLD; i += NT) Wn[i] = 0.f;      // cells outside the map stay zero
+        {                                                           // cells outside the map stay zero
+            const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+            for (int i = tid; i < NPX * WLD / 4; i += NT) ((f32x4*)Wn)[i] = z4;
+            static_assert((NPX * WLD) % 4 == 0, "window array is zeroed 16 bytes at a time");
+        }
         // (visible to all waves after the first step barrier below; S == 0: the barrier before the interpolation)
 
         const char* f2 = (const char*)p.f2[l];
@@ -163,6 +192,7 @@ __global__ __launch_bounds__(TW * 32, 2) void corr_lookup_otf_kernel(const woft_
                 }
             }
             const uint32_t st = st_addr + (uint32_t)(s_idx % NST) * 8192u;
+            if (!(p.ablate & 1) || s_idx < NST)
 #pragma unroll
             for (int t = 0; t < QPW; ++t) lds_dma16(f2 + is_k * 128, b_off[t], st + (uint32_t)(wave + NWV * t) * 1024u);
             if (++is_k == nk) { is_k = 0; ++is_c; }
@@ -175,6 +205,7 @@ __global__ __launch_bounds__(TW * 32, 2) void corr_lookup_otf_kernel(const woft_
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         int c0 = 0;
+        stamp();
         for (int s0 = 0; s0 < S; s0 += NK) {             // one 64-column chunk per iteration, K steps unrolled
 #pragma unroll
             for (int kg = 0; kg < NK / GS; ++kg) {
@@ -188,29 +219,39 @@ __global__ __launch_bounds__(TW * 32, 2) void corr_lookup_otf_kernel(const woft_
 #pragma unroll
                     for (int e = 0; e < GS; ++e) issue((g + DEPTH) * GS + e);
                 }
-#pragma unroll
-                for (int e = 0; e < GS; ++e) {
-                    const int ks = kg * GS + e;
-                    const int s_idx = s0 + ks;
-                    const __bf16* br = b_rows + (s_idx % NST) * 4096;
-                    if (TERMS == 3) {
-#pragma unroll
-                        for (int s2 = 0; s2 < 2; ++s2) {
-                            const int ch = ((s2 * 2 + hh) ^ sw) * 8, cl = ((4 + s2 * 2 + hh) ^ sw) * 8;
-                            const bf16x8 bh = *(const bf16x8*)(br + ch), bl = *(const bf16x8*)(br + cl);
-                            const bf16x8 ah = afr[ks][s2][0], al = afr[ks][s2][TERMS == 3 ? 1 : 0];
-                            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);   // (order of corr_gemm_bf16_kernel)
-                            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
-                            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
-                        }
-                    } else {
-#pragma unroll
-                        for (int s2 = 0; s2 < 4; ++s2) {
-                            const int ch = ((s2 * 2 + hh) ^ sw) * 8;
-                            const bf16x8 bh = *(const bf16x8*)(br + ch);
-                            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks][s2][0], bh, acc, 0, 0, 0);
-                        }
-                    }
+                // the GS steps of the group as one list of k sub-steps; the B fragments of sub-step u + 1 are requested
+                // before the MFMAs of sub-step u (two register sets) -- left alone the compiler reads, waits out the LDS
+                // latency and only then issues the three MFMAs, every sub-step
+                constexpr int NU = GS * NSUB;
+                bf16x8 bq[2][TERMS == 3 ? 2 : 1];
+                auto load_b = [&](auto u_tag) {
+                    constexpr int u = decltype(u_tag)::value;
+                    constexpr int e = u / NSUB, s2 = u % NSUB;
+                    const __bf16* br = b_rows + ((s0 + kg * GS + e) % NST) * 4096;
+                    bq[u & 1][0] = *(const bf16x8*)(br + ((s2 * 2 + hh) ^ sw) * 8);
+                    if (TERMS == 3) bq[u & 1][TERMS == 3 ? 1 : 0] = *(const bf16x8*)(br + ((4 + s2 * 2 + hh) ^ sw) * 8);
+                };
+                if (!(p.ablate & 2)) {
+                    load_b(std::integral_constant<int, 0>{});
+                    [&]<int... U>(std::integer_sequence<int, U...>) {
+                        ([&] {
+                            constexpr int u = U, e = u / NSUB, s2 = u % NSUB;
+                            const int ks = kg * GS + e;
+                            if constexpr (u + 1 < NU) load_b(std::integral_constant<int, u + 1>{});
+                            __builtin_amdgcn_sched_barrier(0);
+                            const bf16x8 bh = bq[u & 1][0];
+                            if (TERMS == 3) {
+                                const bf16x8 bl = bq[u & 1][TERMS == 3 ? 1 : 0];
+                                const bf16x8 ah = afr[ks][s2][0], al = afr[ks][s2][TERMS == 3 ? 1 : 0];
+                                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);   // (order of corr_gemm_bf16_kernel)
+                                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+                                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+                            } else {
+                                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks][s2][0], bh, acc, 0, 0, 0);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }(), ...);
+                    }(std::make_integer_sequence<int, NU>{});
                 }
             }
             // ---- chunk complete: every lane drops its 16 correlations (one box position, 16 source pixels) into
@@ -219,20 +260,29 @@ __global__ __launch_bounds__(TW * 32, 2) void corr_lookup_otf_kernel(const woft_
                 const int pos = c0 + wn * 32 + r32;
                 const int by = pos / bw, bx = pos - by * bw;
                 const int tx = bx0 + bx, ty = by0 + by;  // target pixel of this column
-                const bool col_ok = pos < N;
+                const bool col_ok = pos < N && !(p.ablate & 4);
+                // window origins of the 16 source pixels this lane's accumulator holds: ALL read before the first window
+                // cell is written (a read after a write to the same address space is not moved above it: the reads then
+                // ran one at a time, each waiting out the LDS latency -- ~2.5 k cycles of every 7.6 k-cycle chunk)
+                int2 w0[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) w0[r] = s_w0[wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                    const int cx = tx - s_wx0[m], cy = ty - s_wy0[m];
+                    const int cx = tx - w0[r].x, cy = ty - w0[r].y;
                     if (col_ok && cx >= 0 && cx < WS && cy >= 0 && cy < WS) Wn[m * WLD + cy * WS + cx] = acc[r] * p.alpha;
                     acc[r] = 0.f;
                 }
             }
             c0 += 64;
         }
+        stamp();
         __syncthreads();
         // ---- bilinear samples from the pixel's own window: the arithmetic of corr_lookup_kernel ----
-        if (pvalid) {
+        // (4 threads per pixel, a sample at a time.  Batching the window reads, or a wave per pixel with lane = sample and
+        // contiguous stores, measured the same or slower: 4.6 k / 8 k vs 3.6 k cycles per level)
+        if (pvalid && !(p.ablate & 8)) {
             const float fx = s_fx[mypix], fy = s_fy[mypix];
             const float* wq = Wn + mypix * WLD;
             float* o = p.out + ((int64_t)gy * p.wf + gx) * p.ldo + l * N2;
@@ -248,6 +298,7 @@ __global__ __launch_bounds__(TW * 32, 2) void corr_lookup_otf_kernel(const woft_
                 o[s] = top * (1.f - fy) + bot * fy;
             }
         }
+        stamp();
         __syncthreads();
     }
 }
