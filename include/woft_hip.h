@@ -160,7 +160,11 @@ int woft_corr_gemm_bf16(const void* a, const void* b, int64_t m, int64_t n, int6
  * finalize per-channel statistics from the conv epilogue's partial sums ... */
 int woft_inorm_finalize(const float* stat_sum, const float* stat_sq, int32_t n_part, int32_t ld,
                         int32_t channels, int32_t channels_pad, int64_t count, float eps,
-                        float* mean, float* rstd, void* stream);   /* mean/rstd[channels..channels_pad) := 0 */
+                        float* mean, float* rstd, void* ws, void* stream);   /* mean/rstd[channels..channels_pad) := 0 */
+/* ws: NULL (one workgroup does it all), or woft_inorm_ws_bytes() bytes of device scratch, ZEROED ONCE by the caller and
+ * then owned by the calls on one stream (it holds the cross-workgroup partial sums and their ticket counter, which every
+ * call leaves at zero); channels_pad <= 256, ld % 4 == 0. */
+int64_t woft_inorm_ws_bytes(void);
 /* ... and apply them.  mode 0: (x-mean)*rstd ; 1: relu(.) ; 2: relu(res + relu(.)) */
 int woft_inorm_apply(const float* x, const float* mean, const float* rstd, const float* res,
                      float* out, int64_t n_pix, int32_t channels, int32_t mode, void* stream);

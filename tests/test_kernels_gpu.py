@@ -399,6 +399,33 @@ def test_instance_norm(ops, tiles, precision):
         _close(out.nchw(), ref, 3e-5 if precision == "fp32" else 2e-4, what=f"instance norm mode {mode}")
 
 
+@pytest.mark.parametrize("n_part,channels,ld", [(8100, 64, 64), (2040, 96, 128), (510, 128, 128), (37, 126, 128), (3, 64, 64),
+                                                (5000, 256, 256)])
+def test_instance_norm_finalize(ops, n_part, channels, ld):
+    """woft_inorm_finalize: many workgroups + last-workgroup total (with the scratch), the one-workgroup path (without), and
+    repeated calls on the same scratch all give the fp64 statistics of the partial sums; padding channels come out as zero."""
+    g = torch.Generator().manual_seed(n_part)
+    s1 = (torch.randn(n_part, ld, generator=g) * 40).cuda()
+    s2 = (torch.rand(n_part, ld, generator=g) * 900 + 30).cuda()
+    count = 64 * n_part
+    mu = s1.double().sum(0) / count
+    var = (s2.double().sum(0) / count - mu * mu).clamp_min(0)
+    want_mean, want_rstd = mu.float(), (1.0 / torch.sqrt(var + 1e-5)).float()
+    ws = ops.inorm_ws()
+    outs = []
+    for w in (ws, ws, None, ws):
+        mean, rstd = torch.full((ld,), 7.0, device="cuda"), torch.full((ld,), 7.0, device="cuda")
+        ops.inorm_finalize((s1, s2), n_part, ld, channels, count, mean, rstd, channels_pad=ld, ws=w)
+        torch.cuda.synchronize()
+        outs.append((mean.clone(), rstd.clone()))
+        assert float((mean[:channels] - want_mean[:channels]).abs().max()) <= 1e-6 * float(want_mean.abs().max()) + 1e-7
+        assert float(((rstd[:channels] - want_rstd[:channels]) / want_rstd[:channels]).abs().max()) <= 2e-6
+        assert float(mean[channels:].abs().max() if channels < ld else 0.0) == 0.0
+        assert float(rstd[channels:].abs().max() if channels < ld else 0.0) == 0.0
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[3][1])      # deterministic, scratch reusable
+    assert int(ws.view(torch.int32)[-16:].abs().sum()) == 0                                  # the ticket is back at zero
+
+
 def test_preprocess_and_pool(ops):
     rs = np.random.RandomState(0)
     img = rs.randint(0, 256, (37, 45, 3), dtype=np.uint8)

@@ -238,6 +238,7 @@ class _Plan:
         self._enc_scratch = {}
         n_stat = 2 * math.ceil((hp // 2) * (wp // 2) / 64) * 128
         self.stats = (z(n_stat), z(n_stat))
+        self.fin_ws = ops.inorm_ws(dev)
         self.mean, self.rstd = z(256), z(256)
         self.prog_f_src = self._encoder_program(eng.fnet, self.img[0], [(eng.fnet.conv2, self.f1, 0, EPI.EPI_LINEAR)])
         self.prog_f_dst = self._encoder_program(eng.fnet, self.img[1],
@@ -485,7 +486,7 @@ class _Plan:
                     ops.run_conv(a)
             elif kind == "fin":
                 rows, ld, c, c_pad, count = a
-                ops.inorm_finalize(self.stats, rows, ld, c, count, self.mean, self.rstd, channels_pad=c_pad)
+                ops.inorm_finalize(self.stats, rows, ld, c, count, self.mean, self.rstd, channels_pad=c_pad, ws=self.fin_ws)
             elif kind == "apply":
                 raw, out, mode, res = a
                 ops.inorm_apply(raw, self.mean, self.rstd, out, mode, res=res)

@@ -327,9 +327,14 @@ def conv2d(x, pc, c_out_stride=None, **kw):
     return out
 
 
-def inorm_finalize(stats, n_part, ld, channels, count, mean, rstd, eps=1e-5, channels_pad=None):
+def inorm_ws(device="cuda"):
+    """Scratch of woft_inorm_finalize (cross-workgroup partial sums + ticket), zeroed once; one per stream of calls."""
+    return torch.zeros(int(_lib.load().woft_inorm_ws_bytes()), dtype=torch.uint8, device=device)
+
+
+def inorm_finalize(stats, n_part, ld, channels, count, mean, rstd, eps=1e-5, channels_pad=None, ws=None):
     check(_lib.load().woft_inorm_finalize(ptr(stats[0]), ptr(stats[1]), n_part, ld, channels, channels_pad or channels,
-                                          count, eps, ptr(mean), ptr(rstd), stream_ptr()), "woft_inorm_finalize")
+                                          count, eps, ptr(mean), ptr(rstd), ptr(ws), stream_ptr()), "woft_inorm_finalize")
 
 
 def inorm_apply(x, mean, rstd, out, mode, res=None):
