@@ -165,8 +165,11 @@ int woft_inorm_finalize(const float* stat_sum, const float* stat_sq, int32_t n_p
  * then owned by the calls on one stream (it holds the cross-workgroup partial sums and their ticket counter, which every
  * call leaves at zero); channels_pad <= 256, ld % 4 == 0. */
 int64_t woft_inorm_ws_bytes(void);
-/* ... and apply them.  mode 0: (x-mean)*rstd ; 1: relu(.) ; 2: relu(res + relu(.)) */
+/* ... and apply them.  mode 0: (x-mean)*rstd ; 1: relu(.) ; 2: relu(res' + relu(.)), where res' = res (res_mode 0), or
+ * -- res being the RAW conv output of the block's shortcut, normalised here with its own statistics -- (res-res_mean)*res_rstd
+ * (res_mode 1; the 1x1 downsample branch, extractor.py:40-45) or relu of that (res_mode 2; the block input). */
 int woft_inorm_apply(const float* x, const float* mean, const float* rstd, const float* res,
+                     const float* res_mean, const float* res_rstd, int32_t res_mode,
                      float* out, int64_t n_pix, int32_t channels, int32_t mode, void* stream);
 
 /* uint8 BGR HWC image -> normalised RGB NHWC4 fp32 (2*x/255-1, 4th channel 0).

@@ -43,7 +43,7 @@ def test_argument_validation_without_gpu(lib):
     lp = _lib.LookupParams()
     assert lib.woft_corr_lookup(ctypes.byref(lp), None) == -1
     assert lib.woft_hfit(None, None, None, 10, None, 0, 1.0, 0, None, None, None, None) == -1
-    assert lib.woft_inorm_apply(None, None, None, None, None, 0, 0, 0, None) == -1
+    assert lib.woft_inorm_apply(None, None, None, None, None, None, 0, None, 0, 0, 0, None) == -1
     assert lib.woft_inorm_finalize(None, None, 0, 0, 0, 0, 0, 1e-5, None, None, None, None) == -1
 
 

@@ -65,7 +65,7 @@ _SIGS = {
     "woft_corr_gemm_bf16": (i32, [vp, vp, i64, i64, i64, i64, i32, f32, vp, i64, i32, i32, vp]),
     "woft_inorm_finalize": (i32, [vp, vp, i32, i32, i32, i32, i64, f32, vp, vp, vp, vp]),
     "woft_inorm_ws_bytes": (i64, []),
-    "woft_inorm_apply": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, vp]),
+    "woft_inorm_apply": (i32, [vp, vp, vp, vp, vp, vp, i32, vp, i64, i32, i32, vp]),
     "woft_preprocess_bgr_u8": (i32, [vp, i32, i32, vp, i32, i32, i32, i32, vp]),
     "woft_avgpool2_nhwc": (i32, [vp, i32, i32, i32, vp, vp]),
     "woft_corr_lookup": (i32, [C.POINTER(LookupParams), vp]),

@@ -111,8 +111,11 @@ __global__ __launch_bounds__(FIN_T) void inorm_finalize_kernel(const float* __re
     }
 }
 
+// res_mode (mode 2 only): 0 = res is an activation; 1 / 2 = res is a RAW conv output normalised here with its own statistics
+// (2: followed by ReLU) -- the shortcut of a residual block whose normalisation was deferred to this kernel
 __global__ void inorm_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
                                    const float* __restrict__ rstd, const float* __restrict__ res,
+                                   const float* __restrict__ res_mean, const float* __restrict__ res_rstd, int res_mode,
                                    float* __restrict__ out, int64_t n4, int channels, int mode) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
@@ -120,7 +123,17 @@ __global__ void inorm_apply_kernel(const float* __restrict__ x, const float* __r
         f32x4 v = *(const f32x4*)(x + i * 4);
         const f32x4 mu = *(const f32x4*)(mean + c), rs = *(const f32x4*)(rstd + c);
         f32x4 r = {0.f, 0.f, 0.f, 0.f};
-        if (mode == 2) r = *(const f32x4*)(res + i * 4);
+        if (mode == 2) {
+            r = *(const f32x4*)(res + i * 4);
+            if (res_mode != 0) {
+                const f32x4 rmu = *(const f32x4*)(res_mean + c), rrs = *(const f32x4*)(res_rstd + c);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    r[k] = (r[k] - rmu[k]) * rrs[k];
+                    if (res_mode == 2) r[k] = fmaxf(r[k], 0.f);
+                }
+            }
+        }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             float y = (v[k] - mu[k]) * rs[k];
@@ -178,14 +191,16 @@ extern "C" int woft_inorm_finalize(const float* stat_sum, const float* stat_sq, 
     return woft_launch_status();
 }
 
-extern "C" int woft_inorm_apply(const float* x, const float* mean, const float* rstd, const float* res, float* out,
+extern "C" int woft_inorm_apply(const float* x, const float* mean, const float* rstd, const float* res,
+                                const float* res_mean, const float* res_rstd, int32_t res_mode, float* out,
                                 int64_t n_pix, int32_t channels, int32_t mode, void* stream) {
     if (!x || !mean || !rstd || !out || n_pix <= 0 || channels <= 0 || channels % 4 != 0) return WOFT_EINVAL;
     if (mode < 0 || mode > 2 || (mode == 2 && !res)) return WOFT_EINVAL;
+    if (res_mode < 0 || res_mode > 2 || (res_mode != 0 && (mode != 2 || !res_mean || !res_rstd))) return WOFT_EINVAL;
     const int64_t n4 = n_pix * channels / 4;
     const int64_t blocks = ceil_div64(n4, 256);
     hipLaunchKernelGGL(inorm_apply_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0,
-                       (hipStream_t)stream, x, mean, rstd, res, out, n4, channels, mode);
+                       (hipStream_t)stream, x, mean, rstd, res, res_mean, res_rstd, res_mode, out, n4, channels, mode);
     return woft_launch_status();
 }
 

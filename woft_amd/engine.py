@@ -26,6 +26,8 @@ from .ops import Act, new_act
 
 EPI = _lib
 # the motion encoder's flow branch on a second HIP stream, beside the lookup and the correlation branch (off: one stream)
+# InstanceNorm encoders: conv1's output and the downsample branch stay raw for their consumers to normalise (0: materialised)
+DEFER_NORM = os.environ.get("WOFT_DEFER_NORM", "1") != "0"
 SIDE_STREAM = os.environ.get("WOFT_SIDE_STREAM", "0") != "0"
 
 
@@ -239,7 +241,7 @@ class _Plan:
         n_stat = 2 * math.ceil((hp // 2) * (wp // 2) / 64) * 128
         self.stats = (z(n_stat), z(n_stat))
         self.fin_ws = ops.inorm_ws(dev)
-        self.mean, self.rstd = z(256), z(256)
+        self._norm_slots = {}
         self.prog_f_src = self._encoder_program(eng.fnet, self.img[0], [(eng.fnet.conv2, self.f1, 0, EPI.EPI_LINEAR)])
         self.prog_f_dst = self._encoder_program(eng.fnet, self.img[1],
                                                 [(eng.fnet.conv2, self.f2act[0], 0, EPI.EPI_LINEAR)])
@@ -359,47 +361,72 @@ class _Plan:
         inorm = e.norm == "instance"
         tag = "i" if inorm else "c"
 
+        def slot(name):
+            """(mean, rstd) buffers of one normalised layer: a deferred normalisation may be consumed several launches later."""
+            key = f"{tag}_{name}"
+            if key not in self._norm_slots:
+                self._norm_slots[key] = (torch.zeros(256, device="cuda"), torch.zeros(256, device="cuda"))
+            return self._norm_slots[key]
+
+        def materialise(x):
+            """A pending activation ("raw", act, mode, stats[, cache]) -> its normalised tensor (apply kernel; once)."""
+            if not isinstance(x, list):
+                return x
+            if x[4] is None:
+                _, raw_x, mode, ms, _ = x
+                x[4] = self._scratch(f"{tag}_mat_{len(prog)}", 1, raw_x.h, raw_x.w, raw_x.c)
+                prog.append(("apply", (raw_x, x[4], mode - 1, None, ms, None, 0)))   # apply modes: 0 norm, 1 norm + relu
+            return x[4]
+
         def layer(x, pc, name, relu, res=None, defer=False):
             """-> relu?(norm(conv(x)))  or, with res,  relu(res + relu(norm(conv(x)))).
-            x may be a pending activation ("raw", act, mode): a raw conv output whose InstanceNorm (+ ReLU) was
-            deferred to its consumer -- fused into this conv's LDS-halo loader when this conv runs on that kernel,
-            materialised by the apply kernel otherwise.  defer=True returns such a pending activation."""
-            xin, in_norm = x, 0
-            if isinstance(x, tuple):
-                _, raw_x, mode = x
-                probe = self._cp(raw_x, pc, raw_x, in_norm=mode, in_stats=(self.mean, self.rstd))
-                if probe.in_norm:
-                    xin, in_norm = raw_x, mode
+            x (and res) may be a PENDING activation ["raw", act, mode, stats, materialised]: a raw conv output whose
+            InstanceNorm (+ ReLU) is deferred to its consumers -- fused into this conv's LDS-halo loader when this conv runs
+            on that kernel, into the residual operand of the block's last normalisation kernel, materialised by the apply
+            kernel otherwise.  defer=True returns such a pending activation."""
+            xin, in_norm, in_stats = x, 0, None
+            if isinstance(x, list):
+                _, raw_x, mode, ms, mat = x
+                probe = self._cp(raw_x, pc, raw_x, in_norm=mode, in_stats=ms) if mat is None else None
+                if probe is not None and probe.in_norm:
+                    xin, in_norm, in_stats = raw_x, mode, ms
                 else:
-                    xin = self._scratch(f"{tag}_{name}_in", 1, raw_x.h, raw_x.w, raw_x.c)
-                    prog.append(("apply", (raw_x, xin, mode - 1, None)))        # apply modes: 0 norm, 1 norm + relu
+                    xin = materialise(x)
             ho, wo = pc.out_hw(xin.h, xin.w)
             out = self._scratch(f"{tag}_{name}", 1, ho, wo, pc.cout)
-            kw = dict(in_norm=in_norm, in_stats=(self.mean, self.rstd)) if in_norm else {}
+            kw = dict(in_norm=in_norm, in_stats=in_stats) if in_norm else {}
             if not inorm:
                 epi = EPI.EPI_RELU_RES_RELU if res is not None else (EPI.EPI_RELU if relu else EPI.EPI_LINEAR)
-                prog.append(("conv", self._cp(xin, pc, out, epi=epi, e0=res, **kw)))
+                prog.append(("conv", self._cp(xin, pc, out, epi=epi, e0=materialise(res) if res is not None else None, **kw)))
                 return out
             raw = self._scratch(f"{tag}_raw_{name}", 1, ho, wo, pc.cout)
             p = self._cp(xin, pc, raw, stats=self.stats, **kw)
             rows = 2 * p._m_tiles
+            ms = slot(name)
             prog.append(("conv", p))
-            prog.append(("fin", (rows, pc.cout_pad, pc.cout, raw.cs, p._m)))
+            prog.append(("fin", (rows, pc.cout_pad, pc.cout, raw.cs, p._m, ms)))
             if defer and res is None:
-                return ("raw", raw, 2 if relu else 1)
-            prog.append(("apply", (raw, out, 2 if res is not None else (1 if relu else 0), res)))
+                return ["raw", raw, 2 if relu else 1, ms, None]
+            if res is None:
+                prog.append(("apply", (raw, out, 1 if relu else 0, None, ms, None, 0)))
+            elif isinstance(res, list) and res[4] is None:      # shortcut still raw: normalised inside this kernel
+                prog.append(("apply", (raw, out, 2, res[1], ms, res[3], res[2])))
+            else:
+                prog.append(("apply", (raw, out, 2, materialise(res), ms, None, 0)))
             return out
 
-        x = layer(img, e.conv1, "c1", True)
+        # conv1's output and the 1x1 downsample branch stay raw where every consumer can normalise on the fly (the LDS-halo
+        # conv of the first block, the residual operand of a block's closing kernel): three apply passes fewer per encoder
+        x = layer(img, e.conv1, "c1", True, defer=inorm and DEFER_NORM)
         for i, blk in enumerate(e.blocks):
-            # (the shortcut first: a deferred normalisation reads mean / rstd of the LAST finalize)
-            res = x if blk["stride"] == 1 else layer(x, blk["down"], f"b{i}_d", False)
+            res = x if blk["stride"] == 1 else layer(x, blk["down"], f"b{i}_d", False, defer=inorm and DEFER_NORM)
             y = x
             for k, pc in enumerate(blk["convs"][:-1]):
                 # the block-internal activations have exactly one consumer (the next conv of the block): their
-                # normalisation is deferred to it (the residual input x and the block output are materialised)
+                # normalisation is deferred to it (the block output is materialised)
                 y = layer(y, pc, f"b{i}_{k}", True, defer=inorm)
             x = layer(y, blk["convs"][-1], f"b{i}_o", True, res=res)
+        x = materialise(x)
         for pc, out, co_off, epi in outputs:
             prog.append(("conv", self._cp(x, pc, out, co_off=co_off, epi=epi)))
         return prog
@@ -485,11 +512,11 @@ class _Plan:
                 else:
                     ops.run_conv(a)
             elif kind == "fin":
-                rows, ld, c, c_pad, count = a
-                ops.inorm_finalize(self.stats, rows, ld, c, count, self.mean, self.rstd, channels_pad=c_pad, ws=self.fin_ws)
+                rows, ld, c, c_pad, count, ms = a
+                ops.inorm_finalize(self.stats, rows, ld, c, count, ms[0], ms[1], channels_pad=c_pad, ws=self.fin_ws)
             elif kind == "apply":
-                raw, out, mode, res = a
-                ops.inorm_apply(raw, self.mean, self.rstd, out, mode, res=res)
+                raw, out, mode, res, ms, res_ms, res_mode = a
+                ops.inorm_apply(raw, ms[0], ms[1], out, mode, res=res, res_stats=res_ms, res_mode=res_mode)
             elif kind == "fork":
                 self._fork_ev.record()
                 self._side.wait_event(self._fork_ev)

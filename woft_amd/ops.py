@@ -337,10 +337,13 @@ def inorm_finalize(stats, n_part, ld, channels, count, mean, rstd, eps=1e-5, cha
                                           count, eps, ptr(mean), ptr(rstd), ptr(ws), stream_ptr()), "woft_inorm_finalize")
 
 
-def inorm_apply(x, mean, rstd, out, mode, res=None):
+def inorm_apply(x, mean, rstd, out, mode, res=None, res_stats=None, res_mode=0):
+    """res_mode 1 / 2: `res` is a raw conv output, normalised (2: + ReLU) with res_stats = (mean, rstd) inside the kernel."""
     assert out.cs == x.cs and (res is None or res.cs == x.cs)
+    rm, rr = res_stats if res_stats is not None else (None, None)
     check(_lib.load().woft_inorm_apply(ptr(x.t), ptr(mean), ptr(rstd), ptr(res.t) if res is not None else None,
-                                       ptr(out.t), x.n_pix, x.cs, mode, stream_ptr()), "woft_inorm_apply")
+                                       ptr(rm), ptr(rr), res_mode, ptr(out.t), x.n_pix, x.cs, mode, stream_ptr()),
+          "woft_inorm_apply")
 
 
 def preprocess(img_u8, out, hp, wp, pad_top, pad_left):
