@@ -6,7 +6,7 @@
 // and the 9 x COUT x CPL weights of those channels in registers.  The three input columns of the 3x3 window
 // slide along the run (each new column = 3 loads of CPL floats per lane, one full channel vector per wave
 // instruction), so an input pixel is read three times in total instead of nine.  Each output is the sum of the 64
-// per-lane partial sums (xor butterfly).
+// per-lane partial sums (totalled once per run, through LDS).
 #include "common.h"
 
 namespace {
@@ -65,6 +65,12 @@ __global__ __launch_bounds__(256) void conv3x3_narrow_kernel(const float* __rest
     load_col(x0 + 1, cb[2]);
     const float b0 = bias ? bias[0] : 0.f, b1 = (bias && COUT > 1) ? bias[COUT - 1] : 0.f;
     float* orow = out + (((int64_t)img * h + y) * w) * ldo + co_off;
+    // per-lane partial sums of the whole run first (LDS, [value][lane]), ONE reduction at the end: a butterfly per pixel was
+    // a chain of six dependent cross-lane moves per output (192 per run, most of the kernel's 23 us).  Then lane L totals
+    // one half (32 lanes' partials) of value L >> 1 in lane order and adds its partner's half.
+    constexpr int NV = RUN * COUT, PLD = 65;             // (65: the 32 values a wave reads in one go fall into different banks)
+    __shared__ float part[4][NV * PLD];
+    float* mypart = part[wave];
 #pragma unroll 1
     for (int i0 = 0; i0 < RUN; i0 += 4) {
 #pragma unroll
@@ -74,7 +80,6 @@ __global__ __launch_bounds__(256) void conv3x3_narrow_kernel(const float* __rest
             const vec(&l)[3] = cb[k & 3];
             const vec(&m)[3] = cb[(k + 1) & 3];
             const vec(&r)[3] = cb[(k + 2) & 3];
-            float s[COUT];
 #pragma unroll
             for (int o = 0; o < COUT; ++o) {
                 float t = 0.f;
@@ -86,27 +91,44 @@ __global__ __launch_bounds__(256) void conv3x3_narrow_kernel(const float* __rest
                         t = fmaf(wv[o][ky * 3 + 1][e], m[ky][e], t);
                         t = fmaf(wv[o][ky * 3 + 2][e], r[ky][e], t);
                     }
-                s[o] = t;
+                mypart[((i0 + k) * COUT + o) * PLD + lane] = t;
             }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // (the partials are private to this wave)
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float v[1];
+    {
+        constexpr int LPV = 64 / NV;                     // lanes per value: 2 (NV = 32) or 4 (NV = 16)
+        const int val = lane / LPV, sub = lane % LPV;
+        const float* src = mypart + val * PLD + sub * (64 / LPV);
+        float t = 0.f;
 #pragma unroll
-            for (int d = 32; d >= 1; d >>= 1)
+        for (int e = 0; e < 64 / LPV; ++e) t += src[e];
 #pragma unroll
-                for (int o = 0; o < COUT; ++o) s[o] += __shfl_xor(s[o], d, 64);
-            if (lane == 0 && x < w) {
-                orow[(int64_t)x * ldo] = s[0] + b0;
-                if (COUT > 1) orow[(int64_t)x * ldo + COUT - 1] = s[COUT - 1] + b1;
-                if (COUT == 2 && coords1 != nullptr) {   // coords1 += delta (weighted_raft.py:237), same fp32 adds as
-                    const int64_t i = (int64_t)y * w + x; // woft_coords_update on the stored delta (n_img == 1)
-                    const float cx = coords1[i * 2] + (s[0] + b0), cy = coords1[i * 2 + 1] + (s[COUT - 1] + b1);
-                    coords1[i * 2] = cx;
-                    coords1[i * 2 + 1] = cy;
-                    const float fx = cx - (float)x, fy = cy - (float)y;
-                    if (flow4 != nullptr) *(f32x4*)(flow4 + i * 4) = f32x4{fx, fy, 0.f, 0.f};
-                    if (flow_cat != nullptr) {
-                        flow_cat[i * ld_cat] = fx;
-                        flow_cat[i * ld_cat + 1] = fy;
-                    }
-                }
+        for (int d = 1; d < LPV; d <<= 1) t += __shfl_xor(t, d, 64);
+        v[0] = t;
+    }
+    constexpr int SH = (NV == 32) ? 1 : (NV == 16) ? 2 : 3;             // lanes per value = 1 << SH
+    static_assert(NV == 32 || NV == 16 || NV == 8, "run x output channels");
+    const int idx = lane >> SH, pix = idx / COUT, o = idx - pix * COUT;
+    const int x = x0 + pix;
+    const float tot = v[0] + (o == 0 ? b0 : b1);
+    float other = 0.f;
+    if (COUT == 2) other = __shfl_xor(tot, 1 << SH, 64);                // the pixel's other channel
+    if ((lane & ((1 << SH) - 1)) == 0 && x < w) {
+        orow[(int64_t)x * ldo + (o == 0 ? 0 : COUT - 1)] = tot;
+        if (COUT == 2 && o == 0 && coords1 != nullptr) {   // coords1 += delta (weighted_raft.py:237), same fp32 adds as
+            const int64_t i = (int64_t)y * w + x;          // woft_coords_update on the stored delta (n_img == 1)
+            const float cx = coords1[i * 2] + tot, cy = coords1[i * 2 + 1] + other;
+            coords1[i * 2] = cx;
+            coords1[i * 2 + 1] = cy;
+            const float fx = cx - (float)x, fy = cy - (float)y;
+            if (flow4 != nullptr) *(f32x4*)(flow4 + i * 4) = f32x4{fx, fy, 0.f, 0.f};
+            if (flow_cat != nullptr) {
+                flow_cat[i * ld_cat] = fx;
+                flow_cat[i * ld_cat + 1] = fy;
             }
         }
     }
