@@ -15,7 +15,11 @@ python bench.py --iters 32 --no-cpu-baseline --no-alt-precisions > $out/${tag}_b
 python bench.py --height 2160 --width 3840 --steps 10 --no-cpu-baseline --no-alt-precisions > $out/${tag}_bench_4k.json 2>/dev/null
 python bench.py --height 480 --width 640 --no-cpu-baseline --no-alt-precisions --no-alt-corr > $out/${tag}_bench_480p.json 2>/dev/null
 python tools/bench_hfit.py > $out/${tag}_hfit_fullframe.txt 2>/dev/null
-python tools/bench_lookup.py > $out/${tag}_lookup_isolated.txt 2>/dev/null
+{ python tools/bench_lookup.py; python tools/bench_lookup.py --tw 8; python tools/bench_lookup.py --storage bf16; python tools/bench_lookup.py --storage bf16 --tw 8;
+  for abl in 1 2 3; do LOOKUP_ABL=$abl python tools/bench_lookup.py; done; } 2>/dev/null | grep lookup > $out/${tag}_lookup_isolated.txt
+{ OTF_ABL=16 python tools/bench_lookup_otf.py; for abl in 1 2 3 15; do OTF_ABL=$abl python tools/bench_lookup_otf.py; done; } 2>/dev/null | grep -v amdgpu > $out/${tag}_lookup_otf_timeline.txt
+python tools/layer_times.py 2>/dev/null | grep -v amdgpu > $out/${tag}_layer_times_bf16x3.txt
+python tools/layer_times.py --precision fp32 2>/dev/null | grep -v amdgpu > $out/${tag}_layer_times_fp32.txt
 python tools/regb_check.py 2>/dev/null | grep -v amdgpu > $out/${tag}_conv_kernels_ab.txt
 tools/prof_stats.sh ${tag}_bench_default > /dev/null 2>&1
 mv $out/${tag}_bench_default_kernel_stats.csv $out/${tag}_bench_kernel_stats_bf16x3.csv
