@@ -122,7 +122,8 @@ typedef struct woft_conv_params {
        streamed global -> registers instead of through LDS; it is read from wgt_frag, the same weights in MFMA-fragment
        order: [cout_pad / 32 bands][cin_pad / 32 chunks][taps][planes: hi (, lo)][2 k halves][64 lanes][8] bf16, lane L
        element e of k half s = W[32 band + L % 32][tap][32 chunk + 8 (2 s + L / 32) + e].  tile_n 128: one wave per
-       32-column band and all 128 rows; tile_n 64: 2 x 2 waves.                                                   */
+       32-column band and all 128 rows; tile_n 64: 2 x 2 waves.  halo == 12: the same kernel on 4x16-pixel tiles x 128
+       columns (tile_n 128, cout_pad % 128 == 0, multi-tap layers): one wave per band and all 64 rows.            */
     const void* wgt_frag;
 } woft_conv_params;
 

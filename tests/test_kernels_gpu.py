@@ -262,7 +262,7 @@ def test_conv_gru_epilogues(ops, kh, kw, precision, tol):
     pzr_p = ops.conv_params(ha, pzr, zb, x2=xa, c_split=128, epi=ops._lib.EPI_GRU_ZR, split=128, e0=ha, out1=rh,
                             precision=precision)
     # default choice in the split-bf16 precisions: the kernel that streams the weights global -> registers (conv_regb)
-    assert (pzr_p.halo == 8) == (precision != "fp32")
+    assert (pzr_p.halo in (8, 12)) == (precision != "fp32")
     ops.run_conv(pzr_p)
     ops.run_conv(ops.conv_params(rh, pq, hn, x2=xa, c_split=128, epi=ops._lib.EPI_GRU_Q, e0=ha, e1=zb,
                                  precision=precision))
@@ -271,9 +271,9 @@ def test_conv_gru_epilogues(ops, kh, kw, precision, tol):
     _close(rh.nchw(), r * hprev, 2e-5 * tol, what="r*h")
     _close(hn.nchw(), ref, 3e-5 * tol, what="h")
     if precision != "fp32":
-        # the LDS-staged-weights halo kernels (8x16 and 4x16 pixel tiles) and both column widths of conv_regb compute the
-        # same products in the same order: bit-identical gate tensors
-        for halo, tiles in ((1, None), (4, None), (8, (128, 64)), (8, (128, 128))):
+        # the LDS-staged-weights halo kernels (8x16 and 4x16 pixel tiles), both column widths of conv_regb and its
+        # 4x16-pixel x 128-column layout (halo 12) compute the same products in the same order: bit-identical gate tensors
+        for halo, tiles in ((1, None), (4, None), (8, (128, 64)), (8, (128, 128)), (12, None)):
             z2, rh2, h2 = (ops.new_act(n, h, w, 128, zero=True) for _ in range(3))
             ops.run_conv(ops.conv_params(ha, pzr, z2, x2=xa, c_split=128, epi=ops._lib.EPI_GRU_ZR, split=128, e0=ha,
                                          out1=rh2, precision=precision, halo=halo, tiles=tiles))
@@ -312,7 +312,7 @@ def test_conv_halo_patches_and_fallback(ops, precision, tol):
     p3 = ops.conv_params(ops.act_from_nchw(x), ops.pack_conv(wt, b), big, co_off=128, epi=ops._lib.EPI_RELU,
                          precision=precision)
     assert p3.halo == 8
-    for other in (1, 4):
+    for other in (1, 4, 12):
         p4 = ops.conv_params(ops.act_from_nchw(x), ops.pack_conv(wt, b), ops.new_act(1, 19, 37, 126, cs=128, zero=True),
                              epi=ops._lib.EPI_RELU, precision=precision, halo=other)
         assert p4.halo == other

@@ -998,7 +998,7 @@ extern "C" int woft_conv2d(const woft_conv_params* pp, void* stream) {
         const int64_t cs_max = (p.in1 != nullptr && p.cs1 > p.cs0) ? p.cs1 : p.cs0;
         if ((int64_t)p.n_img * p.h * p.w * cs_max >= (1ll << 31)) return WOFT_EINVAL;     // 32-bit element offsets
         if ((int64_t)p.taps_y * p.taps_x * p.cin_pad >= (1 << 20)) return WOFT_EINVAL;
-        if (p.halo == 8) return woft_conv_regb_launch(p, stream);
+        if (p.halo == 8 || p.halo == 12) return woft_conv_regb_launch(p, stream);
         if (p.halo == 1 && p.tile_n == 128) return launch_halo<8, 16, 128, 2, 2>(p, s);
         if (p.halo == 1 && p.tile_n == 64) return launch_halo<8, 16, 64, 2, 2>(p, s);
         if (p.halo == 2 && p.tile_n == 128 && p.ho == 9 && p.wo == 9) return launch_halo<9, 9, 128, 1, 2>(p, s);

@@ -228,9 +228,9 @@ __global__ __launch_bounds__(256, 2) void conv_regb_kernel(const woft_conv_param
     if (stamps) { stamps[15] = __builtin_amdgcn_s_memtime(); stamps[31] = __builtin_amdgcn_s_memrealtime(); }
 }
 
-template <int WM>
+template <int WM, int TY = 8>
 int launch_regb(const woft_conv_params& p, hipStream_t s) {
-    constexpr int TY = 8, TX = 16, BN = 128 / WM;
+    constexpr int TX = 16, BN = 128 / WM;
     const int tyn = (p.ho + TY - 1) / TY, txn = (p.wo + TX - 1) / TX;
     const int64_t mt = (int64_t)p.n_img * tyn * txn;
     dim3 grid((unsigned)(mt * (p.cout_pad / BN)));
@@ -242,7 +242,7 @@ int launch_regb(const woft_conv_params& p, hipStream_t s) {
     else if (p.taps_y == 5 && p.taps_x == 1) REGB(5, 1, T, 5, 3);        \
     else if (p.taps_y == 1 && p.taps_x == 1) {    /* 1x1: three chunks per unrolled group, input tile three chunks ahead; \
                                                      64-column tiles only (the 128-column layout does not fit 256 registers) */ \
-        if constexpr (WM == 2)                                                                                                  \
+        if constexpr (WM == 2 && TY == 8)                                                                                       \
             hipLaunchKernelGGL((conv_regb_kernel<TY, TX, 1, 1, WM, T, 3, 2, 1, 3, 3>), grid, dim3(256), (size_t)g_regb_dyn_lds, s, p); \
         else return WOFT_EINVAL;                                                                                                \
     } else return WOFT_EINVAL
@@ -254,8 +254,15 @@ int launch_regb(const woft_conv_params& p, hipStream_t s) {
 
 }  // namespace
 
-// Called by woft_conv2d for p.halo == 8 (after its argument checks).
+// Called by woft_conv2d for p.halo == 8 (8 x 16-pixel tiles) and 12 (4 x 16 pixels x 128 columns: four waves = four column
+// bands of 64 rows -- the per-wave work of the 8 x 16 x 64 layout with the weights fetched once per workgroup), after its
+// argument checks.
 int woft_conv_regb_launch(const woft_conv_params& p, void* stream) {
+    if (p.halo == 12) {
+        if (p.wgt_frag == nullptr || p.in_norm != 0 || (p.in_mean != nullptr && p.in_mean != (const float*)1) || p.wh0_lookup != nullptr ||
+            p.epi == WOFT_EPI_WH_MEAN || p.tile_n != 128 || p.cout_pad % 128 != 0 || p.taps_y * p.taps_x == 1) return WOFT_EINVAL;
+        return launch_regb<1, 4>(p, (hipStream_t)stream);
+    }
     if (p.wgt_frag == nullptr || p.in_norm != 0 || (p.in_mean != nullptr && p.in_mean != (const float*)1) || p.wh0_lookup != nullptr || p.epi == WOFT_EPI_WH_MEAN) return WOFT_EINVAL;
     if (p.tile_n == 128 && p.cout_pad % 128 == 0) return launch_regb<1>(p, (hipStream_t)stream);
     if (p.tile_n == 64 && p.cout_pad % 64 == 0) return launch_regb<2>(p, (hipStream_t)stream);

@@ -157,7 +157,8 @@ PRECISION = {"fp32": 0, "bf16x3": 1, "bf16": 2}
 USE_HALO = os.environ.get("WOFT_HALO", "1") != "0"
 USE_REGB = os.environ.get("WOFT_REGB", "1") != "0"
 USE_REGB1 = os.environ.get("WOFT_REGB1", "0") != "0"      # (measured: 45 vs 37 us on convc1 -- the 64 x 64 gather tiles win)
-HALO_TILES = {1: (8, 16, 1), 2: (9, 9, 1), 4: (4, 16, 1), 6: (6, 16, 1), 8: (8, 16, 1)}     # (TY, TX, images per workgroup)
+REGB_TY4 = os.environ.get("WOFT_REGB_TY4", "1") != "0"
+HALO_TILES = {1: (8, 16, 1), 2: (9, 9, 1), 4: (4, 16, 1), 6: (6, 16, 1), 8: (8, 16, 1), 12: (4, 16, 1)}     # (TY, TX, images per workgroup)
 HALO_MIN_BLOCKS = int(os.environ.get("WOFT_HALO_MIN_BLOCKS", "400"))
 WH_HALO = int(os.environ.get("WOFT_WH_HALO", "2"))
 
@@ -265,15 +266,26 @@ def conv_params(x, pc, out, co_off=0, epi=_lib.EPI_LINEAR, x2=None, c_split=0, e
             and x.h >= 8 and x.w >= 16 and x2 is None:
         p.tile_n = tn = 64
         halo = 8
+    # the GRU q convs (1x5 / 5x1, 128 columns) on 4x16-pixel x 128-column tiles instead of 8x16 x 64: same workgroup count and
+    # per-wave work (64 rows x 32 columns), but the four waves are four column bands -- the weight fragments are fetched once
+    # per workgroup instead of by both row halves.  Alone -6...8 % per layer at 1/8 of 1080p; inside a frame +-0 at 1080p
+    # and 4K, +1.5 % frames/s at 720p.  (convm the same alone, nothing in a frame: left on 8x16 x 64; a layer that would pad
+    # to 128 columns -- convc2, 192 -> 256 -- loses 19 %.)  WOFT_REGB_TY4=0: off
+    if REGB_TY4 and auto_halo and halo == 8 and p.tile_n == 64 and pc.cout_pad % 128 == 0 and _round_up(p.cout, 64) == pc.cout_pad \
+            and (pc.taps_y, pc.taps_x) in ((1, 5), (5, 1)):
+        halo, p.tile_n = 12, 128
     p.halo = halo
     p.wgt_frag = None
-    if halo == 8:                       # weights streamed to registers in MFMA-fragment order (conv_regb.hip)
+    if halo in (8, 12):                 # weights streamed to registers in MFMA-fragment order (conv_regb.hip)
         assert p.precision != 0 and not pc.flat and pc.stride == 1 and not in_norm
         assert (pc.taps_y, pc.taps_x) in ((3, 3), (1, 5), (5, 1), (1, 1)) and (ho, wo) == (x.h, x.w)
         frag = pc.frag(2 if p.precision == 1 else 1)
         p.wgt_frag = ptr(frag)
         if tiles is None and p.tile_n not in (64, 128):
             p.tile_n = 128 if pc.cout_pad % 128 == 0 else 64
+        if halo == 12:
+            assert pc.cout_pad % 128 == 0 and pc.taps_y * pc.taps_x > 1
+            p.tile_n = 128
         if pc.taps_y * pc.taps_x == 1:
             p.tile_n = 64
         if p.tile_n == 128 and pc.cout_pad % 128 != 0:
