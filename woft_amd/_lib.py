@@ -126,5 +126,18 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None) if os.environ.get("WOFT_RAW_STREAM", "1") != "0" else None
+_DEV_INDEX = None
+
+
 def stream_ptr():
-    return torch.cuda.current_stream().cuda_stream
+    """HIP stream handle of torch's CURRENT stream on this process's device (every launch is enqueued there).
+    torch.cuda.current_stream() builds a Stream object through several Python layers (7.7 us, x 200 launches per frame =
+    1.5 ms of host time, most of what stands between a frame's device->host read and the next frame's first launches);
+    the raw getter is one C call."""
+    global _DEV_INDEX
+    if _RAW_STREAM is None:
+        return torch.cuda.current_stream().cuda_stream
+    if _DEV_INDEX is None:
+        _DEV_INDEX = torch.cuda.current_device()         # one device per process (bench ranks select theirs first)
+    return _RAW_STREAM(_DEV_INDEX)
