@@ -277,7 +277,8 @@ def main():
         ms = [s.elapsed_time(e) for s, e, _ in evs]
         wh_ms = float(np.mean(ms)) if ms else float("nan")
         n = int(layer.h)
-        n_win = float(np.mean([k for _, _, k in evs])) if evs else float(P)   # windows per launch (P, or the mask region)
+        # windows per launch: P, the mask region, or -- sparse weight head -- the device-side count of windows that really ran
+        n_win = float(np.mean([float(k) for _, _, k in evs])) if evs else float(P)
         flops = 2.0 * n_win * n * n * 9 * 128 * 128
         rows = 96 if (n == 9 and args.precision != "fp32") else n * n  # 81 pixels occupy 3 MFMA row tiles
         issued = flops * terms * rows / (n * n)
@@ -291,8 +292,11 @@ def main():
                 "algorithmic_flops_per_launch": flops, "windows_per_launch": n_win, "mfma_terms_per_product": terms,
                 "avg_launch_ms": wh_ms, "launches_timed": len(ms)}
 
-    wh_desc = ("1/8-res pixels of the template mask (N_in = HW/4, SURVEY 8d) + upsampling support: the weights the tracker "
-               "reads (TRK:287-312), the tracker's default; identical tracks to evaluating it everywhere (checked below)"
+    sparse_wh = bool(getattr(tracker, "_sparse_weights", False))
+    wh_desc = (("the windows under the upsampling support of the <= 500 Sobol-drawn correspondences the fit reads (the draw is "
+                "decided by the flow alone; TRK:287-312 + subsampler), inside the template-mask region" if sparse_wh else
+                "1/8-res pixels of the template mask (N_in = HW/4, SURVEY 8d) + upsampling support: the weights the tracker "
+                "reads (TRK:287-312)") + ": the tracker's default; identical tracks to evaluating it everywhere (checked below)"
                if mask_region else "every template pixel (as the reference's network evaluates it)")
     out = {
         "metric": "tracked frames/sec at 1080p, 12 RAFT iters; flow EPE vs reference",

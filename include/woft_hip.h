@@ -255,6 +255,14 @@ int woft_wh_pack(const float* lookup, int32_t ld_lookup, const float* f1, int32_
                  float alpha, int64_t n_pix, int32_t nwin, float* mean, float* x8, void* stream);
 int woft_wh_reduce(const float* act, int32_t c, int32_t nwin2, const float* w, float bias,
                    int64_t n_pix, float* out, void* stream);
+/* The windows of a window list that a set of full-resolution pixels needs: dyn_index[j] = index[j] if the 1/8-res pixel
+ * index[j] lies in the 3x3 neighbourhood of the cell of one of the n = min(count[0], n_max) points pts[i] = (x, y) (image
+ * coordinates; cell = ((y + top) >> 3, (x + left) >> 3): the support of the x8 convex upsampling, weighted_raft.py:92-103),
+ * else -1.  A negative entry of woft_conv_params.wh0_index / out_index makes the weight-head launches skip that window.
+ * bitmap: hf*wf int32 of scratch; n_needed (optional): receives the number of kept windows.  The tracker's fit reads the
+ * weights of its Sobol-sampled correspondences only (TRK:287-312 + the subsampler), and the flow alone decides which. */
+int woft_wh_needed(const float* pts, const int32_t* count, int32_t n_max, int32_t top, int32_t left, int32_t hf, int32_t wf,
+                   const int32_t* index, int32_t n_win, int32_t* bitmap, int32_t* dyn_index, int32_t* n_needed, void* stream);
 
 /* Convex upsampling of flow and weight logits + TC epilogue
  * (weighted_raft.py:92-103,285-288; optical_flow/raft.py:148-159,185-199).

@@ -232,6 +232,61 @@ def test_weight_head_on_mask_region_only():
     assert not conf.tracker_class(conf)._mask_weight_head()
 
 
+@pytest.mark.parametrize("cfg", ["WOFT.py", "WOFT_IRLS.py"])
+def test_weight_head_on_the_drawn_correspondences_only(cfg):
+    """With a subsampler in front of the fit only the weights of the drawn correspondences are read, and the draw is decided
+    by the flow alone (masks, bounds, Sobol points): the tracker selects first and has the weight head evaluated on the
+    windows under the drawn pixels' upsampling support (woft_wh_needed + negative window-list entries).  Same weights at the
+    drawn pixels, bit for bit; identical homographies, lost flags included (a forced-lost frame runs the local stage, whose
+    flow is not from the pinned template and keeps the full head)."""
+    from pytracking.utils.config import load_config
+    H, W, iters = 544, 960, 3        # (large enough that the 500 drawn pixels leave windows of the region unneeded)
+    sd = synth.make_state_dict(seed=5)
+    template = synth.make_template(H, W, seq_id=7)
+    frames = [synth.make_frame(template, t) for t in (1, 2, 3, 4)]
+    mask = np.zeros((H, W), np.uint8)
+    mask[0:300, 100:700] = 255
+    outs, sel = {}, {}
+    for sparse in (False, True):
+        conf = load_config(ROOT / "pytracking" / "configs" / cfg)
+        conf.flow_config.model = sd
+        conf.flow_config.iters = iters
+        conf.flow_config.precision = "bf16x3"
+        conf.flow_config.padding_mode = "RAFT"
+        conf.sparse_weight_head = sparse
+        trk = conf.tracker_class(conf)
+        trk.init(template, mask)
+        assert trk._sparse_weights == sparse and trk._fused is not None
+        trk.flower.defer_min_ratio = 0        # (this region, ~3 000 windows, is below the provider's pay-off rule: force it)
+        res = []
+        for t, f in enumerate(frames):
+            Hm, meta = trk.track(f)
+            res.append((Hm, meta.lost, meta.N_lost))
+            assert trk.flower.weights_deferred == sparse          # (the last flow of the frame was the template's)
+            if t == 1:
+                b = trk._fb
+                n = int(b["res"].view(torch.int32)[12])
+                sel[sparse] = (b["pa"][:n].clone(), b["pb"][:n].clone(), b["w"][:n].clone())
+        outs[sparse] = res
+        if sparse:
+            plan = trk.flower.engine.plan(*[(d + 7) // 8 * 8 for d in (H, W)])
+            dyn, _, _, n_needed = next(iter(plan._wh_dyn.values()))
+            n_region = int(plan.wh_region[0].numel())
+            assert 0 < int(n_needed) < n_region and int((dyn >= 0).sum()) == int(n_needed)
+            print(f"{cfg}: {int(n_needed)} of {n_region} windows of the mask region evaluated")
+    for k in range(3):
+        assert torch.equal(sel[False][k], sel[True][k])           # same draw, same targets, same weights
+    for a, b in zip(outs[False], outs[True]):
+        assert np.array_equal(a[0], b[0]) and a[1:] == b[1:]
+    # off when there is nothing to draw from (no subsampler), and by the key / the environment
+    conf = load_config(ROOT / "pytracking" / "configs" / cfg)
+    conf.flow_config.model, conf.flow_config.iters = sd, 1
+    conf.subsampler_fn = None
+    trk = conf.tracker_class(conf)
+    trk.init(template, mask)
+    assert not trk._sparse_weights
+
+
 @pytest.mark.parametrize("name,cfg", [("woft", "WOFT.py"), ("lost", "WOFT.py"), ("irls", "WOFT_IRLS.py")])
 @pytest.mark.parametrize("backend", ["device", "callables"])
 def test_tracker_vs_reference_tracker_runs(golden_dir, monkeypatch, name, cfg, backend):

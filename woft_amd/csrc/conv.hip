@@ -399,6 +399,11 @@ __global__ __launch_bounds__(256, (STAGES == 1 ? 4 : (TY == 9 ? 3 : 1))) void co
     int m_tile, n_tile;
     woft::tile_of_block(blockIdx.x, p.n_img * tyn * txn, p.cout_pad / BN, m_tile, n_tile);
     const int img0 = m_tile / (tyn * txn);
+    if (TY == 9) {      // weight-head windows: a NEGATIVE entry of the window list = window not wanted in this launch (the
+                        // list is rewritten on the device per frame: woft_wh_needed) -- the whole workgroup leaves
+        if (p.wh0_index != nullptr && p.wh0_index[img0] < 0) return;
+        if (p.out_index != nullptr && p.out_index[img0] < 0) return;
+    }
     const int trem = m_tile - img0 * (tyn * txn);
     const int y0 = (trem / txn) * TY, x0 = (trem % txn) * TX;
     const int n0 = n_tile * BN;

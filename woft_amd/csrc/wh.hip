@@ -146,6 +146,49 @@ __global__ __launch_bounds__(256) void wh_conv0_kernel(const float* __restrict__
 
 }  // namespace
 
+// ---- the windows a set of selected correspondences needs (tracker: the fit reads the weights of its <= 500 Sobol-sampled
+//      correspondences only, and which ones they are is decided by the flow alone) --------------------------------------
+// The x8 convex upsampling of the weight map at full-resolution pixel (x, y) reads the 3x3 neighbourhood of its 1/8-res
+// cell ((y + top) >> 3, (x + left) >> 3) (weighted_raft.py:92-103: unfold with padding 1).
+__global__ void wh_mark_kernel(const float* __restrict__ pts, const int* __restrict__ count, int n_max, int top, int left,
+                               int hf, int wf, int* __restrict__ bitmap) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = count ? min(count[0], n_max) : n_max;
+    if (i >= n) return;
+    const int cx = ((int)pts[2 * i] + left) >> 3, cy = ((int)pts[2 * i + 1] + top) >> 3;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int yy = cy + dy, xx = cx + dx;
+            if (yy >= 0 && yy < hf && xx >= 0 && xx < wf) bitmap[yy * wf + xx] = 1;       // (every writer writes 1)
+        }
+}
+
+__global__ void wh_dyn_index_kernel(const int* __restrict__ index, int n_win, const int* __restrict__ bitmap,
+                                    int* __restrict__ dyn, int* __restrict__ n_needed) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_win) return;
+    const int src = index[j];
+    const bool need = bitmap[src] != 0;
+    dyn[j] = need ? src : -1;
+    if (need && n_needed != nullptr) atomicAdd(n_needed, 1);
+}
+
+extern "C" int woft_wh_needed(const float* pts, const int32_t* count, int32_t n_max, int32_t top, int32_t left, int32_t hf,
+                              int32_t wf, const int32_t* index, int32_t n_win, int32_t* bitmap, int32_t* dyn_index,
+                              int32_t* n_needed, void* stream) {
+    if (!pts || !index || !bitmap || !dyn_index || n_max <= 0 || n_win <= 0 || hf <= 0 || wf <= 0) return WOFT_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    (void)hipMemsetAsync(bitmap, 0, (size_t)hf * wf * sizeof(int32_t), s);
+    if (n_needed) (void)hipMemsetAsync(n_needed, 0, sizeof(int32_t), s);
+    hipLaunchKernelGGL(wh_mark_kernel, dim3((n_max + 255) / 256), dim3(256), 0, s, pts, count, n_max, top, left, hf, wf,
+                       bitmap);
+    hipLaunchKernelGGL(wh_dyn_index_kernel, dim3((n_win + 255) / 256), dim3(256), 0, s, index, n_win, bitmap, dyn_index,
+                       n_needed);
+    return woft_launch_status();
+}
+
 extern "C" int woft_wh_conv0(const float* lookup, int32_t ld_lookup, const float* mean, int64_t n_pix, int32_t nwin,
                              const float* wt, const float* bias, float* out, const int32_t* index, void* stream) {
     if (!lookup || !mean || !wt || !bias || !out || n_pix <= 0 || n_pix >= (1ll << 31)) return WOFT_EINVAL;

@@ -304,6 +304,7 @@ class _Plan:
             # the head restricted to a subset of the source pixels (set_weight_region): programs per region
             self.wh_region = None                        # None = every source pixel
             self._wh_regions = {}
+            self._wh_dyn = {}                            # per region: (dynamic window list, its programs, scratch)
 
     def _wh_program(self, n_win, index):
         """Launch list of the head's 128->128 layers on n_win windows (all source pixels, or those listed in the
@@ -580,8 +581,10 @@ class _Plan:
             self.inp_c.t.copy_(self.xbuf.t[:, :self.eng.spec.cdim])
             self.run(self.prog_gate_bias)
 
-    def flow(self, iters, crop, h, w, flow_up=None, dst=None, wout=None, do_sigmoid=False, trace=None):
-        """Target features -> volume -> `iters` refinements -> full-resolution outputs."""
+    def flow(self, iters, crop, h, w, flow_up=None, dst=None, wout=None, do_sigmoid=False, trace=None, defer_wh=False):
+        """Target features -> volume -> `iters` refinements -> full-resolution outputs.
+        defer_wh (full weighted model with a weight region set): stop before the weight head -- flow_up / dst are final,
+        wout is NOT written -- and let finish_weights() evaluate the head where the caller then says it reads the weights."""
         e, sp = self.eng, self.eng.spec
         if iters < 1:
             raise ValueError("iters must be >= 1")
@@ -596,7 +599,47 @@ class _Plan:
         for p in self.prog_mask:
             ops.run_conv(p)
         wlow = None
+        if defer_wh:
+            assert e.weighted and not sp.small and self.wh_region is not None
+            ops.convex_upsample(self.coords, None, self.mask.t, self.hf, self.wf, crop, h, w, flow_up=flow_up, dst=dst,
+                                wout=None, do_sigmoid=do_sigmoid)
+            return
         if e.weighted:
+            self._weight_head(self.wh_region[1] if self.wh_region is not None else self.prog_wh,
+                              self.wh_region[0] if self.wh_region is not None else None)
+            wlow = self.wlow
+        wout = wout if e.weighted else None
+        if sp.small:                                                 # no mask head: bilinear x8 (utils.py:82-84)
+            ops.upflow8(self.coords, wlow, self.hf, self.wf, crop, h, w, flow_up=flow_up, dst=dst, wout=wout,
+                        do_sigmoid=do_sigmoid)
+        else:
+            ops.convex_upsample(self.coords, wlow, self.mask.t, self.hf, self.wf, crop, h, w, flow_up=flow_up,
+                                dst=dst, wout=wout, do_sigmoid=do_sigmoid)
+
+    def finish_weights(self, pts, count, n_max, pad, crop, h, w, flow_up=None, dst=None, wout=None, do_sigmoid=False):
+        """After flow(defer_wh=True): the weight head on the windows of the current region that the (count) full-resolution
+        pixels pts (n_max, 2) need (woft_wh_needed: the 3x3 upsampling support of their 1/8-res cells), then the upsampling
+        with the weights.  wout is exact at those pixels (the head has no cross-pixel terms); elsewhere it is unspecified.
+        pad = (top, left) of the padded image the 1/8-res grid belongs to."""
+        index, _ = self.wh_region[:2]
+        key = index.data_ptr()
+        if key not in self._wh_dyn:
+            dyn = torch.full_like(index, -1)
+            prog, fused = self._wh_program(int(index.numel()), dyn)
+            assert fused
+            self._wh_dyn[key] = (dyn, prog, torch.zeros(self.P, dtype=torch.int32, device=index.device),
+                                 torch.zeros(1, dtype=torch.int32, device=index.device))
+        dyn, prog, bitmap, n_needed = self._wh_dyn[key]
+        ops.wh_needed(pts, count, n_max, pad[0], pad[1], self.hf, self.wf, index, bitmap, dyn, n_needed)
+        self._weight_head(prog, dyn, n_needed)
+        ops.convex_upsample(self.coords, self.wlow, self.mask.t, self.hf, self.wf, crop, h, w, flow_up=flow_up, dst=dst,
+                            wout=wout, do_sigmoid=do_sigmoid)
+
+    def _weight_head(self, prog_wh, index, n_needed=None):
+        """Final lookup + the weight head (weighted_raft.py:266-272, 347-384) on all source pixels (index None) or on the
+        windows listed in `index` -> self.wlow."""
+        e, sp = self.eng, self.eng.spec
+        if True:                                                     # (one indentation level kept: the body moved here as is)
             self._lookup(self.lookup)                                # final lookup, weighted_raft.py:266
             lib = _lib.load()
             n = sp.nwin
@@ -606,15 +649,13 @@ class _Plan:
                                         _lib.ptr(self.cs_tot), 1.0 / (math.sqrt(float(sp.fdim)) * self.P), self.P, n,
                                         _lib.ptr(self.wmean), None if self.wh0_direct else _lib.ptr(self.x8.t),
                                         _lib.stream_ptr()), "woft_wh_pack")
-            region = self.wh_region
-            prog_wh = region[1] if region is not None else self.prog_wh
-            n_win = int(region[0].numel()) if region is not None else self.P
-            if region is not None:
+            n_win = int(index.numel()) if index is not None else self.P
+            if index is not None:
                 self.wlow.zero_()                                    # pixels outside the region
             if self.wh0_direct and not self.wh0_fused:
                 _lib.check(lib.woft_wh_conv0(_lib.ptr(self.corr.t), self.corr.cs, _lib.ptr(self.wmean), n_win, n,
                                              _lib.ptr(self.wh0_t), _lib.ptr(e.wh0.bias), _lib.ptr(self.a1.t),
-                                             _lib.ptr(region[0]) if region is not None else None,
+                                             _lib.ptr(index) if index is not None else None,
                                              _lib.stream_ptr()), "woft_wh_conv0")
             for k, p in enumerate(prog_wh):
                 if k == 0 and self.wh_events is not None:            # bench.py: HIP events around the first 128->128 layer
@@ -622,17 +663,10 @@ class _Plan:
                     s.record()
                     ops.run_conv(p)
                     t.record()
-                    self.wh_events.append((s, t, n_win))
+                    # (dynamic window list: the number of windows that really ran is on the device)
+                    self.wh_events.append((s, t, n_win if n_needed is None else n_needed.clone()))
                 else:
                     ops.run_conv(p)
             if not self.wh_fused:
                 _lib.check(lib.woft_wh_reduce(_lib.ptr(self.a1.t), 128, n * n, _lib.ptr(e.wh6_w), e.wh6_b, self.P,
                                               _lib.ptr(self.wlow), _lib.stream_ptr()), "woft_wh_reduce")
-            wlow = self.wlow
-        wout = wout if e.weighted else None
-        if sp.small:                                                 # no mask head: bilinear x8 (utils.py:82-84)
-            ops.upflow8(self.coords, wlow, self.hf, self.wf, crop, h, w, flow_up=flow_up, dst=dst, wout=wout,
-                        do_sigmoid=do_sigmoid)
-        else:
-            ops.convex_upsample(self.coords, wlow, self.mask.t, self.hf, self.wf, crop, h, w, flow_up=flow_up,
-                                dst=dst, wout=wout, do_sigmoid=do_sigmoid)

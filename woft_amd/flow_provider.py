@@ -76,16 +76,18 @@ class RAFTWrapper:
         self._pinned = None
         self._pinned_key = None
         self._wmask, self._wregion = None, {}
+        self.weights_deferred, self._deferred = False, None
+        self.defer_min_ratio = 11          # defer_weights: region windows per named pixel from which deferring pays
         self._out = {}
         self._cache_errors = set()
 
-    def _run_flow(self, plan, iters, crop, oh, ow, o, weighted, do_sigmoid):
+    def _run_flow(self, plan, iters, crop, oh, ow, o, weighted, do_sigmoid, defer_wh=False):
         """plan.flow() eagerly, or -- use_graph -- as ONE hipGraph launch (captured at the second call with the same
         arguments; the per-launch event hooks of bench.py force the eager path)."""
         def eager():
             plan.flow(iters, crop, oh, ow, flow_up=o["flow"], dst=o["dst"], wout=o["w"] if weighted else None,
-                      do_sigmoid=do_sigmoid)
-        if not self.use_graph or plan.lookup_events is not None or plan.wh_events is not None or plan.conv_events is not None:
+                      do_sigmoid=do_sigmoid, defer_wh=defer_wh)
+        if defer_wh or not self.use_graph or plan.lookup_events is not None or plan.wh_events is not None or plan.conv_events is not None:
             return eager()
         graphs = plan.__dict__.setdefault("_graphs", {})
         region = plan.wh_region
@@ -101,6 +103,18 @@ class RAFTWrapper:
             graphs[key] = g
         else:
             g.replay()
+
+    def finish_weights(self, pts, count, n_max):
+        """After compute_flow(..., defer_weights=True) with `weights_deferred` set: evaluate the weight head for the
+        (count, a device int32; at most n_max) source pixels pts (n_max, 2) = (x, y) and return the (1, H*W) weight tensor
+        (borrowed), exact at those pixels and unspecified elsewhere.  The weights of a source pixel do not depend on the
+        other pixels (weighted_raft.py:363-383), and the caller knows which correspondences it keeps before it needs
+        their weights (TRK:287-312 + subsampler: decided by the flow alone)."""
+        plan, crop, oh, ow, o, do_sigmoid = self._deferred
+        self._deferred = None
+        plan.finish_weights(pts, count, n_max, crop, crop, oh, ow, flow_up=o["flow"], dst=o["dst"], wout=o["w"],
+                            do_sigmoid=do_sigmoid)
+        return o["w"]
 
     # ---- template caching (results-identical: InstanceNorm is per sample, extractor.py:171-190) ----
     def pin_source(self, src_img):
@@ -192,11 +206,15 @@ class RAFTWrapper:
         return o["src"], own(o["dst"]), (own(weights) if weights is not None else None)     # (src: constant grid)
 
     def compute_flow(self, src_img, dst_img, mode="TC", vis=False, src_img_identifier=None,
-                     numpy_out=False, do_sigmoid=False, borrow=False):
+                     numpy_out=False, do_sigmoid=False, borrow=False, defer_weights=False):
         """src_img / dst_img: (H, W, 3) uint8 BGR (numpy, or CUDA tensors already on the device).
         mode 'TC' -> (src_coords (2,HW) int64, dst_coords (2,HW) f32, weights (1,HW) f32 | None)
         mode 'flow' -> (flow (2,H,W), weights (1,H,W) | None).
-        borrow (extension, default off): return the provider's own output buffers, valid until the next call."""
+        borrow (extension, default off): return the provider's own output buffers, valid until the next call.
+        defer_weights (extension, default off: 0; else the number of source pixels the caller will name; honoured for flows
+        from the pinned source whose weight region is large against it, else ignored: check `weights_deferred` after the
+        call): return the flow / correspondences with weights = None and evaluate the weight head later, in
+        finish_weights(), only where the caller then says it reads the weights."""
         assert mode in ["flow", "TC"]
         assert src_img.shape == dst_img.shape
         if src_img_identifier is not None:                 # pre-computed flow (raft.py:92-109)
@@ -237,7 +255,17 @@ class RAFTWrapper:
         plan.load_image(1, d, top, left)
         o = self._outputs(oh, ow)
         weighted = self.C.raft_type == "weighted"
-        self._run_flow(plan, int(self.C.iters), (top, left), oh, ow, o, weighted, bool(do_sigmoid))
+        # (defer_weights = the number of pixels the caller will name: worth the second upsampling pass only if their 3x3
+        # supports cannot cover most of the region anyway -- at 720p a quarter-frame mask has 3 900 windows, 500 pixels need
+        # up to 4 500: measured +-0 there, +5 % at 1080p, +11 % at 4K)
+        self.weights_deferred = bool(defer_weights and weighted and not self.engine.small and plan.wh_region is not None
+                                     and not self.use_graph and mode == "TC" and not numpy_out
+                                     and int(plan.wh_region[0].numel()) > self.defer_min_ratio * int(defer_weights))
+        self._deferred = (plan, (top, left), oh, ow, o, bool(do_sigmoid)) if self.weights_deferred else None
+        self._run_flow(plan, int(self.C.iters), (top, left), oh, ow, o, weighted, bool(do_sigmoid),
+                       defer_wh=self.weights_deferred)
+        if self.weights_deferred:
+            return self._deliver(o, None, mode, oh, ow, numpy_out, borrow)
         logger.debug(f"flow enqueue time [s]: {float(timer() - start_time)}")
         weights = o["w"] if weighted else None
         if self.C.weights_postprocessing_fn and weights is not None:

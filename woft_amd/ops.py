@@ -506,6 +506,13 @@ def coords_update(coords, delta, ld_delta, wf, flow4=None, flow_cat=None, ld_cat
                                          ptr(flow_cat), ld_cat, stream_ptr()), "woft_coords_update")
 
 
+def wh_needed(pts, count, n_max, top, left, hf, wf, index, bitmap, dyn_index, n_needed=None):
+    """dyn_index[j] = index[j] where the weight-head window of 1/8-res pixel index[j] is needed by one of the (count) points
+    pts (n_max, 2) = (x, y) image coordinates, else -1 (woft_wh_needed)."""
+    check(_lib.load().woft_wh_needed(ptr(pts), ptr(count), n_max, top, left, hf, wf, ptr(index), index.numel(), ptr(bitmap),
+                                     ptr(dyn_index), ptr(n_needed), stream_ptr()), "woft_wh_needed")
+
+
 def convex_upsample(coords, wlow, mask, hf, wf, crop, h, w, flow_up=None, dst=None, wout=None, do_sigmoid=False):
     check(_lib.load().woft_convex_upsample(ptr(coords), ptr(wlow), ptr(mask), mask.shape[1], hf, wf, crop[0], crop[1],
                                            h, w, ptr(flow_up), ptr(dst), ptr(wout), int(do_sigmoid), stream_ptr()),

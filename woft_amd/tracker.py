@@ -84,6 +84,7 @@ class YAOFTrackerSingleControl:
         self.flower = config.flow_config.of_class(config.flow_config)
         self.device = "cuda"
         self._fused = self._fused_specs()
+        self._sparse_weights = False
         self._replay = None
 
     # ---- which solver back end ------------------------------------------------------------------
@@ -145,6 +146,14 @@ class YAOFTrackerSingleControl:
             # the head everywhere, as the reference's network does.
             if hasattr(self.flower, "pin_weight_region"):
                 self.flower.pin_weight_region(inside if self._mask_weight_head() else None)
+            # ... and with a subsampler in front of the fit (the default config draws 500 correspondences), only the weights
+            # of the DRAWN correspondences are read, and the draw does not depend on the weights: the head is evaluated after
+            # the selection, on the windows under the drawn pixels' upsampling support (config key sparse_weight_head =
+            # False / env WOFT_SPARSE_WH=0: on the whole mask region, as above).  Identical homographies (tested).
+            v = self.C.sparse_weight_head
+            on = (os.environ.get("WOFT_SPARSE_WH", "1") != "0") if (isinstance(v, type(self.C)) or v is None) else bool(v)
+            self._sparse_weights = bool(on and self._fused is not None and self._fused["n_draw"] and self._mask_weight_head()
+                                        and hasattr(self.flower, "finish_weights"))
         self._set_pose(_EYE.copy(), good=True)
         self.prev_img, self.prev_img_identifier = img, img_identifier
         self.lost, self.N_lost = False, 0
@@ -220,6 +229,8 @@ class YAOFTrackerSingleControl:
         """-> (grid coords (2, n) int64, target coords (2, n) f32, weights (1, n) f32 | None, (gh, gw)); borrowed
         buffers of the provider: consumed before the next flow."""
         kw = {"borrow": True} if hasattr(self.flower, "pin_source") else {}
+        if self._sparse_weights and src is self.template_img:
+            kw["defer_weights"] = int(self._fused["n_draw"])         # (see _solve_device)
         src_xy, dst_xy, w = self.flower.compute_flow(src, dst, mode="TC", vis=False, src_img_identifier=None,
                                                      do_sigmoid=True, **kw)
         s = getattr(self.flower, "last_flow_shape", None)
@@ -275,6 +286,13 @@ class YAOFTrackerSingleControl:
         F, b = self._fused, self._fused_buffers(grid[0] * grid[1])
         res = b["res"]
         ires = res.view(torch.int32)
+        if w is None and getattr(self.flower, "weights_deferred", False):
+            # The correspondences the fit will read are decided by the flow alone (masks, bounds, Sobol draw): select them
+            # first, let the provider evaluate the weight head on the windows under THEIR upsampling support only, then
+            # select again, now with weights (same selection; exact weights at the selected pixels: identical fit)
+            ops.tc_select(dst_xy, None, src_mask_u8, dst_valid_u8, frame_hw[0], frame_hw[1], bounds, F["sobol_u"], b["ws"],
+                          b["pa"], b["pb"], b["w"], ires[12:14], grid=grid)
+            w = self.flower.finish_weights(b["pb"], ires[12:13], b["pb"].shape[0])      # (pb: the source pixels)
         ops.tc_select(dst_xy, w, src_mask_u8, dst_valid_u8, frame_hw[0], frame_hw[1], bounds, F["sobol_u"], b["ws"],
                       b["pa"], b["pb"], b["w"], ires[12:14], grid=grid)
         ops.hfit(b["pa"], b["pb"], b["w"], res[0:9], ires[10:11], count=ires[12:13], reweight=F["reweight"],
