@@ -274,6 +274,11 @@ int woft_wh_needed(const float* pts, const int32_t* count, int32_t n_max, int32_
 int woft_convex_upsample(const float* coords1, const float* wlow, const float* mask, int32_t ld_mask,
                          int32_t hf, int32_t wf, int32_t crop_top, int32_t crop_left, int32_t h, int32_t w,
                          float* flow_up, float* dst, float* wout, int32_t do_sigmoid, void* stream);
+/* The weight output of woft_convex_upsample at a list of pixels only: wsel[i] = wout at pixel pts[i] = (x, y) of the
+ * un-padded image, i < min(count[0], n_max) (count: device, may be NULL); same operations, same order. */
+int woft_convex_weights_at(const float* pts, const int32_t* count, int32_t n_max, const float* wlow, const float* mask,
+                           int32_t ld_mask, int32_t hf, int32_t wf, int32_t crop_top, int32_t crop_left,
+                           int32_t do_sigmoid, float* wsel, void* stream);
 /* Pre-computed flow read from the reference's cache files (utils/caching.py:53-59; raft.py:93-106) to the same
  * outputs: dst[2][h*w] = pixel grid + flow[2][h*w] (may be NULL), wout[h*w] = weights or sigmoid(weights)
  * (weights / wout may be NULL). */

@@ -78,6 +78,7 @@ _SIGS = {
     "woft_wh_reduce": (i32, [vp, i32, i32, vp, f32, i64, vp, vp]),
     "woft_wh_needed": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, i32, vp, vp, vp, vp]),
     "woft_convex_upsample": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, i32, vp]),
+    "woft_convex_weights_at": (i32, [vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
     "woft_upflow8": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, i32, vp]),
     "woft_warp_perspective_u8": (i32, [vp, i32, i32, i32, C.POINTER(C.c_double), vp, vp, i32, vp]),
     "woft_resize_linear_u8": (i32, [vp, i32, i32, i32, vp, i32, i32, f32, f32, vp]),

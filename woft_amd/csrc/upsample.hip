@@ -63,6 +63,44 @@ __global__ __launch_bounds__(256) void convex_upsample_kernel(
     }
 }
 
+// The weight channel of convex_upsample_kernel at a list of full-resolution pixels only: wsel[i] = wout[pts[i]], the same
+// operations in the same order (one thread per pixel: the fit reads the weights of its <= 500 drawn correspondences).
+__global__ void convex_weights_at_kernel(const float* __restrict__ pts, const int* __restrict__ count, int n_max,
+                                         const float* __restrict__ wlow, const float* __restrict__ mask, int ld_mask, int hf,
+                                         int wf, int crop_top, int crop_left, int do_sigmoid, float* __restrict__ wsel) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = count ? min(count[0], n_max) : n_max;
+    if (i >= n) return;
+    const int X = (int)pts[2 * i] + crop_left, Y = (int)pts[2 * i + 1] + crop_top;
+    const int hc = Y >> 3, wc = X >> 3, lane = (Y & 7) * 8 + (X & 7);
+    const float* m = mask + ((int64_t)hc * wf + wc) * ld_mask + lane;
+    float e[9];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        e[k] = m[k * 64];
+        mx = fmaxf(mx, e[k]);
+    }
+    float den = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        e[k] = expf(e[k] - mx);
+        den += e[k];
+    }
+    float aw = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const int ny = hc + k / 3 - 1, nx = wc + k % 3 - 1;
+        float vw = 0.f;
+        if (ny >= 0 && ny < hf && nx >= 0 && nx < wf) vw = 8.f * wlow[(int64_t)ny * wf + nx];
+        const float s = e[k] / den;
+        aw += s * vw;
+    }
+    float v = aw / 8.f;
+    if (do_sigmoid) v = sigmoidf_(v);
+    wsel[i] = v;
+}
+
 // 8 * bilinear(align_corners=True) upsampling (small model, no mask head).
 __global__ void upflow8_kernel(const float* __restrict__ coords1, const float* __restrict__ wlow, int hf, int wf,
                                int crop_top, int crop_left, int h, int w, float* __restrict__ flow_up,
@@ -193,6 +231,15 @@ extern "C" int woft_resize_linear_u8(const uint8_t* img, int32_t h, int32_t w, i
     const int64_t n = (int64_t)ho * wo;
     hipLaunchKernelGGL(resize_linear_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, (hipStream_t)stream, img,
                        h, w, c, out, ho, wo, scale_y, scale_x);
+    return woft_launch_status();
+}
+
+extern "C" int woft_convex_weights_at(const float* pts, const int32_t* count, int32_t n_max, const float* wlow,
+                                      const float* mask, int32_t ld_mask, int32_t hf, int32_t wf, int32_t crop_top,
+                                      int32_t crop_left, int32_t do_sigmoid, float* wsel, void* stream) {
+    if (!pts || !wlow || !mask || !wsel || n_max <= 0 || hf <= 0 || wf <= 0 || ld_mask < 576) return WOFT_EINVAL;
+    hipLaunchKernelGGL(convex_weights_at_kernel, dim3((n_max + 255) / 256), dim3(256), 0, (hipStream_t)stream, pts, count,
+                       n_max, wlow, mask, ld_mask, hf, wf, crop_top, crop_left, do_sigmoid, wsel);
     return woft_launch_status();
 }
 

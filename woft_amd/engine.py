@@ -616,10 +616,12 @@ class _Plan:
             ops.convex_upsample(self.coords, wlow, self.mask.t, self.hf, self.wf, crop, h, w, flow_up=flow_up,
                                 dst=dst, wout=wout, do_sigmoid=do_sigmoid)
 
-    def finish_weights(self, pts, count, n_max, pad, crop, h, w, flow_up=None, dst=None, wout=None, do_sigmoid=False):
+    def finish_weights(self, pts, count, n_max, pad, crop, h, w, flow_up=None, dst=None, wout=None, do_sigmoid=False,
+                       w_points=None):
         """After flow(defer_wh=True): the weight head on the windows of the current region that the (count) full-resolution
         pixels pts (n_max, 2) need (woft_wh_needed: the 3x3 upsampling support of their 1/8-res cells), then the upsampling
         with the weights.  wout is exact at those pixels (the head has no cross-pixel terms); elsewhere it is unspecified.
+        w_points (n_max floats): receive the weights of the named pixels only, in their order, instead of the full map.
         pad = (top, left) of the padded image the 1/8-res grid belongs to."""
         index, _ = self.wh_region[:2]
         key = index.data_ptr()
@@ -632,6 +634,10 @@ class _Plan:
         dyn, prog, bitmap, n_needed = self._wh_dyn[key]
         ops.wh_needed(pts, count, n_max, pad[0], pad[1], self.hf, self.wf, index, bitmap, dyn, n_needed)
         self._weight_head(prog, dyn, n_needed)
+        if w_points is not None:     # the weights of the named pixels only, in their order (no second full-resolution pass)
+            ops.convex_weights_at(pts, count, n_max, self.wlow, self.mask.t, self.hf, self.wf, crop, w_points,
+                                  do_sigmoid=do_sigmoid)
+            return
         ops.convex_upsample(self.coords, self.wlow, self.mask.t, self.hf, self.wf, crop, h, w, flow_up=flow_up, dst=dst,
                             wout=wout, do_sigmoid=do_sigmoid)
 

@@ -77,7 +77,7 @@ class RAFTWrapper:
         self._pinned_key = None
         self._wmask, self._wregion = None, {}
         self.weights_deferred, self._deferred = False, None
-        self.defer_min_ratio = 11          # defer_weights: region windows per named pixel from which deferring pays
+        self.defer_min_ratio = 6           # defer_weights: region windows per named pixel from which deferring pays
         self._out = {}
         self._cache_errors = set()
 
@@ -104,17 +104,18 @@ class RAFTWrapper:
         else:
             g.replay()
 
-    def finish_weights(self, pts, count, n_max):
+    def finish_weights(self, pts, count, n_max, out=None):
         """After compute_flow(..., defer_weights=True) with `weights_deferred` set: evaluate the weight head for the
         (count, a device int32; at most n_max) source pixels pts (n_max, 2) = (x, y) and return the (1, H*W) weight tensor
-        (borrowed), exact at those pixels and unspecified elsewhere.  The weights of a source pixel do not depend on the
+        (borrowed), exact at those pixels and unspecified elsewhere -- or, with out (n_max floats), just the weights of
+        the named pixels, in their order.  The weights of a source pixel do not depend on the
         other pixels (weighted_raft.py:363-383), and the caller knows which correspondences it keeps before it needs
         their weights (TRK:287-312 + subsampler: decided by the flow alone)."""
         plan, crop, oh, ow, o, do_sigmoid = self._deferred
         self._deferred = None
         plan.finish_weights(pts, count, n_max, crop, crop, oh, ow, flow_up=o["flow"], dst=o["dst"], wout=o["w"],
-                            do_sigmoid=do_sigmoid)
-        return o["w"]
+                            do_sigmoid=do_sigmoid, w_points=out)
+        return o["w"] if out is None else out
 
     # ---- template caching (results-identical: InstanceNorm is per sample, extractor.py:171-190) ----
     def pin_source(self, src_img):
@@ -255,9 +256,8 @@ class RAFTWrapper:
         plan.load_image(1, d, top, left)
         o = self._outputs(oh, ow)
         weighted = self.C.raft_type == "weighted"
-        # (defer_weights = the number of pixels the caller will name: worth the second upsampling pass only if their 3x3
-        # supports cannot cover most of the region anyway -- at 720p a quarter-frame mask has 3 900 windows, 500 pixels need
-        # up to 4 500: measured +-0 there, +5 % at 1080p, +11 % at 4K)
+        # (defer_weights = the number of pixels the caller will name: worth it only if their 3x3 supports cannot cover most
+        # of the region anyway -- measured with 500 pixels: +0.7 % at 720p (3 900 windows), +6 % at 1080p, +11 % at 4K)
         self.weights_deferred = bool(defer_weights and weighted and not self.engine.small and plan.wh_region is not None
                                      and not self.use_graph and mode == "TC" and not numpy_out
                                      and int(plan.wh_region[0].numel()) > self.defer_min_ratio * int(defer_weights))

@@ -519,6 +519,13 @@ def convex_upsample(coords, wlow, mask, hf, wf, crop, h, w, flow_up=None, dst=No
           "woft_convex_upsample")
 
 
+def convex_weights_at(pts, count, n_max, wlow, mask, hf, wf, crop, wsel, do_sigmoid=False):
+    """wsel[i] = the weight convex_upsample would write at pixel pts[i] = (x, y), i < count (woft_convex_weights_at)."""
+    check(_lib.load().woft_convex_weights_at(ptr(pts), ptr(count), n_max, ptr(wlow), ptr(mask), mask.shape[1], hf, wf,
+                                             crop[0], crop[1], int(do_sigmoid), ptr(wsel), stream_ptr()),
+          "woft_convex_weights_at")
+
+
 def upflow8(coords, wlow, hf, wf, crop, h, w, flow_up=None, dst=None, wout=None, do_sigmoid=False):
     check(_lib.load().woft_upflow8(ptr(coords), ptr(wlow), hf, wf, crop[0], crop[1], h, w, ptr(flow_up), ptr(dst),
                                    ptr(wout), int(do_sigmoid), stream_ptr()), "woft_upflow8")

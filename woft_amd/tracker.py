@@ -288,13 +288,14 @@ class YAOFTrackerSingleControl:
         ires = res.view(torch.int32)
         if w is None and getattr(self.flower, "weights_deferred", False):
             # The correspondences the fit will read are decided by the flow alone (masks, bounds, Sobol draw): select them
-            # first, let the provider evaluate the weight head on the windows under THEIR upsampling support only, then
-            # select again, now with weights (same selection; exact weights at the selected pixels: identical fit)
+            # first, then let the provider evaluate the weight head on the windows under THEIR upsampling support only and
+            # hand back the weights of exactly these pixels (exact: the head has no cross-pixel terms) -- identical fit
             ops.tc_select(dst_xy, None, src_mask_u8, dst_valid_u8, frame_hw[0], frame_hw[1], bounds, F["sobol_u"], b["ws"],
                           b["pa"], b["pb"], b["w"], ires[12:14], grid=grid)
-            w = self.flower.finish_weights(b["pb"], ires[12:13], b["pb"].shape[0])      # (pb: the source pixels)
-        ops.tc_select(dst_xy, w, src_mask_u8, dst_valid_u8, frame_hw[0], frame_hw[1], bounds, F["sobol_u"], b["ws"],
-                      b["pa"], b["pb"], b["w"], ires[12:14], grid=grid)
+            self.flower.finish_weights(b["pb"], ires[12:13], b["pb"].shape[0], out=b["w"])      # (pb: the source pixels)
+        else:
+            ops.tc_select(dst_xy, w, src_mask_u8, dst_valid_u8, frame_hw[0], frame_hw[1], bounds, F["sobol_u"], b["ws"],
+                          b["pa"], b["pb"], b["w"], ires[12:14], grid=grid)
         ops.hfit(b["pa"], b["pb"], b["w"], res[0:9], ires[10:11], count=ires[12:13], reweight=F["reweight"],
                  huber_k=F["huber_k"], n_irls=F["n_irls"], ws=b["fit_ws"])
         ops.inlier_frac(b["pa"], b["pb"], res[0:9], res[9:10], thr=F["thr"], count=ires[12:13])
