@@ -218,6 +218,8 @@ typedef struct woft_lookup_otf_params {
     float alpha;            /* 1 / sqrt(k)  (corr.py:68)                                            */
     const float* coords;    /* [hf*wf][2]                                                           */
     float* out;             /* [hf*wf][ldo], channel order of woft_corr_lookup                      */
+    const int32_t* need;    /* optional [hf*wf]: source pixels whose samples are wanted (non-zero); an 8 x 8 block without
+                               any is skipped (its output rows are left untouched).  NULL: every pixel                 */
     int32_t ldo;
     int32_t ablate;         /* developer knob of tools/bench_lookup_otf.py (1: no target-row stream after the first steps,
                                2: no MFMAs, 4: no window scatter, 8: no interpolation / output); 0 in production */

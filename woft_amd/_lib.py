@@ -47,7 +47,7 @@ class LookupOtfParams(C.Structure):
     _fields_ = [
         ("f1", vp), ("f2", vp * 4), ("h", i32 * 4), ("w", i32 * 4),
         ("levels", i32), ("radius", i32), ("terms", i32), ("hf", i32), ("wf", i32), ("k", i32),
-        ("alpha", f32), ("coords", vp), ("out", vp), ("ldo", i32), ("ablate", i32),
+        ("alpha", f32), ("coords", vp), ("out", vp), ("need", vp), ("ldo", i32), ("ablate", i32),
     ]
 
 

@@ -65,6 +65,14 @@ __global__ __launch_bounds__(TW * 32, 2) void corr_lookup_otf_kernel(const woft_
         tile = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
     }
     const int px0 = (tile % tiles_x) * TW, py0 = (tile / tiles_x) * 8;
+    if (p.need != nullptr) {      // nobody wants this block's samples (the weight head on a subset of the source pixels)
+        int any = 0;
+        for (int e = threadIdx.x; e < NPX; e += NT) {
+            const int y = py0 + (e >> TSH), x = px0 + (e & (TW - 1));
+            if (y < p.hf && x < p.wf) any |= p.need[y * p.wf + x];
+        }
+        if (!__syncthreads_or(any)) return;
+    }
 
     // The block's source features stay in REGISTERS for the whole kernel, as the MFMA A fragments of this wave's
     // 32 rows (lane (r32, hh): row r32, k = 8 (2 s + hh) .. + 7 of every line; hi and lo halves of the line) -- the

@@ -633,7 +633,7 @@ class _Plan:
                                  torch.zeros(1, dtype=torch.int32, device=index.device))
         dyn, prog, bitmap, n_needed = self._wh_dyn[key]
         ops.wh_needed(pts, count, n_max, pad[0], pad[1], self.hf, self.wf, index, bitmap, dyn, n_needed)
-        self._weight_head(prog, dyn, n_needed)
+        self._weight_head(prog, dyn, n_needed, need=bitmap)
         if w_points is not None:     # the weights of the named pixels only, in their order (no second full-resolution pass)
             ops.convex_weights_at(pts, count, n_max, self.wlow, self.mask.t, self.hf, self.wf, crop, w_points,
                                   do_sigmoid=do_sigmoid)
@@ -641,12 +641,17 @@ class _Plan:
         ops.convex_upsample(self.coords, self.wlow, self.mask.t, self.hf, self.wf, crop, h, w, flow_up=flow_up, dst=dst,
                             wout=wout, do_sigmoid=do_sigmoid)
 
-    def _weight_head(self, prog_wh, index, n_needed=None):
+    def _weight_head(self, prog_wh, index, n_needed=None, need=None):
         """Final lookup + the weight head (weighted_raft.py:266-272, 347-384) on all source pixels (index None) or on the
         windows listed in `index` -> self.wlow."""
         e, sp = self.eng, self.eng.spec
         if True:                                                     # (one indentation level kept: the body moved here as is)
-            self._lookup(self.lookup)                                # final lookup, weighted_raft.py:266
+            if need is not None and self.otf:                        # final lookup, weighted_raft.py:266 -- only the 8x8
+                self.lookup.need = _lib.ptr(need)                    # blocks that hold a wanted window (volume-free lookup)
+                self._lookup(self.lookup)
+                self.lookup.need = None
+            else:
+                self._lookup(self.lookup)
             lib = _lib.load()
             n = sp.nwin
             _lib.check(lib.woft_colsum(_lib.ptr(self.f2act[0].t), self.P, sp.fdim, _lib.ptr(self.cs_ws), 256,
