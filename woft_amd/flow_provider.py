@@ -81,17 +81,18 @@ class RAFTWrapper:
         self._out = {}
         self._cache_errors = set()
 
-    def _run_flow(self, plan, iters, crop, oh, ow, o, weighted, do_sigmoid, defer_wh=False):
+    def _run_flow(self, plan, iters, crop, oh, ow, o, weighted, do_sigmoid, defer_wh=False, want_flow=True):
         """plan.flow() eagerly, or -- use_graph -- as ONE hipGraph launch (captured at the second call with the same
         arguments; the per-launch event hooks of bench.py force the eager path)."""
         def eager():
-            plan.flow(iters, crop, oh, ow, flow_up=o["flow"], dst=o["dst"], wout=o["w"] if weighted else None,
+            # (mode "TC" hands out dst = grid + flow only: the (2, H, W) flow map is then not written at all)
+            plan.flow(iters, crop, oh, ow, flow_up=o["flow"] if want_flow else None, dst=o["dst"], wout=o["w"] if weighted else None,
                       do_sigmoid=do_sigmoid, defer_wh=defer_wh)
         if defer_wh or not self.use_graph or plan.lookup_events is not None or plan.wh_events is not None or plan.conv_events is not None:
             return eager()
         graphs = plan.__dict__.setdefault("_graphs", {})
         region = plan.wh_region
-        key = (iters, crop, oh, ow, weighted, do_sigmoid, o["flow"].data_ptr(),
+        key = (iters, crop, oh, ow, weighted, do_sigmoid, want_flow, o["flow"].data_ptr(),
                region[0].data_ptr() if region is not None else 0)
         g = graphs.get(key)
         if g is None:
@@ -263,7 +264,7 @@ class RAFTWrapper:
                                      and int(plan.wh_region[0].numel()) > self.defer_min_ratio * int(defer_weights))
         self._deferred = (plan, (top, left), oh, ow, o, bool(do_sigmoid)) if self.weights_deferred else None
         self._run_flow(plan, int(self.C.iters), (top, left), oh, ow, o, weighted, bool(do_sigmoid),
-                       defer_wh=self.weights_deferred)
+                       defer_wh=self.weights_deferred, want_flow=(mode == "flow"))
         if self.weights_deferred:
             return self._deliver(o, None, mode, oh, ow, numpy_out, borrow)
         logger.debug(f"flow enqueue time [s]: {float(timer() - start_time)}")
