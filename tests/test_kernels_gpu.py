@@ -531,6 +531,44 @@ def test_corr_gemm_presplit(ops, h, w, precision, tol):
         _close(vols[l], ref[l], tol * 0.1, what=f"level {l}: pre-split GEMM vs the conv kernel")
 
 
+def test_lookup_on_the_fly_wanted_blocks(ops):
+    """woft_lookup_otf_params.need: 8x8 blocks of source pixels without a wanted pixel are skipped (their output rows stay
+    as they were), the others are computed in full -- the same bits as without the map."""
+    h, w, c = 24, 40, 256
+    f1, f2 = _rand(1, c, h, w, seed=51), _rand(1, c, h, w, seed=52)
+    coords = raft_ref.coords_grid(1, h, w) + _rand(1, 2, h, w, seed=53, scale=3.0)
+    cg = coords[0].permute(1, 2, 0).reshape(h * w, 2).contiguous().cuda()
+    a1, a2 = ops.act_from_nchw(f1), ops.act_from_nchw(f2)
+
+    def split(t):
+        o = torch.zeros(t.shape[0], 2 * c, dtype=torch.bfloat16, device="cuda")
+        ops.split_bf16_lines(t, o)
+        return o
+    f2s, dims, cur = [], [], a2
+    for l in range(4):
+        f2s.append(split(cur.t))
+        dims.append((cur.h, cur.w))
+        if l < 3:
+            nxt = ops.new_act(1, cur.h // 2, cur.w // 2, c)
+            ops.avgpool2(cur, nxt)
+            cur = nxt
+    full, part = torch.zeros(h * w, 352, device="cuda"), torch.full((h * w, 352), 3.0, device="cuda")
+    ops.run_lookup_otf(ops.make_lookup_otf_params(split(a1.t), f2s, dims, h, w, c, cg, full, 4, 3))
+    need = torch.zeros(h, w, dtype=torch.int32, device="cuda")
+    need[3, 5] = 1            # block (0, 0)
+    need[23, 39] = 1          # block (2, 4)
+    p = ops.make_lookup_otf_params(split(a1.t), f2s, dims, h, w, c, cg, part, 4, 3)
+    p.need = need.data_ptr()
+    ops.run_lookup_otf(p)
+    torch.cuda.synchronize()
+    blk = torch.zeros(h, w, dtype=torch.bool)
+    blk[0:8, 0:8] = True
+    blk[16:24, 32:40] = True
+    blk = blk.reshape(-1)
+    assert torch.equal(part.cpu()[blk][:, :324], full.cpu()[blk][:, :324])
+    assert float((part.cpu()[~blk] - 3.0).abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("h,w,dtype", [(17, 25, torch.float32), (24, 40, torch.float32), (33, 47, torch.bfloat16),
                                        (8, 9, torch.bfloat16)])
 def test_lookup_tile_shapes(ops, h, w, dtype):
@@ -713,6 +751,47 @@ def test_convex_upsample(ops):
     torch.cuda.synchronize()
     _close(f_c, fu[0, :, top:top + h, left:left + w], 2e-5, what="flow_up crop")
     _close(w_c.reshape(h, w), wu[0, 0, top:top + h, left:left + w], 2e-5, what="w_up crop")
+
+
+def test_weights_at_points_and_needed_windows(ops):
+    """The sparse weight head's helpers.  woft_convex_weights_at: the weight woft_convex_upsample writes at a pixel, computed
+    for a list of pixels only -- bit for bit, with crop offsets, raw and sigmoid, count on the device.  woft_wh_needed: the
+    window list rewritten to the windows under the 3x3 upsampling support of those pixels' 1/8-res cells (numpy reference)."""
+    hf, wf = 9, 11
+    flow = _rand(1, 2, hf, wf, seed=35, scale=4.0)
+    wl = _rand(1, 1, hf, wf, seed=36, scale=3.0).reshape(-1).cuda()
+    mask = _rand(1, 576, hf, wf, seed=37, scale=2.0)
+    coords = (raft_ref.coords_grid(1, hf, wf) + flow)[0].permute(1, 2, 0).reshape(-1, 2).contiguous().cuda()
+    mk = mask[0].permute(1, 2, 0).reshape(-1, 576).contiguous().cuda()
+    rs = np.random.RandomState(3)
+    for (top, left, h, w), sig in (((0, 0, 8 * hf, 8 * wf), True), ((2, 1, 8 * hf - 5, 8 * wf - 3), False)):
+        w_full = torch.zeros(h * w, device="cuda")
+        ops.convex_upsample(coords, wl, mk, hf, wf, (top, left), h, w, None, None, w_full, do_sigmoid=sig)
+        n_max, n = 64, 50
+        pts = np.stack([rs.randint(0, w, n_max), rs.randint(0, h, n_max)], 1).astype(np.float32)
+        pts[0], pts[1] = (0, 0), (w - 1, h - 1)
+        pts_d = torch.from_numpy(pts).cuda()
+        count = torch.tensor([n], dtype=torch.int32, device="cuda")
+        wsel = torch.full((n_max,), -7.0, device="cuda")
+        ops.convex_weights_at(pts_d, count, n_max, wl, mk, hf, wf, (top, left), wsel, do_sigmoid=sig)
+        torch.cuda.synchronize()
+        idx = (pts[:n, 1] * w + pts[:n, 0]).astype(np.int64)
+        assert torch.equal(wsel[:n].cpu(), w_full.cpu()[idx])
+        assert float((wsel[n:] + 7.0).abs().max()) == 0.0                      # beyond the count: untouched
+        # needed windows of a window list (here: every second 1/8-res pixel) for these points
+        index = torch.arange(0, hf * wf, 2, dtype=torch.int32, device="cuda")
+        bitmap = torch.full((hf * wf,), 5, dtype=torch.int32, device="cuda")    # (scratch: cleared by the call)
+        dyn = torch.zeros_like(index)
+        n_needed = torch.zeros(1, dtype=torch.int32, device="cuda")
+        ops.wh_needed(pts_d, count, n_max, top, left, hf, wf, index, bitmap, dyn, n_needed)
+        torch.cuda.synchronize()
+        need = np.zeros((hf, wf), bool)
+        for x, y in pts[:n]:
+            cy, cx = (int(y) + top) >> 3, (int(x) + left) >> 3
+            need[max(cy - 1, 0):cy + 2, max(cx - 1, 0):cx + 2] = True
+        want = np.where(need.reshape(-1)[index.cpu().numpy()], index.cpu().numpy(), -1)
+        assert np.array_equal(dyn.cpu().numpy(), want) and int(n_needed) == int((want >= 0).sum())
+        assert np.array_equal(bitmap.cpu().numpy() != 0, need.reshape(-1))
 
 
 def test_upflow8(ops):
