@@ -234,6 +234,69 @@ def test_cached_flow_wire_format(tmp_path):
     _, dst2, w2 = prov.compute_flow(img, img, mode="TC", src_img_identifier=("ds", "seq", 9), numpy_out=True)
     _, dst3, w3 = prov.compute_flow(img, img, mode="TC", numpy_out=True)
     assert dst2.shape == (2, h * w) and np.array_equal(dst2, dst3) and np.array_equal(w2, w3)
+    # unreadable caches fall back the same way (the reference computes the flow on ANY exception, raft.py:108-109):
+    # a truncated archive, an object placeholder instead of the weight array, a missing array
+    blob = (d / "7-8.npz").read_bytes()
+    (d / "10-11.npz").write_bytes(blob[:len(blob) // 2])
+    np.savez(d / "11-12.npz", half_flow=flow, half_weights=np.array(None, dtype=object))
+    np.savez(d / "12-13.npz", half_flow=flow)
+    (d / "13-14.npz").write_bytes(b"")
+    for i in (10, 11, 12, 13):
+        _, dst4, w4 = prov.compute_flow(img, img, mode="TC", src_img_identifier=("ds", "seq", i), numpy_out=True)
+        assert np.array_equal(dst4, dst3) and np.array_equal(w4, w3), i
+
+
+@torch.no_grad()
+def test_weights_postprocessing_fn_and_backbone_model(tmp_path):
+    """Flow config keys the reference reads: `weights_postprocessing_fn` -- a callable on the (1, 1, H, W)
+    weight LOGITS, before the sigmoid (raft.py:152-159), for computed and for cached flows -- and `backbone_model`
+    (raft.py:58-62: the fnet / cnet / update_block tensors of `model` are dropped; here they come from that checkpoint)."""
+    h, w = 128, 160
+    sd = synth.make_state_dict(seed=3)
+    a = synth.make_template(h, w, seq_id=2)
+    b = synth.make_frame(a, 2)
+    base = _flow_config(sd, 2, precision="bf16x3")
+    _, dst0, logit0 = base.of_class(base).compute_flow(a, b, mode="TC")
+    seen = {}
+
+    def post(wmap):
+        seen["shape"] = tuple(wmap.shape)
+        return 2.0 * torch.nn.functional.avg_pool2d(wmap, 3, stride=1, padding=1)     # a spatial map -> map function
+    c = _flow_config(sd, 2, precision="bf16x3")
+    c.weights_postprocessing_fn = post
+    prov = c.of_class(c)
+    prov.pin_source(a)
+    prov.pin_weight_region(np.ones((h, w), bool))
+    for kw in ({}, {"weight_region": True, "defer_weights": 10}):         # (the callable may read any pixel: full map)
+        _, dst1, w1 = prov.compute_flow(a, b, mode="TC", do_sigmoid=True, **kw)
+        assert seen["shape"] == (1, 1, h, w) and not prov.weights_deferred
+        want = torch.sigmoid(post(logit0.reshape(1, 1, h, w))).reshape(1, -1)
+        assert torch.equal(dst1, dst0) and torch.allclose(w1, want, rtol=0, atol=1e-6)
+    fl, wl = prov.compute_flow(a, b, mode="flow")
+    assert torch.allclose(wl, post(logit0.reshape(1, 1, h, w)).reshape(1, h, w), rtol=0, atol=1e-6)
+    # cached flow: the same callable on the stored logits
+    rng = np.random.RandomState(1)
+    d = tmp_path / "ds" / "s"
+    d.mkdir(parents=True)
+    wts = rng.randn(1, h, w).astype(np.float32)
+    np.savez(d / "0-1.npz", half_flow=rng.randn(2, h, w).astype(np.float32), half_weights=wts)
+    c.flow_cache_dir = tmp_path
+    _, _, wc = prov.compute_flow(a, b, mode="TC", src_img_identifier=("ds", "s", 0), do_sigmoid=True)
+    want = torch.sigmoid(post(torch.from_numpy(wts)[None].cuda())).reshape(1, -1)
+    assert torch.allclose(wc, want, rtol=0, atol=1e-6)
+    # backbone_model: weight head of `model`, backbone of the second checkpoint
+    other = synth.make_state_dict(seed=9)
+    path = tmp_path / "backbone.pth"
+    torch.save({"module." + k: v for k, v in other.items()}, path)
+    merged = {k: (other[k] if any(t in k for t in ("fnet", "cnet", "update_block")) else v) for k, v in sd.items()}
+    assert any(not torch.equal(merged[k], sd[k]) for k in sd) and any(torch.equal(merged[k], sd[k]) for k in sd)
+    ref = _flow_config(merged, 2, precision="bf16x3")
+    _, dst_ref, w_ref = ref.of_class(ref).compute_flow(a, b, mode="TC")
+    for src in (path, other):
+        c2 = _flow_config(sd, 2, precision="bf16x3")
+        c2.backbone_model = src
+        _, dst2, w2 = c2.of_class(c2).compute_flow(a, b, mode="TC")
+        assert torch.equal(dst2, dst_ref) and torch.equal(w2, w_ref)
 
 
 @torch.no_grad()
@@ -301,7 +364,7 @@ def test_graph_replay_matches_eager(precision, small):
                 m = np.zeros((h, w), bool)
                 m[40:100, 60:150] = True
                 prov.pin_weight_region(m)
-            src, dst, wt = prov.compute_flow(a, f, mode="TC", do_sigmoid=True)
+            src, dst, wt = prov.compute_flow(a, f, mode="TC", do_sigmoid=True, weight_region=True)
             res.append((dst.cpu().numpy().copy(), None if wt is None else wt.cpu().numpy().copy()))
         outs[graph] = res
         if graph:

@@ -92,6 +92,12 @@ def test_tracker_lost_branch_and_interfaces():
     tracker.set_fast_meta(meta)
     Hf, mf = tracker.track(frames[0])
     assert Hf is meta.estim_H_current2template and mf is meta and not tracker.lost
+    tracker.set_fast_meta(meta)                      # reference-style cancellation: `tracker.fast_forward = False`
+    assert tracker.fast_forward
+    tracker.fast_forward = False
+    assert not tracker.fast_forward and tracker.track(frames[0])[1] is not meta
+    with pytest.raises(ValueError):
+        tracker.fast_forward = True
     two = mask.copy()
     two[:8, :8] = 255
     with pytest.raises(AssertionError):
@@ -216,11 +222,19 @@ def test_weight_head_on_mask_region_only():
         if not full:
             n_sel = int(plan.wh_region[0].numel())
             assert 0 < n_sel < plan.P // 2
-            _, _, w_reg = trk.flower.compute_flow(template, frames[0], mode="TC", do_sigmoid=True, numpy_out=True)
-            trk.flower.pin_weight_region(None)
+            # the region belongs to the TRACKER's calls (weight_region=True); anybody else's compute_flow gets the
+            # reference's full weight map -- after init(), too
+            _, _, w_reg = trk.flower.compute_flow(template, frames[0], mode="TC", do_sigmoid=True, numpy_out=True,
+                                                  weight_region=True)
             _, _, w_full = trk.flower.compute_flow(template, frames[0], mode="TC", do_sigmoid=True, numpy_out=True)
             sel = (mask > 0).reshape(-1)
             assert np.array_equal(w_reg[0, sel], w_full[0, sel])
+            assert not np.array_equal(w_reg[0, ~sel], w_full[0, ~sel])       # (outside: 0.5 = sigmoid(0) vs real weights)
+            assert float(np.abs(w_full[0, ~sel] - 0.5).max()) > 1e-3
+            trk.flower.pin_weight_region(None)
+            _, _, w_none = trk.flower.compute_flow(template, frames[0], mode="TC", do_sigmoid=True, numpy_out=True,
+                                                   weight_region=True)
+            assert np.array_equal(w_none, w_full)
     for a, b in zip(outs[True], outs[False]):
         assert np.array_equal(a, b)
     # the key's default: on (the tracker never reads the other weights); off when a post-hoc filter of the weight map is set

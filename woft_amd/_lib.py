@@ -129,7 +129,7 @@ def ptr(t):
 
 
 _RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None) if os.environ.get("WOFT_RAW_STREAM", "1") != "0" else None
-_DEV_INDEX = None
+_CUR_DEV = torch.cuda.current_device
 
 
 def stream_ptr():
@@ -137,9 +137,6 @@ def stream_ptr():
     torch.cuda.current_stream() builds a Stream object through several Python layers (7.7 us, x 200 launches per frame =
     1.5 ms of host time, most of what stands between a frame's device->host read and the next frame's first launches);
     the raw getter is one C call."""
-    global _DEV_INDEX
     if _RAW_STREAM is None:
         return torch.cuda.current_stream().cuda_stream
-    if _DEV_INDEX is None:
-        _DEV_INDEX = torch.cuda.current_device()         # one device per process (bench ranks select theirs first)
-    return _RAW_STREAM(_DEV_INDEX)
+    return _RAW_STREAM(_CUR_DEV())                       # (current_device(): one cheap C call; follows set_device / device guards)

@@ -111,6 +111,7 @@ __global__ __launch_bounds__(256) void wh_conv0_kernel(const float* __restrict__
     const f32x2 bias = *(const f32x2*)(b0 + co);
     for (int p = blockIdx.x * 4 + wave; p < n_pix; p += gridDim.x * 4) {
         const int src = index ? index[p] : p;           // window p of the output = source pixel index[p]
+        if (src < 0) continue;                          // (dynamic window list: -1 = window not wanted in this launch)
         const float* __restrict__ lk = lookup + (int64_t)src * ld;
         const float mv = mean[src];
         float* __restrict__ o = out + (int64_t)p * (NW * NW * 128) + co;

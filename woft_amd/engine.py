@@ -645,39 +645,38 @@ class _Plan:
         """Final lookup + the weight head (weighted_raft.py:266-272, 347-384) on all source pixels (index None) or on the
         windows listed in `index` -> self.wlow."""
         e, sp = self.eng, self.eng.spec
-        if True:                                                     # (one indentation level kept: the body moved here as is)
-            if need is not None and self.otf:                        # final lookup, weighted_raft.py:266 -- only the 8x8
-                self.lookup.need = _lib.ptr(need)                    # blocks that hold a wanted window (volume-free lookup)
-                self._lookup(self.lookup)
-                self.lookup.need = None
+        if need is not None and self.otf:                        # final lookup, weighted_raft.py:266 -- only the 8x8
+            self.lookup.need = _lib.ptr(need)                    # blocks that hold a wanted window (volume-free lookup)
+            self._lookup(self.lookup)
+            self.lookup.need = None
+        else:
+            self._lookup(self.lookup)
+        lib = _lib.load()
+        n = sp.nwin
+        _lib.check(lib.woft_colsum(_lib.ptr(self.f2act[0].t), self.P, sp.fdim, _lib.ptr(self.cs_ws), 256,
+                                   _lib.ptr(self.cs_tot), _lib.stream_ptr()), "woft_colsum")
+        _lib.check(lib.woft_wh_pack(_lib.ptr(self.corr.t), self.corr.cs, _lib.ptr(self.f1.t), sp.fdim,
+                                    _lib.ptr(self.cs_tot), 1.0 / (math.sqrt(float(sp.fdim)) * self.P), self.P, n,
+                                    _lib.ptr(self.wmean), None if self.wh0_direct else _lib.ptr(self.x8.t),
+                                    _lib.stream_ptr()), "woft_wh_pack")
+        n_win = int(index.numel()) if index is not None else self.P
+        if index is not None:
+            self.wlow.zero_()                                    # pixels outside the region
+        if self.wh0_direct and not self.wh0_fused:
+            _lib.check(lib.woft_wh_conv0(_lib.ptr(self.corr.t), self.corr.cs, _lib.ptr(self.wmean), n_win, n,
+                                         _lib.ptr(self.wh0_t), _lib.ptr(e.wh0.bias), _lib.ptr(self.a1.t),
+                                         _lib.ptr(index) if index is not None else None,
+                                         _lib.stream_ptr()), "woft_wh_conv0")
+        for k, p in enumerate(prog_wh):
+            if k == 0 and self.wh_events is not None:            # bench.py: HIP events around the first 128->128 layer
+                s, t = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                ops.run_conv(p)
+                t.record()
+                # (dynamic window list: the number of windows that really ran is on the device)
+                self.wh_events.append((s, t, n_win if n_needed is None else n_needed.clone()))
             else:
-                self._lookup(self.lookup)
-            lib = _lib.load()
-            n = sp.nwin
-            _lib.check(lib.woft_colsum(_lib.ptr(self.f2act[0].t), self.P, sp.fdim, _lib.ptr(self.cs_ws), 256,
-                                       _lib.ptr(self.cs_tot), _lib.stream_ptr()), "woft_colsum")
-            _lib.check(lib.woft_wh_pack(_lib.ptr(self.corr.t), self.corr.cs, _lib.ptr(self.f1.t), sp.fdim,
-                                        _lib.ptr(self.cs_tot), 1.0 / (math.sqrt(float(sp.fdim)) * self.P), self.P, n,
-                                        _lib.ptr(self.wmean), None if self.wh0_direct else _lib.ptr(self.x8.t),
-                                        _lib.stream_ptr()), "woft_wh_pack")
-            n_win = int(index.numel()) if index is not None else self.P
-            if index is not None:
-                self.wlow.zero_()                                    # pixels outside the region
-            if self.wh0_direct and not self.wh0_fused:
-                _lib.check(lib.woft_wh_conv0(_lib.ptr(self.corr.t), self.corr.cs, _lib.ptr(self.wmean), n_win, n,
-                                             _lib.ptr(self.wh0_t), _lib.ptr(e.wh0.bias), _lib.ptr(self.a1.t),
-                                             _lib.ptr(index) if index is not None else None,
-                                             _lib.stream_ptr()), "woft_wh_conv0")
-            for k, p in enumerate(prog_wh):
-                if k == 0 and self.wh_events is not None:            # bench.py: HIP events around the first 128->128 layer
-                    s, t = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    s.record()
-                    ops.run_conv(p)
-                    t.record()
-                    # (dynamic window list: the number of windows that really ran is on the device)
-                    self.wh_events.append((s, t, n_win if n_needed is None else n_needed.clone()))
-                else:
-                    ops.run_conv(p)
-            if not self.wh_fused:
-                _lib.check(lib.woft_wh_reduce(_lib.ptr(self.a1.t), 128, n * n, _lib.ptr(e.wh6_w), e.wh6_b, self.P,
-                                              _lib.ptr(self.wlow), _lib.stream_ptr()), "woft_wh_reduce")
+                ops.run_conv(p)
+        if not self.wh_fused:
+            _lib.check(lib.woft_wh_reduce(_lib.ptr(self.a1.t), 128, n * n, _lib.ptr(e.wh6_w), e.wh6_b, self.P,
+                                          _lib.ptr(self.wlow), _lib.stream_ptr()), "woft_wh_reduce")

@@ -5,6 +5,7 @@
 """
 import logging
 import os
+import zipfile
 from pathlib import Path
 from timeit import default_timer as timer
 
@@ -44,14 +45,22 @@ class RAFTWrapper:
         cp = config.class_params
         if cp.mask_estimation:
             raise NotImplementedError("mask_estimation (MaskHead) is unset in every shipped config")
-        if self.C.backbone_model:
-            raise NotImplementedError("backbone_model (a second checkpoint merged into the state-dict, raft.py:58-62) "
-                                      "is unset in every shipped RAFT config")
         if self.C.raft_type not in ("orig", "weighted"):
             raise ValueError(f"Unknown RAFT type {self.C.raft_type}")
         logger.info(f"Loading weights from: {self.C.model}")
-        state_dict = self.C.model if isinstance(self.C.model, dict) else torch.load(self.C.model, map_location="cpu")
-        state_dict = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in state_dict.items()}
+
+        def read(src):
+            sd = src if isinstance(src, dict) else torch.load(src, map_location="cpu")
+            return {(k[len("module."):] if k.startswith("module.") else k): v for k, v in sd.items()}
+        state_dict = read(self.C.model)
+        if self.C.backbone_model:
+            # raft.py:58-62 drops every fnet / cnet / update_block tensor of `model` ("will overwrite backbone later ...
+            # weights pre-trained on standard RAFT"); the overwrite itself is not in the reference's wrapper (the backbone
+            # stays at its random initialisation there).  Here the announced merge is carried out: the backbone tensors
+            # come from the `backbone_model` checkpoint (a path or a state-dict), everything else (the weight head) from `model`.
+            in_backbone = lambda k: ("fnet" in k) or ("cnet" in k) or ("update_block" in k)
+            state_dict = {k: v for k, v in state_dict.items() if not in_backbone(k)}
+            state_dict.update({k: v for k, v in read(self.C.backbone_model).items() if in_backbone(k)})
         weighted = self.C.raft_type == "weighted"
         small = bool(cp.small)
         # arithmetic of the convolutions / correlation GEMM: "fp32" (exact fp32 MFMA, the reference's
@@ -177,8 +186,7 @@ class RAFTWrapper:
         wts = data["half_weights"].astype(np.float32)
         wts = np.ascontiguousarray(wts) if wts.size > 1 else None
         h, w = flow.shape[1:]
-        if self.C.weights_postprocessing_fn and wts is not None:
-            raise NotImplementedError("weights_postprocessing_fn is None in every shipped config")
+        post = self.C.weights_postprocessing_fn if wts is not None else None
         o = self._outputs(h, w)
         o["flow"].copy_(torch.from_numpy(flow), non_blocking=True)
         wl = None
@@ -186,9 +194,17 @@ class RAFTWrapper:
             wl = torch.from_numpy(wts).cuda(non_blocking=True)
         lib = _lib.load()
         _lib.check(lib.woft_flow_to_tc(_lib.ptr(o["flow"]), _lib.ptr(wl), h, w, _lib.ptr(o["dst"]),
-                                       _lib.ptr(o["w"]) if wl is not None else None, int(bool(do_sigmoid)),
+                                       _lib.ptr(o["w"]) if wl is not None else None, int(bool(do_sigmoid) and not post),
                                        _lib.stream_ptr()), "woft_flow_to_tc")
+        if post:
+            self._postprocess_logits(o, h, w, do_sigmoid)
         return self._deliver(o, o["w"] if wl is not None else None, mode, h, w, numpy_out, borrow)
+
+    def _postprocess_logits(self, o, h, w, do_sigmoid):
+        """raft.py:152-159: `weights_postprocessing_fn` maps the (1, 1, H, W) weight LOGITS, then the sigmoid (if asked)."""
+        wts = self.C.weights_postprocessing_fn(o["w"].reshape(1, 1, h, w))
+        wts = torch.as_tensor(wts, device=o["w"].device, dtype=torch.float32).reshape(1, h * w)
+        o["w"].copy_(torch.sigmoid(wts) if do_sigmoid else wts)
 
     def _deliver(self, o, weights, mode, oh, ow, numpy_out, borrow):
         """The caller's view of the outputs.  The kernels write into per-resolution buffers that the NEXT call at the
@@ -205,14 +221,17 @@ class RAFTWrapper:
         self.last_flow_shape = {"batch": 1, "delta": 2, "H": oh, "W": ow}
         if numpy_out:
             return host(o["src"]), host(o["dst"]), (host(weights) if weights is not None else None)
-        return o["src"], own(o["dst"]), (own(weights) if weights is not None else None)     # (src: constant grid)
+        return own(o["src"]), own(o["dst"]), (own(weights) if weights is not None else None)
 
     def compute_flow(self, src_img, dst_img, mode="TC", vis=False, src_img_identifier=None,
-                     numpy_out=False, do_sigmoid=False, borrow=False, defer_weights=False):
+                     numpy_out=False, do_sigmoid=False, borrow=False, defer_weights=False, weight_region=False):
         """src_img / dst_img: (H, W, 3) uint8 BGR (numpy, or CUDA tensors already on the device).
         mode 'TC' -> (src_coords (2,HW) int64, dst_coords (2,HW) f32, weights (1,HW) f32 | None)
         mode 'flow' -> (flow (2,H,W), weights (1,H,W) | None).
         borrow (extension, default off): return the provider's own output buffers, valid until the next call.
+        weight_region (extension, default off): the caller reads the weights only inside the region declared with
+        pin_weight_region() (flows from the pinned source); without it every call returns the full weight map, as the
+        reference does.
         defer_weights (extension, default off: 0; else the number of source pixels the caller will name; honoured for flows
         from the pinned source whose weight region is large against it, else ignored: check `weights_deferred` after the
         call): return the flow / correspondences with weights = None and evaluate the weight head later, in
@@ -222,7 +241,8 @@ class RAFTWrapper:
         if src_img_identifier is not None:                 # pre-computed flow (raft.py:92-109)
             try:
                 return self._cached_flow(src_img, src_img_identifier, mode, numpy_out, do_sigmoid, borrow)
-            except (OSError, KeyError) as ex:              # no such file / no such array: compute the flow instead
+            except (OSError, KeyError, ValueError, EOFError, zipfile.BadZipFile) as ex:   # no such file / array, object
+                # placeholders, truncated archives (the reference falls back on any exception, raft.py:108-109): compute the flow
                 key = (type(ex), str(ex))                  # (the reference logs each distinct error once)
                 if key not in self._cache_errors:
                     self._cache_errors.add(key)
@@ -252,7 +272,9 @@ class RAFTWrapper:
             plan.encode_source()
             plan.source_tag = self if src_img is self._pinned else None
             self._pinned_key = key if src_img is self._pinned else None
-        plan.set_weight_region(self._weight_region(key, hp, wp, top, left, oh, ow) if src_img is self._pinned else None)
+        post = self.C.weights_postprocessing_fn or None     # (a map -> map callable may read any pixel: full map)
+        plan.set_weight_region(self._weight_region(key, hp, wp, top, left, oh, ow)
+                               if (weight_region and src_img is self._pinned and not post) else None)
         d = up(dst_img)
         plan.load_image(1, d, top, left)
         o = self._outputs(oh, ow)
@@ -263,13 +285,12 @@ class RAFTWrapper:
                                      and not self.use_graph and mode == "TC" and not numpy_out
                                      and int(plan.wh_region[0].numel()) > self.defer_min_ratio * int(defer_weights))
         self._deferred = (plan, (top, left), oh, ow, o, bool(do_sigmoid)) if self.weights_deferred else None
-        self._run_flow(plan, int(self.C.iters), (top, left), oh, ow, o, weighted, bool(do_sigmoid),
+        self._run_flow(plan, int(self.C.iters), (top, left), oh, ow, o, weighted, bool(do_sigmoid) and not post,
                        defer_wh=self.weights_deferred, want_flow=(mode == "flow"))
         if self.weights_deferred:
             return self._deliver(o, None, mode, oh, ow, numpy_out, borrow)
         logger.debug(f"flow enqueue time [s]: {float(timer() - start_time)}")
         weights = o["w"] if weighted else None
-        if self.C.weights_postprocessing_fn and weights is not None:
-            # the reference applies it to the logits before the sigmoid (raft.py:152-159)
-            raise NotImplementedError("weights_postprocessing_fn is None in every shipped config")
+        if post and weights is not None:
+            self._postprocess_logits(o, oh, ow, do_sigmoid)    # the logits, then the sigmoid (raft.py:152-159)
         return self._deliver(o, weights, mode, oh, ow, numpy_out, borrow)

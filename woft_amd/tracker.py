@@ -141,9 +141,9 @@ class YAOFTrackerSingleControl:
             # weights of the other template pixels are never read by this tracker, and the weight head has no
             # cross-pixel terms (weighted_raft.py:363-383), so for flows FROM the template it is evaluated on the mask's
             # pixels only -- bit-identical weights there, identical homographies (tested), ~25 % fewer milliseconds per
-            # frame at a quarter-frame mask.  `compute_flow` called directly keeps returning the full weight map (the
-            # region is a property of the pinned template, set here); config key mask_weight_head = False evaluates
-            # the head everywhere, as the reference's network does.
+            # frame at a quarter-frame mask.  Only the tracker's own calls ask for the region (`weight_region=True`, _flow
+            # below): `compute_flow` called directly returns the full weight map; config key mask_weight_head = False
+            # evaluates the head everywhere for the tracker too, as the reference's network does.
             if hasattr(self.flower, "pin_weight_region"):
                 self.flower.pin_weight_region(inside if self._mask_weight_head() else None)
             # ... and with a subsampler in front of the fit (the default config draws 500 correspondences), only the weights
@@ -168,6 +168,15 @@ class YAOFTrackerSingleControl:
     @property
     def fast_forward(self):
         return self._replay is not None
+
+    @fast_forward.setter
+    def fast_forward(self, value):
+        """Reference-style `tracker.fast_forward = False` (TRK:47,55,64) cancels a pending replay; True without a stored
+        meta has nothing to replay (set_fast_meta is the way in)."""
+        if not value:
+            self._replay = None
+        elif self._replay is None:
+            raise ValueError("fast_forward = True needs set_fast_meta(meta)")
 
     def track(self, input_img, debug=False, img_identifier=None):
         if self.C.downscale_inputs:                                  # TRK:60-61
@@ -228,7 +237,9 @@ class YAOFTrackerSingleControl:
     def _flow(self, src, dst):
         """-> (grid coords (2, n) int64, target coords (2, n) f32, weights (1, n) f32 | None, (gh, gw)); borrowed
         buffers of the provider: consumed before the next flow."""
-        kw = {"borrow": True} if hasattr(self.flower, "pin_source") else {}
+        # (borrowed buffers, and -- only for THIS caller -- weights restricted to the region pinned in init(): a direct
+        #  compute_flow() call by anybody else returns the full weight map, as the reference's does)
+        kw = {"borrow": True, "weight_region": True} if hasattr(self.flower, "pin_source") else {}
         if self._sparse_weights and src is self.template_img:
             kw["defer_weights"] = int(self._fused["n_draw"])         # (see _solve_device)
         src_xy, dst_xy, w = self.flower.compute_flow(src, dst, mode="TC", vis=False, src_img_identifier=None,
@@ -313,12 +324,17 @@ class YAOFTrackerSingleControl:
         keep = ops.tc_flags(dst_xy if bounds else None, src_mask_u8, dst_valid_u8, frame_hw[0], frame_hw[1], bounds,
                             grid=grid)
         pick = lambda t: None if t is None else t[:, keep]
-        src_xy, dst_xy, w, post = pick(src_xy).float(), pick(dst_xy), pick(w), pick(post)
+        src_xy, dst_xy, w, post = pick(src_xy), pick(dst_xy), pick(w), pick(post)
+        if judge:
+            src_xy = src_xy.float()                                  # TRK:131 (global stage); the local stage hands the
+                                                                     # subsampler the int64 grid coordinates (TRK:186-193)
         if C.flow_numpy_out and not judge:                           # (the reference asks numpy of the local flow only)
             to_np = lambda t: None if t is None else t.cpu().numpy()
             src_xy, dst_xy, w, post = to_np(src_xy), to_np(dst_xy), to_np(w), to_np(post)
         if C.subsampler_fn:
             src_xy, dst_xy, w, post = C.subsampler_fn(src_xy, dst_xy, w, post)
+        if not judge:
+            src_xy = src_xy.float() if isinstance(src_xy, torch.Tensor) else src_xy.astype(np.float32)
         H = C.H_estimator(dst_xy.T[None], src_xy.T[None], w)
         H = H.float() if isinstance(H, torch.Tensor) else torch.as_tensor(np.asarray(H)).float()
         fit = _Fit(H=H.detach().cpu().numpy()[0].astype(np.float64), success=None)
