@@ -99,7 +99,8 @@ def cpu_baseline(sd, template, mask, frames_np, iters):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=200,
+                    help="timed track() calls (default 200: a ~2 s timed region; the extra passes use min(steps, 40))")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
@@ -123,6 +124,9 @@ def main():
                     help="reference-format tracker config under pytracking/configs: weighted LSq (the reference's "
                          "default, WOFT.py) or the IRLS estimator (BASELINE config 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ladder", action="store_true",
+                    help="skip the 'reference_work' (full weight head in bf16x3 and in exact fp32), 'lost_frame' and "
+                         "'steady_state' passes")
     ap.add_argument("--no-template-cache", action="store_true",
                     help="recompute the template's features every frame, as the reference does")
     args = ap.parse_args()
@@ -150,6 +154,7 @@ def main():
     from woft_amd import dist as wdist, ops, synth
     from pytracking.utils.config import load_config
     rank, world, local = wdist.init_distributed()
+    binding = wdist.bind_to_gpu_node(wdist.device_index(), local, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch {args.gpus} ranks "
                          f"(or run plain `python bench.py --gpus {args.gpus}`, which launches them itself)")
@@ -157,7 +162,7 @@ def main():
     assert H % 8 == 0 and W % 8 == 0
 
     sd = synth.make_state_dict(seed=7)
-    template, frames = make_sequence(H, W, rank, Wm + K)
+    template, frames = make_sequence(H, W, rank, CLIP)       # (every pass indexes frames[i % CLIP])
     mask = synth.make_init_mask(H, W)
 
     def make_tracker(precision, corr=None, mask_wh=None, graph=False):
@@ -202,6 +207,8 @@ def main():
     torch.cuda.synchronize()
     wdist.barrier()
     elapsed = time.perf_counter() - t0
+    per_rank = wdist.gather_floats([elapsed, binding.get("numa_node") if binding.get("numa_node") is not None else -1,
+                                    binding.get("cores") or 0, float(bool(binding.get("bound")))])
     elapsed = wdist.max_over_ranks(elapsed)
     events, wh_events, conv_events = plan.lookup_events, plan.wh_events, plan.conv_events
     plan.lookup_events = plan.wh_events = plan.conv_events = None
@@ -312,7 +319,11 @@ def main():
                    "weight_head": wh_desc,
                    "template_cache": not args.no_template_cache, "weights": "synthetic seed 7 (reference key set)",
                    "frames_resident_in_hbm": True},
-        "lost_frames": n_lost, "hbm_allocated_peak_gb": peak_gb,
+        "lost_frames": n_lost, "hbm_allocated_peak_gb": peak_gb, "tracks_gathered": [int(tracks.shape[0]), int(tracks.shape[1])],
+        # one entry per rank (a straggler shows here; `value` uses the slowest rank): ms per step inside the same barriers,
+        # the NUMA node of the rank's GPU and the host cores its launch thread is pinned to (woft_amd.dist.bind_to_gpu_node)
+        "per_rank": [{"rank": r, "ms_per_step": 1000.0 * float(v[0]) / K, "gpu_numa_node": (int(v[1]) if v[1] >= 0 else None),
+                      "host_cores": int(v[2]), "bound": bool(v[3])} for r, v in enumerate(per_rank.tolist())],
     }
     layers = {e[2]: e[1] for e in plan.prog_iter if len(e) > 2 and e[2] in ROOF_TAGS}
     same = {(p_.halo, p_.tile_n, p_.taps_y, p_.taps_x) for p_ in layers.values()}
@@ -362,6 +373,8 @@ def main():
     gc.collect()
     torch.cuda.empty_cache()
 
+    K2 = min(K, 40)                        # steps of the extra passes that run "the full K" of a default-sized run
+
     def side_run(n_steps, check_tracks=False, **kw):
         """Another tracker on the same sequence with the same history; -> timing (+ track identity with the timed run)."""
         trk = make_tracker(kw.pop("precision", args.precision), **kw)
@@ -392,7 +405,7 @@ def main():
         for prec in ("fp32", "bf16x3", "bf16"):
             if prec == args.precision:
                 continue
-            r, trk, pl, _ = side_run(K if prec == "fp32" else min(K, 8), precision=prec)
+            r, trk, pl, _ = side_run(K2 if prec == "fp32" else min(K, 8), precision=prec)
             _, dst, _ = trk.flower.compute_flow(template, frames[0], mode="TC", do_sigmoid=True)
             tc_gpu[prec] = dst.cpu()
             r["correlation"] = trk.flower.engine.corr
@@ -426,7 +439,7 @@ def main():
             drop()
     if world == 1 and not args.no_alt_corr:
         # the weight head on every pixel (or, with --full-weight-head, on the mask region): full K steps, same tracks
-        r, trk, pl, _ = side_run(K, check_tracks=True, mask_wh=not mask_region)
+        r, trk, pl, _ = side_run(K2, check_tracks=True, mask_wh=not mask_region)
         out["alt_weight_head"] = {("full" if mask_region else "mask_region"): r}
         del trk, pl
         drop()
@@ -437,6 +450,78 @@ def main():
         out["alt_graph"] = r
         del trk, pl
         drop()
+    if world == 1 and not args.no_ladder:
+        # ---- like-for-like ladder: the flow operator doing the reference's FULL work (weight head on every pixel, as
+        # WeightedRAFT.forward evaluates it) in the fp32-emulating arithmetic of the headline and in the reference's own
+        # arithmetic class (exact fp32 MFMA products, all-pairs volume); same sequence, same step count each
+        ladder = {}
+        for name, kw in (("bf16x3_full_weight_head", dict(precision="bf16x3", mask_wh=False)),
+                         ("fp32_full_weight_head", dict(precision="fp32", mask_wh=False))):
+            r, trk, pl, _ = side_run(max(K2, 20), check_tracks=(kw["precision"] == args.precision), **kw)
+            r["correlation"] = trk.flower.engine.corr
+            ladder[name] = r
+            del trk, pl
+            drop()
+        ladder["note"] = ("headline = bf16x3 + weight head only under the drawn correspondences (tracker-level pruning, identical "
+                          "tracks); these two lines remove the pruning, the second also the split-bf16 arithmetic")
+        out["reference_work"] = ladder
+
+        # ---- lost frames (TRK:167-207): every 4th frame the re-detection verdict is overruled to 'lost', so the frame
+        # also runs the frame t-1 -> t flow (second buffer set: the template stays resident) and its fit.  Per-frame wall
+        # time, one host sync per frame: the lost frame, the frame right after it, and the other frames of the same pass
+        trk = make_tracker(args.precision)
+        every, seen = 4, {"i": 0}
+        inner = trk._global_stage
+
+        def overruled(frame, prewarp_H):
+            fit = inner(frame, prewarp_H)
+            seen["i"] += 1
+            if seen["i"] % every == 0:
+                fit.success = False
+            return fit
+        trk._global_stage = overruled
+        n_lf = max(K2, 24)
+        track_all(trk, 0, Wm)
+        seen["i"] = 0
+        torch.cuda.synchronize()
+        per_frame, metas = [], []
+        for i in range(Wm, Wm + n_lf):
+            if i > 0 and i % CLIP == 0:
+                restart_clip(trk)
+            t1 = time.perf_counter()
+            _, m_ = trk.track(frames[i % CLIP])
+            torch.cuda.synchronize()
+            per_frame.append(1000.0 * (time.perf_counter() - t1))
+            metas.append(bool(m_.lost))
+        lost_ms = [t for t, l in zip(per_frame, metas) if l]
+        after_ms = [t for j, (t, l) in enumerate(zip(per_frame, metas)) if not l and j > 0 and metas[j - 1]]
+        other_ms = [t for j, (t, l) in enumerate(zip(per_frame, metas)) if not l and not (j > 0 and metas[j - 1])]
+        med = lambda v: float(np.median(v)) if v else None
+        out["lost_frame"] = {"frames": n_lf, "lost_frames": int(sum(metas)), "forced_every": every,
+                             "lost_frame_ms": med(lost_ms), "frame_after_lost_ms": med(after_ms), "normal_frame_ms": med(other_ms),
+                             "lost_over_normal": (med(lost_ms) / med(other_ms)) if lost_ms and other_ms else None,
+                             "local_stage_weight_head": "deferred to the drawn correspondences" if getattr(trk, "_sparse_weights", False) else "full map",
+                             "note": "wall ms per track() with a device sync after every frame (so each is a little above the "
+                                     "pipelined ms_per_step of the headline)"}
+        del trk
+        drop()
+        if K < 200:
+            # ---- the driver times --steps frames (0.2 s at 20 steps); the same configuration over >= 2 s, in chunks of 20
+            trk = make_tracker(args.precision)
+            track_all(trk, 0, Wm)
+            torch.cuda.synchronize()
+            chunks, t_all = [], time.perf_counter()
+            for c in range(10):
+                t1 = time.perf_counter()
+                track_all(trk, Wm + 20 * c, 20)
+                torch.cuda.synchronize()
+                chunks.append(20.0 / (time.perf_counter() - t1))
+            dt = time.perf_counter() - t_all
+            out["steady_state"] = {"steps": 200, "frames_per_s": 200.0 / dt, "ms_per_step": 1000.0 * dt / 200,
+                                   "frames_per_s_by_chunk_of_20": {"min": float(np.min(chunks)), "median": float(np.median(chunks)),
+                                                                  "max": float(np.max(chunks))}}
+            del trk
+            drop()
     if world == 1 and not args.no_cpu_baseline:
         torch.set_num_threads(usable_cores())
         n_cpu = 3

@@ -1,0 +1,58 @@
+"""bench.py's N > 1 path end to end on the 1-GPU test box: `python bench.py --gpus 8` launches 8 ranks itself
+(torch.distributed.run on 127.0.0.1); with fewer than 8 devices the ranks share device 0 and gather over gloo
+(WOFT_SINGLE_DEVICE) -- launch line, rendezvous, per-rank sequences, barrier + max-over-ranks timing, the all_gather of the
+tracks and the JSON contract are the 8-GPU run's, only the transport (RCCL over xGMI) differs."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _run(extra, timeout=1200):
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--no-cpu-baseline", "--no-ladder", "--no-alt-precisions", "--no-alt-corr",
+           *extra]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.lstrip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]                 # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_bench_eight_ranks_dry_run():
+    d = _run(["--gpus", "8", "--steps", "2", "--warmup", "1", "--height", "256", "--width", "320"])
+    assert d["n_gpus"] == 8 and d["steps"] == 2 and d["scaling"] == "weak" and d["config"]["sequences"] == 8
+    assert d["tracks_gathered"] == [8, 2]                      # every rank's track reached rank 0
+    assert len(d["per_rank"]) == 8 and [r["rank"] for r in d["per_rank"]] == list(range(8))
+    assert all(r["ms_per_step"] > 0 and r["host_cores"] >= 1 for r in d["per_rank"])
+    slowest = max(r["ms_per_step"] for r in d["per_rank"])
+    assert d["ms_per_step"] >= slowest * 0.999                 # value = all ranks' frames / the slowest rank's time
+    assert abs(d["value"] - 8 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
+    assert "roofline" in d and d["metric"].startswith("tracked frames/sec")
+
+
+def test_bench_line_carries_ladder_and_lost_frames():
+    """Small-size run of the default bench line's extra passes: the like-for-like ladder, the lost-frame pass (forced every
+    4th frame; the local flow runs in the second buffer set, so the frame after it costs what a normal frame costs) and the
+    >= 200-step steady-state figure."""
+    env = dict(os.environ)
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--no-cpu-baseline", "--no-alt-precisions", "--no-alt-corr",
+           "--steps", "8", "--warmup", "2", "--height", "384", "--width", "512"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.lstrip().startswith("{")][-1])
+    lad = d["reference_work"]
+    assert lad["bf16x3_full_weight_head"]["tracks_identical_to_timed_run"] is True
+    assert lad["fp32_full_weight_head"]["correlation"] == "volume" and lad["fp32_full_weight_head"]["steps"] >= 20
+    lf = d["lost_frame"]
+    assert lf["lost_frames"] == lf["frames"] // lf["forced_every"] > 0
+    assert lf["lost_frame_ms"] > lf["normal_frame_ms"] > 0 and lf["frame_after_lost_ms"] > 0
+    assert d["steady_state"]["steps"] == 200 and d["steady_state"]["frames_per_s"] > 0
+    assert len(d["per_rank"]) == 1

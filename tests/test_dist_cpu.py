@@ -35,6 +35,10 @@ def _worker(rank, world, port, q):
     wd.barrier()
     tracks = wd.gather_tracks(results, device="cpu")
     slow = wd.max_over_ranks(0.5 + rank, device="cpu")
+    per_rank = wd.gather_floats([10.0 * rank, rank + 0.25], device="cpu")
+    assert per_rank.tolist() == [[0.0, 0.25], [10.0, 1.25]]
+    info = wd.bind_to_gpu_node(0, rank, world)        # no GPU here: reports why it did not bind, never raises
+    assert info["bound"] is False and info["cores"] >= 1
     q.put((rank, tracks.numpy(), slow))
     torch.distributed.destroy_process_group()
 
@@ -70,3 +74,5 @@ def test_single_process_passthrough():
     res = [(np.eye(3), SimpleNamespace(lost=False, N_lost=0, global_H_success=True))]
     t = wd.gather_tracks(res)
     assert tuple(t.shape) == (1, 1, 12) and wd.max_over_ranks(2.0) == 2.0
+    assert wd.gather_floats([1.5, 2]).tolist() == [[1.5, 2.0]]
+    assert wd._cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]

@@ -301,6 +301,62 @@ def test_weight_head_on_the_drawn_correspondences_only(cfg):
     assert not trk._sparse_weights
 
 
+def test_lost_frames_keep_the_template_resident_and_defer_the_local_weights():
+    """The lost branch (TRK:167-207) runs the frame t-1 -> t flow in a SECOND buffer set, so the template's feature /
+    context / gate-bias tensors stay resident (the reference alternates template and frame t-1 as sources, TRK:101,181) and
+    the frame after a lost one costs what any frame costs; its weight head, like the global stage's, is evaluated only under
+    the correspondences the fit draws (which start inside the carried mask, TRK:314-327; the draw does not depend on the
+    weights).  Identical homographies with and without the deferral, frame for frame; the template is encoded once."""
+    from pytracking.utils.config import load_config
+    H, W, iters = 544, 960, 3
+    sd = synth.make_state_dict(seed=5)
+    template = synth.make_template(H, W, seq_id=3)
+    frames = [synth.make_frame(template, t) for t in (1, 2, 3, 4, 5)]
+    mask = np.zeros((H, W), np.uint8)
+    mask[100:400, 200:800] = 255
+    lost_at = {1, 2, 4}
+    outs = {}
+    for sparse in (False, True):
+        conf = load_config(ROOT / "pytracking" / "configs" / "WOFT.py")
+        conf.flow_config.model, conf.flow_config.iters, conf.flow_config.precision = sd, iters, "bf16x3"
+        conf.sparse_weight_head = sparse
+        trk = conf.tracker_class(conf)
+        trk.init(template, mask)
+        trk.flower.defer_min_ratio = 0
+        inner, k = trk._global_stage, {"i": -1}
+
+        def overruled(frame, prewarp_H, inner=inner, k=k):
+            fit = inner(frame, prewarp_H)
+            k["i"] += 1
+            if k["i"] in lost_at:
+                fit.success = False
+            return fit
+        trk._global_stage = overruled
+        plan0 = trk.flower.engine.plan(H, W)
+        encodes = {"n": 0}
+        enc0 = plan0.encode_source
+
+        def counted(enc0=enc0, encodes=encodes):
+            encodes["n"] += 1
+            return enc0()
+        plan0.encode_source = counted
+        res, deferred_local = [], []
+        for t, f in enumerate(frames):
+            Hm, meta = trk.track(f)
+            res.append((Hm, meta.lost, meta.N_lost, getattr(meta, "H_local_cur2init", None)))
+            if meta.lost:
+                deferred_local.append(trk.flower.weights_deferred)       # (the frame's last flow was frame t-1 -> t)
+        assert [r[1] for r in res] == [t in lost_at for t in range(5)]
+        assert encodes["n"] == 1 and plan0.source_tag is trk.flower        # template encoded once, never evicted
+        plan1 = trk.flower.engine.plan(H, W, 1)
+        assert plan1 is not plan0 and plan1.source_tag is None
+        assert deferred_local == [sparse] * 3
+        outs[sparse] = res
+    for a, b in zip(outs[False], outs[True]):
+        assert np.array_equal(a[0], b[0]) and a[1:3] == b[1:3]
+        assert (a[3] is None) == (b[3] is None) and (a[3] is None or np.array_equal(a[3], b[3]))
+
+
 @pytest.mark.parametrize("name,cfg", [("woft", "WOFT.py"), ("lost", "WOFT.py"), ("irls", "WOFT_IRLS.py")])
 @pytest.mark.parametrize("backend", ["device", "callables"])
 def test_tracker_vs_reference_tracker_runs(golden_dir, monkeypatch, name, cfg, backend):

@@ -13,7 +13,7 @@ python bench.py --height 720 --width 1280 --tracker-config WOFT_IRLS --no-cpu-ba
 python bench.py --iters 32 --precision bf16 --no-cpu-baseline --no-alt-precisions > $out/${tag}_bench_1080p_it32_bf16.json 2>/dev/null
 python bench.py --iters 32 --no-cpu-baseline --no-alt-precisions > $out/${tag}_bench_1080p_it32_bf16x3.json 2>/dev/null
 python bench.py --height 2160 --width 3840 --steps 10 --no-cpu-baseline --no-alt-precisions > $out/${tag}_bench_4k.json 2>/dev/null
-python bench.py --height 480 --width 640 --no-cpu-baseline --no-alt-precisions --no-alt-corr > $out/${tag}_bench_480p.json 2>/dev/null
+python bench.py --height 480 --width 640 --no-cpu-baseline --no-ladder --no-alt-precisions --no-alt-corr > $out/${tag}_bench_480p.json 2>/dev/null
 python tools/bench_hfit.py > $out/${tag}_hfit_fullframe.txt 2>/dev/null
 { python tools/bench_lookup.py; python tools/bench_lookup.py --tw 8; python tools/bench_lookup.py --storage bf16; python tools/bench_lookup.py --storage bf16 --tw 8;
   for abl in 1 2 3; do LOOKUP_ABL=$abl python tools/bench_lookup.py; done; } 2>/dev/null | grep lookup > $out/${tag}_lookup_isolated.txt
@@ -31,7 +31,7 @@ tools/lookup_pmc.sh $tag > /dev/null 2>&1
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pmc_busy
 (cd $root && rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_busy -o p -- \
-    python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-alt-precisions --no-alt-corr) > /tmp/pmc_busy.log 2>&1
+    python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-ladder --no-alt-precisions --no-alt-corr) > /tmp/pmc_busy.log 2>&1
 f=$(find /tmp/pmc_busy -name '*counter_collection.csv' | head -1)
 [ -n "$f" ] && python $root/tools/mfma_busy.py "$f" bf16x3 > $out/${tag}_pmc_mfma_util_conv.csv
 ls -la $out | grep ${tag}_

@@ -8,7 +8,7 @@ tag=${1:-r02}
 root=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p $root/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-cmd="python $root/bench.py --corr volume --steps 2 --warmup 1 --no-alt-precisions --no-alt-corr --no-cpu-baseline"
+cmd="python $root/bench.py --corr volume --steps 2 --warmup 1 --no-alt-precisions --no-alt-corr --no-cpu-baseline --no-ladder"
 for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/lpmc_$c
     (cd $root && rocprofv3 --pmc $c --output-format csv -d /tmp/lpmc_$c -o p -- $cmd) > /tmp/lpmc_$c.log 2>&1

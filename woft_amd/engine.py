@@ -178,8 +178,11 @@ class RaftEngine:
             self.wh6_b = float(sd[w + "6.bias"].item())
         self._plans = {}
 
-    def plan(self, hp, wp):
-        key = (hp, wp)
+    def plan(self, hp, wp, slot=0):
+        """Buffers + launch programs for one padded input size.  slot: an independent second set for the same size (the
+        flow provider keeps a pinned source image -- the tracker's template -- resident in slot 0 and runs flows from other
+        sources, the tracker's frame t-1 -> t flow of a lost frame, in slot 1: 5 GB more at 1080p, of 288)."""
+        key = (hp, wp) if slot == 0 else (hp, wp, slot)
         if key not in self._plans:
             self._plans[key] = _Plan(self, hp, wp)
         return self._plans[key]

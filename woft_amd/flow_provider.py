@@ -84,7 +84,7 @@ class RAFTWrapper:
         self.use_graph = (os.environ.get("WOFT_GRAPH") or str(int(bool(getattr(self.C, "graph", False))))) == "1"
         self._pinned = None
         self._pinned_key = None
-        self._wmask, self._wregion = None, {}
+        self._wmask, self._wregion, self._all_pixels = None, {}, {}
         self.weights_deferred, self._deferred = False, None
         self.defer_min_ratio = 6           # defer_weights: region windows per named pixel from which deferring pays
         self._out = {}
@@ -249,7 +249,10 @@ class RAFTWrapper:
                     logger.warning(f"no cached flow: {ex}")
         H, W = src_img.shape[:2]
         hp, wp, top, left, oh, ow, lh, lw = _pad_geometry(H, W, self.C.padding_mode)
-        plan = self.engine.plan(hp, wp)
+        # a flow from another source leaves the pinned source's tensors (fmap1, net, inp, gate biases) where they are:
+        # it runs in a second buffer set (the reference's lost branch, TRK:181-184, alternates template and frame t-1)
+        pinned_here = src_img is self._pinned
+        plan = self.engine.plan(hp, wp, 0 if (pinned_here or self._pinned is None) else 1)
         start_time = timer()
 
         def up(a):
@@ -264,17 +267,27 @@ class RAFTWrapper:
             return t.contiguous()
 
         key = (hp, wp, top, left)
-        if src_img is self._pinned and self._pinned_key == key and plan.source_tag is self:
+        if pinned_here and self._pinned_key == key and plan.source_tag is self:
             pass                                           # fmap1 / net / inp still resident in the plan
         else:
             s = up(src_img)
             plan.load_image(0, s, top, left)
             plan.encode_source()
-            plan.source_tag = self if src_img is self._pinned else None
-            self._pinned_key = key if src_img is self._pinned else None
+            plan.source_tag = self if pinned_here else None
+            if pinned_here:
+                self._pinned_key = key
         post = self.C.weights_postprocessing_fn or None     # (a map -> map callable may read any pixel: full map)
-        plan.set_weight_region(self._weight_region(key, hp, wp, top, left, oh, ow)
-                               if (weight_region and src_img is self._pinned and not post) else None)
+        region = None
+        if weight_region and not post:
+            if pinned_here:
+                region = self._weight_region(key, hp, wp, top, left, oh, ow)
+            if region is None and defer_weights:
+                # no pinned region (another source, or no mask declared), but the caller will name the pixels whose weights
+                # it reads (defer_weights): the window list is every source pixel, thinned on the device in finish_weights()
+                if plan.P not in self._all_pixels:
+                    self._all_pixels[plan.P] = torch.arange(plan.P, dtype=torch.int32, device="cuda")
+                region = self._all_pixels[plan.P]
+        plan.set_weight_region(region)
         d = up(dst_img)
         plan.load_image(1, d, top, left)
         o = self._outputs(oh, ow)

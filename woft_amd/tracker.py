@@ -240,8 +240,10 @@ class YAOFTrackerSingleControl:
         # (borrowed buffers, and -- only for THIS caller -- weights restricted to the region pinned in init(): a direct
         #  compute_flow() call by anybody else returns the full weight map, as the reference's does)
         kw = {"borrow": True, "weight_region": True} if hasattr(self.flower, "pin_source") else {}
-        if self._sparse_weights and src is self.template_img:
-            kw["defer_weights"] = int(self._fused["n_draw"])         # (see _solve_device)
+        if self._sparse_weights:
+            # both stages: the template flow on its mask region, the frame t-1 -> t flow of a lost frame on the pixels of
+            # the carried mask (TRK:314-327) -- either way only the drawn correspondences' weights are read (_solve_device)
+            kw["defer_weights"] = int(self._fused["n_draw"])
         src_xy, dst_xy, w = self.flower.compute_flow(src, dst, mode="TC", vis=False, src_img_identifier=None,
                                                      do_sigmoid=True, **kw)
         s = getattr(self.flower, "last_flow_shape", None)
