@@ -363,6 +363,84 @@ def gen_tracker():
     np.savez_compressed(GOLD / "tracker_ref_runs.npz", **out)
 
 
+def demo_frame(i):
+    """Frame i (1-based) of the reference's demo sequence demo/V24_7 (1280 x 720 JPEG), decoded with PIL -> BGR uint8
+    (cv2.imread's channel order; the decoder differs from OpenCV's libjpeg build by at most a grey level, which is why
+    the DECODED frames are stored in the fixture)."""
+    from PIL import Image
+    rgb = np.asarray(Image.open(REF / "demo" / "V24_7" / f"{i:08d}.jpg").convert("RGB"))
+    return np.ascontiguousarray(rgb[:, :, ::-1])
+
+
+@torch.no_grad()
+def gen_real():
+    """BASELINE config 2 at its real size on REAL frames: the reference's flow network on a 720 x 1280 pair of the demo
+    sequence (12 iterations), and the reference's own tracker (config ablation_08.py = IRLS; functional cv2 stub) over
+    three of its frames.  Stored: the decoded uint8 frames, the 1/8-resolution outputs in full, the full-resolution flow
+    and weight logits on a stride-4 lattice (+ their per-row means in full: a checksum of what the lattice skips)."""
+    import tempfile
+    from raft_core.weighted_raft import WeightedRAFT
+    from pytracking.utils.config import load_config
+    sd = synth.make_state_dict(seed=7, small=False, weighted=True)
+    net = WeightedRAFT(ref_args(False)).eval()
+    net.load_state_dict(sd, strict=True)
+    f1, f2, f3 = demo_frame(1), demo_frame(4), demo_frame(7)
+    out = dict(frame1=f1, frame2=f2, frame3=f3, seed=7, iters=12, stride=4)
+    flow_low, flow_up, _, w_low, w_up = net(to_t(f1), to_t(f3), iters=12, test_mode=True)
+    out.update(flow_low=flow_low.numpy(), w_low=w_low.numpy(),
+               flow_up_s4=flow_up[..., ::4, ::4].contiguous().numpy(), w_up_s4=w_up[..., ::4, ::4].contiguous().numpy(),
+               flow_up_rowmean=flow_up.double().mean(-1).numpy(), w_up_rowmean=w_up.double().mean(-1).numpy())
+    install_functional_cv2()
+    mask = np.zeros(f1.shape[:2], np.uint8)
+    mask[180:560, 360:960] = 255
+    with tempfile.TemporaryDirectory() as td:
+        model = os.path.join(td, "sd.pth")
+        torch.save(sd, model)
+        conf = load_config(REF / "pytracking/configs/ablation_08.py")
+        conf.flow_config.model, conf.flow_config.iters = model, 12
+        est = conf.H_estimator
+        conf.H_estimator = lambda a, b, w: torch.Tensor(est(a.as_subclass(FakeCuda), b, w))
+        trk = conf.tracker_class(conf)
+        trk.init(f1, mask)
+        Hs, meta = [], []
+        for f in (f2, f3):
+            Hc, m = trk.track(f)
+            Hs.append(np.asarray(Hc, np.float64))
+            meta.append([float(bool(m.lost)), float(m.N_lost), float(bool(m.global_H_success))])
+    out.update(mask=mask, track_H=np.stack(Hs), track_meta=np.asarray(meta))
+    np.savez_compressed(GOLD / "real_720p.npz", **out)
+
+
+@torch.no_grad()
+def gen_degenerate():
+    """Inputs on which a normalisation or a division degenerates (extractor.py:28-32 InstanceNorm with zero variance;
+    saturated regions; identical frames = zero flow), through the reference's network: 128 x 160, 4 iterations."""
+    from raft_core.weighted_raft import WeightedRAFT
+    sd = synth.make_state_dict(seed=7, small=False, weighted=True)
+    net = WeightedRAFT(ref_args(False)).eval()
+    net.load_state_dict(sd, strict=True)
+    H, W = 128, 160
+    a, b = pair(H, W, seed=21)
+    const = np.full((H, W, 3), 117, np.uint8)
+    sat = a.copy()
+    sat[:, :W // 2] = 255                                 # half the frame saturated, a black bar, texture elsewhere
+    sat[40:60] = 0
+    sat2 = b.copy()
+    sat2[:, :W // 2] = 255
+    sat2[43:63] = 0
+    cases = {"constant": (const, const.copy()), "constant_vs_texture": (const, b), "saturated": (sat, sat2),
+             "identical": (a, a.copy())}
+    out = dict(seed=7, iters=4)
+    for name, (x, y) in cases.items():
+        flow_low, flow_up, _, w_low, w_up = net(to_t(x), to_t(y), iters=4, test_mode=True)
+        out[f"{name}_img1"], out[f"{name}_img2"] = x, y
+        out[f"{name}_flow_up"], out[f"{name}_w_up"] = flow_up.numpy(), w_up.numpy()
+        out[f"{name}_flow_low"], out[f"{name}_w_low"] = flow_low.numpy(), w_low.numpy()
+        print(name, "flow |max|", float(flow_up.abs().max()), "finite", bool(torch.isfinite(flow_up).all()),
+              "w range", float(w_up.min()), float(w_up.max()))
+    np.savez_compressed(GOLD / "degenerate_128x160_it4.npz", **out)
+
+
 def main():
     GOLD.mkdir(parents=True, exist_ok=True)
     install_stubs()
@@ -376,6 +454,10 @@ def main():
         gen_hfit()
     if only in (None, "tracker"):
         gen_tracker()
+    if only in (None, "degenerate"):
+        gen_degenerate()
+    if only in (None, "real"):
+        gen_real()
     for p in sorted(GOLD.iterdir()):
         print(f"{p.name:40s} {p.stat().st_size/1024:9.1f} KB")
 

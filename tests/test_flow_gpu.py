@@ -374,3 +374,50 @@ def test_graph_replay_matches_eager(precision, small):
         assert np.array_equal(d0, d1)
         if w0 is not None:
             assert np.array_equal(w0, w1)
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("precision,epe_mean,epe_max,wtol", [("fp32", 1e-3, 1e-2, 2e-4), ("bf16x3", 1e-3, 1e-2, 2e-4),
+                                                               ("bf16", 5e-2, 0.5, 1e-2)])
+@pytest.mark.parametrize("name", ["constant", "constant_vs_texture", "saturated", "identical"])
+def test_degenerate_inputs_vs_reference(golden_dir, name, precision, epe_mean, epe_max, wtol):
+    """Constant image (InstanceNorm variance 0, extractor.py:28-32: rstd = 1/sqrt(eps) = 316 on a channel that holds
+    nothing but rounding noise), half-saturated frames with a black bar, identical frames -- against the REFERENCE's own
+    outputs on these inputs (tests/golden/degenerate_128x160_it4.npz), in all three arithmetic modes."""
+    g = np.load(golden_dir / "degenerate_128x160_it4.npz")
+    sd = synth.make_state_dict(seed=int(g["seed"]))
+    fc = _flow_config(sd, int(g["iters"]), precision=precision)
+    flower = fc.of_class(fc)
+    flow, w = flower.compute_flow(g[f"{name}_img1"], g[f"{name}_img2"], mode="flow", do_sigmoid=False)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(flow).all()) and bool(torch.isfinite(w).all())
+    m, mx = _epe(flow, torch.from_numpy(g[f"{name}_flow_up"])[0])
+    dw = float((w.cpu() - torch.from_numpy(g[f"{name}_w_up"])[0]).abs().max())
+    print(f"{name} / {precision}: EPE mean {m:.2e} max {mx:.2e}, weight logits {dw:.2e}")
+    assert m < epe_mean and mx < epe_max, (m, mx)
+    assert dw < wtol
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("precision,corr,epe_mean,epe_max,wtol", [("bf16x3", "otf", 1e-3, 1e-2, 3e-4), ("fp32", "volume", 1e-3, 1e-2, 3e-4),
+                                                                    ("bf16", "otf", 5e-2, 0.5, 1e-2)])
+def test_real_frames_720p_vs_reference(golden_dir, precision, corr, epe_mean, epe_max, wtol):
+    """BASELINE config 2 at its REAL size on REAL frames: a 720 x 1280 pair of the reference's demo sequence (decoded
+    frames stored in tests/golden/real_720p.npz), 12 iterations, against the reference's flow and weight logits -- 1/8
+    resolution in full, full resolution on the stored stride-4 lattice and through the per-row means."""
+    g = np.load(golden_dir / "real_720p.npz")
+    sd = synth.make_state_dict(seed=int(g["seed"]))
+    fc = _flow_config(sd, int(g["iters"]), precision=precision)
+    fc.corr = corr
+    flower = fc.of_class(fc)
+    flow, w = flower.compute_flow(g["frame1"], g["frame3"], mode="flow", do_sigmoid=False)
+    torch.cuda.synchronize()
+    s = int(g["stride"])
+    assert tuple(flow.shape) == (2, 720, 1280)
+    m, mx = _epe(flow[:, ::s, ::s], torch.from_numpy(g["flow_up_s4"])[0])
+    dw = float((w[:, ::s, ::s].cpu() - torch.from_numpy(g["w_up_s4"])[0]).abs().max())
+    rm = float((flow.double().mean(-1).cpu() - torch.from_numpy(g["flow_up_rowmean"])[0]).abs().max())
+    print(f"720p real frames, {precision}/{corr}: EPE mean {m:.2e} max {mx:.2e}; row means {rm:.2e}; weight logits {dw:.2e} "
+          f"(mean |flow| {float(np.sqrt((g['flow_up_s4'] ** 2).sum(1)).mean()):.2f} px)")
+    assert m < epe_mean and mx < epe_max, (m, mx)
+    assert rm < epe_mean and dw < wtol

@@ -189,3 +189,35 @@ def test_tracker_state_machine_vs_reference_runs(golden_dir, name, estimator):
         assert hasattr(m, "H_local_cur2init") == bool(has_local)
         if has_local:
             assert _box_err(m.H_local_cur2init, g[f"{name}_Hlocal_{i}"], H, W) < 0.02
+
+
+DEGENERATE = ["constant", "constant_vs_texture", "saturated", "identical"]
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("name", DEGENERATE)
+def test_degenerate_inputs(golden_dir, name):
+    """Inputs on which InstanceNorm's variance is zero (extractor.py:28-32 on a constant image), large saturated regions,
+    identical frames: the oracle against the REFERENCE's outputs on them."""
+    g = np.load(golden_dir / "degenerate_128x160_it4.npz")
+    sd = synth.make_state_dict(seed=int(g["seed"]), small=False, weighted=True)
+    out = raft_ref.raft_forward(sd, _t(g[f"{name}_img1"]), _t(g[f"{name}_img2"]), int(g["iters"]))
+    m, mx = _epe(out["flow_up"], g[f"{name}_flow_up"])
+    assert m < 1e-4 and mx < 1e-3, (m, mx)
+    assert np.abs(out["weights_up"].numpy() - g[f"{name}_w_up"]).max() < 2e-4
+
+
+@torch.no_grad()
+def test_real_frames_720p(golden_dir):
+    """BASELINE config 2 at its real size on real frames (the reference's demo sequence): oracle flow vs the reference's."""
+    g = np.load(golden_dir / "real_720p.npz")
+    sd = synth.make_state_dict(seed=int(g["seed"]), small=False, weighted=True)
+    out = raft_ref.raft_forward(sd, _t(g["frame1"]), _t(g["frame3"]), int(g["iters"]))
+    s = int(g["stride"])
+    m, mx = _epe(out["flow_low"], g["flow_low"])
+    assert m < 1e-4 and mx < 2e-3, (m, mx)
+    m, mx = _epe(out["flow_up"][..., ::s, ::s], g["flow_up_s4"])
+    assert m < 1e-4 and mx < 2e-3, (m, mx)
+    assert np.abs(out["flow_up"].double().mean(-1).numpy() - g["flow_up_rowmean"]).max() < 1e-4
+    assert np.abs(out["weights_up"][..., ::s, ::s].numpy() - g["w_up_s4"]).max() < 3e-4
+    assert np.abs(out["weights_up"].double().mean(-1).numpy() - g["w_up_rowmean"]).max() < 1e-4

@@ -473,3 +473,28 @@ def test_operator_outputs_are_not_aliased():
     assert d3.data_ptr() == d4.data_ptr()
     with pytest.raises(TypeError):
         flower.compute_flow(a.astype(np.float32), b.astype(np.float32))
+
+
+@pytest.mark.parametrize("backend", ["device", "callables"])
+def test_tracker_on_real_720p_frames_vs_reference_tracker(golden_dir, monkeypatch, backend):
+    """BASELINE config 2 (720p sequence, RAFT full 12 iterations + IRLS homography) at its real size on real frames: the
+    HIP tracker with the IRLS config against the REFERENCE's own tracker (config ablation_08.py) on three frames of the
+    reference's demo sequence (tests/golden/real_720p.npz): box corners < 1 px, same lost flags.  Default arithmetic
+    (bf16x3, volume-free correlation, weight head under the drawn correspondences on the device back end)."""
+    from pytracking.utils.config import load_config
+    g = np.load(golden_dir / "real_720p.npz")
+    monkeypatch.setenv("WOFT_FUSED", "1" if backend == "device" else "0")
+    sd = synth.make_state_dict(seed=int(g["seed"]))
+    conf = load_config(ROOT / "pytracking" / "configs" / "WOFT_IRLS.py")
+    conf.flow_config.model, conf.flow_config.iters, conf.flow_config.precision = sd, int(g["iters"]), "bf16x3"
+    tracker = conf.tracker_class(conf)
+    assert (tracker._fused is not None) == (backend == "device")
+    tracker.init(g["frame1"], g["mask"])
+    H, W = g["mask"].shape
+    for i, f in enumerate((g["frame2"], g["frame3"])):
+        Hg, mg = tracker.track(f)
+        lost, n_lost, ok = g["track_meta"][i]
+        assert (mg.lost, mg.N_lost, bool(mg.global_H_success)) == (bool(lost), int(n_lost), bool(ok)), i
+        err = _corners_err(Hg, g["track_H"][i], H, W)
+        print(f"real 720p frame {i}: corners within {err:.3f} px of the reference tracker")
+        assert err < 1.0, (i, err)
