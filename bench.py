@@ -367,7 +367,8 @@ def main():
                 torch.cuda.synchronize()
                 res[name] = {"avg_launch_us": 1e3 * float(np.mean([s_.elapsed_time(e_) for s_, e_ in evs]))}
             plan.coords.copy_(saved)
-            res["in_timed_region_avg_launch_us"] = 1e3 * float(np.mean([s_.elapsed_time(e_) for s_, e_ in events])) if events else None
+            res["in_timed_region_avg_launch_us"] = (1e3 * float(np.mean([s_.elapsed_time(e_) for s_, e_ in events]))
+                                                    if events else None)
             out["lookup_otf_by_flow_field"] = res
     tracker = plan = None                 # (frees the main engine's buffers before the extra runs)
     gc.collect()

@@ -48,9 +48,17 @@ enum woft_epilogue {
                                    update.py:47-50 */
     WOFT_EPI_GRU_Q = 6,         /* out = (1-z)*h + z*tanh(y), h = e0, z = e1   update.py:50-51 */
     WOFT_EPI_CTX = 7,           /* n < split: tanh(y) else relu(y)   weighted_raft.py:217-219   */
-    WOFT_EPI_WH_MEAN = 8        /* halo 2 (9x9 patches), one N tile: out[image] = e1[0] + mean over the 81 pixels of
+    WOFT_EPI_WH_MEAN = 8,       /* halo 2 (9x9 patches), one N tile: out[image] = e1[0] + mean over the 81 pixels of
                                    <e0[0..cout), relu(y)> -- the weight head's last ReLU, 1x1 conv and patch mean
                                    (weighted_raft.py:341,378-383) without writing the activation               */
+    WOFT_EPI_FLOWHEAD = 9       /* halo 8 only.  FlowHead (update.py:10-17) conv2(relu(conv1(x))) with conv2 (3x3 -> 2
+                                   channels) folded into conv1's epilogue: instead of relu(y) the launch writes, per
+                                   pixel m, the 18 partial products s[tap * 2 + o] = <W2[o][:, tap], relu(y[m])> over
+                                   the channels of column tile t to out[(t * M + m) * ldo + 0..17] (ldo >= 20; t <
+                                   cout_pad / tile_n planes; M = n_img * ho * wo).  e0 = W2 as bf16 MFMA B fragments,
+                                   [cout / 32 bands][2 k halves][planes hi(, lo)][64 lanes][8], lane = 32 * (k half
+                                   of the half) + column j, columns j >= 18 zero.  woft_flow_head_gather finishes
+                                   the 3x3 sum.                                                                */
 };
 
 typedef struct woft_conv_params {
@@ -145,6 +153,14 @@ int woft_conv3x3_narrow(const float* in, int32_t cs, int32_t n_img, int32_t h, i
 int woft_flow_head_update(const float* in, int32_t cs, int32_t h, int32_t w, int32_t cin_pad, const float* wgt,
                           const float* bias, float* delta, int64_t ld_delta, float* coords1, float* flow4,
                           float* flow_cat, int32_t ld_cat, void* stream);
+/* Second half of the flow head when its first conv ran with WOFT_EPI_FLOWHEAD: delta[q][o] = bias2[o] + sum over the
+ * 3x3 taps (ky, kx) and the n_planes column-tile planes of part[(plane * h * w + q + (ky-1) * w + (kx-1)) * ld +
+ * (ky * 3 + kx) * 2 + o] (pixels outside the image contribute nothing: zero padding, update.py:14), in a fixed order;
+ * then, exactly as woft_flow_head_update: delta stored, coords1 += delta, flow = coords1 - grid written to flow4 /
+ * flow_cat (optional).  One image of h x w pixels. */
+int woft_flow_head_gather(const float* part, int32_t n_planes, int32_t ld, int32_t h, int32_t w, const float* bias2,
+                          float* delta, int64_t ld_delta, float* coords1, float* flow4, float* flow_cat, int32_t ld_cat,
+                          void* stream);
 /* x (n floats, n % 32 == 0) -> n/32 lines of 128 bytes, line = [bf16 hi of 32 values | bf16 lo of the same 32],
  * hi = bf16(x), lo = bf16(x - hi): the operand format of woft_corr_gemm_bf16 with terms = 3. */
 int woft_split_bf16_lines(const float* x, int64_t n, void* out, void* stream);

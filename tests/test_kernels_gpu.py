@@ -239,6 +239,51 @@ def test_flow_head_update_one_launch(ops, cin, h, w):
     assert bool((res[1][3][:, :6] == -5.0).all()) and bool((res[1][3][:, 8:] == -5.0).all())
 
 
+@pytest.mark.parametrize("precision,tol", [("bf16x3", 3e-5), ("bf16", 2e-2)])
+@pytest.mark.parametrize("cin,cmid,h,w", [(128, 256, 135, 240), (128, 256, 17, 25), (96, 128, 40, 64)])
+def test_flow_head_in_one_conv_launch(ops, cin, cmid, h, w, precision, tol):
+    """FlowHead (update.py:10-17) = conv2(relu(conv1(h))) with the 3x3 -> 2-channel conv2 folded into conv1's epilogue
+    (WOFT_EPI_FLOWHEAD: 18 partial products per pixel and column tile on the matrix cores) + woft_flow_head_gather (3x3
+    neighbour sum, bias, coords1 += delta, flow operands of the next iteration): against torch fp64 and against the
+    two-launch path (conv1 -> woft_flow_head_update); sizes with ragged 8x16 tiles, both tile widths, the small model's
+    channel counts."""
+    x = torch.tanh(_rand(1, cin, h, w, seed=70))
+    w1 = _rand(cmid, cin, 3, 3, seed=71, scale=1 / math.sqrt(cin * 9))
+    b1 = _rand(cmid, seed=72, scale=0.1)
+    w2 = _rand(2, cmid, 3, 3, seed=73, scale=1 / math.sqrt(cmid * 9))
+    b2 = _rand(2, seed=74, scale=0.1)
+    pc1, pc2 = ops.pack_conv(w1, b1), ops.pack_conv(w2, b2)
+    xa = ops.act_from_nchw(x, cs=(cin + 31) // 32 * 32)
+    frags = ops.pack_flowhead_frags(w2, 2 if precision == "bf16x3" else 1)
+    part = torch.full((4 * h * w, 20), float("nan"), device="cuda")
+    p = ops.flowhead_params(xa, pc1, part, frags, precision=precision)
+    assert p is not None and p.halo == 8
+    start = (_rand(h * w, 2, seed=75, scale=30.0) + 15.0).cuda()
+    coords = start.clone()
+    delta = ops.new_act(1, h, w, 2, cs=4, zero=True)
+    flow4 = torch.full((h * w, 4), -3.0, device="cuda")
+    cat = torch.full((h * w, 12), -5.0, device="cuda")
+    ops.run_conv(p)
+    ops.flow_head_gather(part, p._n_planes, h, w, pc2.bias[:2].contiguous(), delta, coords, flow4, cat[:, 6:], 12)
+    torch.cuda.synchronize()
+    ref = F.conv2d(F.relu(F.conv2d(x.double(), w1.double(), b1.double(), padding=1)), w2.double(), b2.double(), padding=1)
+    got = delta.t[:, :2].reshape(h, w, 2).permute(2, 0, 1)[None]
+    _close(got, ref.float(), tol, rtol=tol, what=f"fused flow head {precision}")
+    assert torch.equal(coords, start + delta.t[:, :2])
+    gx = (torch.arange(h * w, device="cuda") % w).float()
+    gy = torch.div(torch.arange(h * w, device="cuda"), w, rounding_mode="floor").float()
+    assert torch.equal(flow4[:, 0], coords[:, 0] - gx) and torch.equal(flow4[:, 1], coords[:, 1] - gy)
+    assert torch.equal(cat[:, 6:8], flow4[:, :2]) and bool((flow4[:, 2:] == 0).all())
+    assert bool((cat[:, :6] == -5.0).all()) and bool((cat[:, 8:] == -5.0).all())
+    # the two-launch path (conv1 with ReLU epilogue, then the exact-fp32 narrow conv): same delta up to the split-bf16
+    # rounding of the second conv's products
+    mid = ops.conv2d(xa, pc1, epi=1, precision=precision, c_out_stride=cmid)
+    d2 = ops.new_act(1, h, w, 2, cs=4, zero=True)
+    ops.flow_head_update(mid, pc2, d2, start.clone())
+    torch.cuda.synchronize()
+    _close(got, d2.t[:, :2].reshape(h, w, 2).permute(2, 0, 1)[None], tol, rtol=tol, what="fused vs two launches")
+
+
 @pytest.mark.parametrize("kh,kw", [(1, 5), (5, 1), (3, 3)])
 @pytest.mark.parametrize("precision,tol", [("fp32", 1.0), ("bf16x3", 4.0)])
 def test_conv_gru_epilogues(ops, kh, kw, precision, tol):

@@ -12,7 +12,7 @@ import torch  # noqa: F401  (must precede the CDLL so both share one HIP runtime
 
 LIB_PATH = Path(os.environ.get("WOFT_HIP_LIB") or Path(__file__).resolve().parent / "lib" / "libwoft_hip.so")  # (env: A/B of builds)
 
-EPI_LINEAR, EPI_RELU, EPI_SIGMOID, EPI_TANH, EPI_RELU_RES_RELU, EPI_GRU_ZR, EPI_GRU_Q, EPI_CTX, EPI_WH_MEAN = range(9)
+EPI_LINEAR, EPI_RELU, EPI_SIGMOID, EPI_TANH, EPI_RELU_RES_RELU, EPI_GRU_ZR, EPI_GRU_Q, EPI_CTX, EPI_WH_MEAN, EPI_FLOWHEAD = range(10)
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -62,6 +62,7 @@ _SIGS = {
     "woft_corr_lookup_otf": (i32, [C.POINTER(LookupOtfParams), vp]),
     "woft_conv3x3_narrow": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, i64, i32, vp]),
     "woft_flow_head_update": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, i64, vp, vp, vp, i32, vp]),
+    "woft_flow_head_gather": (i32, [vp, i32, i32, i32, i32, vp, vp, i64, vp, vp, vp, i32, vp]),
     "woft_corr_gemm_bf16": (i32, [vp, vp, i64, i64, i64, i64, i32, f32, vp, i64, i32, i32, vp]),
     "woft_inorm_finalize": (i32, [vp, vp, i32, i32, i32, i32, i64, f32, vp, vp, vp, vp]),
     "woft_inorm_ws_bytes": (i64, []),

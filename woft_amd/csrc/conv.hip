@@ -725,7 +725,7 @@ int launch_halo(const woft_conv_params& p, hipStream_t s) {
     const int64_t mt = (int64_t)p.n_img * tyn * txn;
     dim3 grid((unsigned)(mt * (p.cout_pad / BN)));
 #define HALO_LAUNCH(KY, KX, T, N) \
-    hipLaunchKernelGGL((conv_halo_bf16_kernel<TY, TX, KY, KX, BN, T, WM, STAGES, N>), grid, dim3(256), 0, s, p)
+    woft_launch(0, conv_halo_bf16_kernel<TY, TX, KY, KX, BN, T, WM, STAGES, N>, grid, dim3(256), 0, s, p)
 #define HALO_TAPS(T)                                                                            \
     if (p.wh0_lookup != nullptr) {        /* weight head, first two layers in one launch */      \
         if constexpr (TY == 9 && STAGES == 2)                                                    \
@@ -930,7 +930,7 @@ int launch_conv(const woft_conv_params& p, hipStream_t s) {
     const int64_t M = (int64_t)p.n_img * p.ho * p.wo;
     dim3 grid((unsigned)(ceil_div64(M, BM) * (p.cout_pad / BN)));       // 1-D: see woft::tile_of_block
     if (p.precision == 0) {
-        hipLaunchKernelGGL((conv_mfma_f32_kernel<BM, BN>), grid, dim3(256), 0, s, p);
+        woft_launch(0, conv_mfma_f32_kernel<BM, BN>, grid, dim3(256), 0, s, p);
         return woft_launch_status();
     }
     // split-bf16 kernels use 32-bit element offsets
@@ -938,9 +938,9 @@ int launch_conv(const woft_conv_params& p, hipStream_t s) {
     if ((int64_t)p.n_img * p.h * p.w * cs_max >= (1ll << 31)) return WOFT_EINVAL;
     if ((int64_t)p.taps_y * p.taps_x * p.cin_pad >= (1 << 20)) return WOFT_EINVAL;
     if (p.precision == 1)
-        hipLaunchKernelGGL((conv_mfma_bf16_kernel<BM, BN, 3>), grid, dim3(256), 0, s, p);
+        woft_launch(0, conv_mfma_bf16_kernel<BM, BN, 3>, grid, dim3(256), 0, s, p);
     else
-        hipLaunchKernelGGL((conv_mfma_bf16_kernel<BM, BN, 1>), grid, dim3(256), 0, s, p);
+        woft_launch(0, conv_mfma_bf16_kernel<BM, BN, 1>, grid, dim3(256), 0, s, p);
     return woft_launch_status();
 }
 
@@ -966,7 +966,10 @@ extern "C" int woft_conv2d(const woft_conv_params* pp, void* stream) {
         return WOFT_EINVAL;
     if ((p.tile_m != 64 && p.tile_m != 128) || (p.tile_n != 64 && p.tile_n != 128)) return WOFT_EINVAL;
     if (p.cout_pad % p.tile_n != 0 || p.cout > p.cout_pad) return WOFT_EINVAL;
-    if (p.epi < 0 || p.epi > WOFT_EPI_WH_MEAN) return WOFT_EINVAL;
+    if (p.epi < 0 || p.epi > WOFT_EPI_FLOWHEAD) return WOFT_EINVAL;
+    if (p.epi == WOFT_EPI_FLOWHEAD && (p.halo != 8 || p.precision == 0 || p.stat_sum != nullptr || p.bias_map != nullptr ||
+                                       p.e0 == nullptr))
+        return WOFT_EINVAL;
     if (p.epi == WOFT_EPI_WH_MEAN && (p.halo != 2 || p.cout_pad != p.tile_n || p.e0 == nullptr || p.e1 == nullptr ||
                                       p.stat_sum != nullptr))
         return WOFT_EINVAL;

@@ -134,7 +134,56 @@ __global__ __launch_bounds__(256) void conv3x3_narrow_kernel(const float* __rest
     }
 }
 
+// woft_flow_head_gather: one thread per pixel; 9 taps x n_planes 8-byte loads (both output channels of a tap)
+__global__ __launch_bounds__(256) void flow_head_gather_kernel(const float* __restrict__ part, int n_planes, int ld, int h, int w,
+                                                               const float* __restrict__ bias2, float* __restrict__ delta,
+                                                               int64_t ld_delta, float* __restrict__ coords1,
+                                                               float* __restrict__ flow4, float* __restrict__ flow_cat,
+                                                               int ld_cat) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= h * w) return;
+    const int y = i / w, x = i - y * w;
+    float dx = bias2 ? bias2[0] : 0.f, dy = bias2 ? bias2[1] : 0.f;
+    const int64_t plane = (int64_t)h * w * ld;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int yy = y + ky - 1, xx = x + kx - 1;
+            if (yy < 0 || yy >= h || xx < 0 || xx >= w) continue;
+            const float* src = part + ((int64_t)yy * w + xx) * ld + (ky * 3 + kx) * 2;
+            for (int t = 0; t < n_planes; ++t) {
+                const f32x2 v = *(const f32x2*)(src + t * plane);
+                dx += v[0];
+                dy += v[1];
+            }
+        }
+    delta[i * ld_delta] = dx;
+    delta[i * ld_delta + 1] = dy;
+    const float cx = coords1[i * 2] + dx, cy = coords1[i * 2 + 1] + dy;
+    coords1[i * 2] = cx;
+    coords1[i * 2 + 1] = cy;
+    const float fx = cx - (float)x, fy = cy - (float)y;
+    if (flow4 != nullptr) *(f32x4*)(flow4 + (int64_t)i * 4) = f32x4{fx, fy, 0.f, 0.f};
+    if (flow_cat != nullptr) {
+        flow_cat[(int64_t)i * ld_cat] = fx;
+        flow_cat[(int64_t)i * ld_cat + 1] = fy;
+    }
+}
+
 }  // namespace
+
+extern "C" int woft_flow_head_gather(const float* part, int32_t n_planes, int32_t ld, int32_t h, int32_t w, const float* bias2,
+                                     float* delta, int64_t ld_delta, float* coords1, float* flow4, float* flow_cat,
+                                     int32_t ld_cat, void* stream) {
+    if (!part || !delta || !coords1 || n_planes < 1 || ld < 18 || ld % 2 != 0 || h <= 0 || w <= 0 || ld_delta < 2 ||
+        (flow_cat != nullptr && ld_cat < 2) || (int64_t)h * w >= (1ll << 31))
+        return WOFT_EINVAL;
+    hipLaunchKernelGGL(flow_head_gather_kernel, dim3((unsigned)ceil_div64((int64_t)h * w, 256)), dim3(256), 0, (hipStream_t)stream,
+                       part, n_planes, ld, h, w, bias2, delta, ld_delta, coords1, flow4, flow_cat, ld_cat);
+    return woft_launch_status();
+}
 
 static int narrow_launch(const float* in, int32_t cs, int32_t n_img, int32_t h, int32_t w, int32_t cin_pad,
                          const float* wgt, const float* bias, int32_t cout, float* out, int64_t ldo, int32_t co_off,

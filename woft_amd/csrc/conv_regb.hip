@@ -219,6 +219,89 @@ __global__ __launch_bounds__(256, 2) void conv_regb_kernel(const woft_conv_param
     __syncthreads();                                     // halo buffers are dead: reuse them as epilogue staging
 
     const HaloRowMap<TY, TX> rowmap{img0, p.n_img, y0, x0, p.ho, p.wo};
+    if (p.epi == WOFT_EPI_FLOWHEAD) {
+        // Flow head, second conv folded into the first one's epilogue (update.py:10-17: conv2(relu(conv1(h))), 3 x 3, 2
+        // output channels).  A 3 x 3 conv is linear in its input pixels: delta[q] = b2 + sum_taps <W2[tap], y[q + tap]>, so
+        // this launch emits, per pixel p and tap, the 2 partial dot products s[p][tap][o] = <W2[o][:, tap], y[p]> over the
+        // channels this workgroup holds (18 values per pixel) and woft_flow_head_gather adds the 9 neighbours' shares --
+        // the 256-channel activation (33 MB at 1/8 of 1080p, the store tail of this launch and three reads of the next)
+        // is never written.  The partial products run on the matrix cores: relu(acc + bias) is transposed through the
+        // wave's LDS staging area into A fragments (lane = pixel row, k = its 32 channels), split into bf16 hi / lo as any
+        // other activation, and multiplied with the pre-split W2 fragments of the band (p.e0, [band][k half][plane][64][8],
+        // column j = tap * 2 + o, 18 of 32 used).  The 32-channel shares of the waves of one row group are totalled in a
+        // fixed order through LDS; the column tiles' shares land in separate planes of p.out ([n_tile][pixel][ldo]).
+        float* stage = (float*)smem + wave * TM * woft::STAGE_FLOATS;
+        const int ncol = n0 + wn * 32;
+        f32x4 bv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            bv[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (p.bias != nullptr) bv[q] = *(const f32x4*)(p.bias + ncol + (q >> 1) * 16 + 8 * hh + (q & 1) * 4);
+        }
+        const __bf16* wf = (const __bf16*)p.e0 + (int64_t)(ncol / 32) * (2 * NP * 512) + lane * 8;
+        bf16x8 w2[2][NP];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) w2[s2][pl] = *(const bf16x8*)(wf + (s2 * NP + pl) * 512);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                stage[i * woft::STAGE_FLOATS + ((r & 3) + 8 * (r >> 2) + 4 * hh) * woft::STAGE_LD + r32] = acc[i][r];
+        __builtin_amdgcn_wave_barrier();
+        f32x16 sacc[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const float* row = stage + i * woft::STAGE_FLOATS + r32 * woft::STAGE_LD + 8 * hh;
+            bf16x8 ah[2], al[2];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    f32x4 yv = *(const f32x4*)(row + 16 * s2 + 4 * q);
+                    const f32x4 b4 = bv[2 * s2 + q];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) yv[e] = fmaxf(p.alpha * yv[e] + b4[e], 0.f);
+                    const bf16x4 hi = __builtin_convertvector(yv, bf16x4);
+                    const bf16x4 lo = __builtin_convertvector(yv - __builtin_convertvector(hi, f32x4), bf16x4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { ah[s2][4 * q + e] = hi[e]; al[s2][4 * q + e] = lo[e]; }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[i][r] = 0.f;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                if (NP == 2) {
+                    sacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[s2], w2[s2][0], sacc[i], 0, 0, 0);
+                    sacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s2], w2[s2][NP - 1], sacc[i], 0, 0, 0);
+                }
+                sacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s2], w2[s2][0], sacc[i], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        constexpr int SLD = 20;                          // floats per pixel row of a share: 18 values + 2 (16-byte rows)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (r32 < SLD) stage[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh) * SLD + r32] = sacc[i][r];
+        __syncthreads();
+        const int64_t M = (int64_t)p.n_img * p.ho * p.wo;
+        float* dst = p.out + (int64_t)n_tile * M * p.ldo;
+        for (int idx = tid; idx < BM * (SLD / 4); idx += 256) {
+            const int row = idx / (SLD / 4), c4 = (idx - row * (SLD / 4)) * 4;
+            const int wmr = row / WROWS, lr = row - wmr * WROWS;
+            f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w_ = 0; w_ < WN; ++w_)
+                t += *(const f32x4*)((const float*)smem + (wmr * WN + w_) * TM * woft::STAGE_FLOATS + lr * SLD + c4);
+            const int64_t m = rowmap(row);
+            if (m >= 0) *(f32x4*)(dst + m * p.ldo + c4) = t;
+        }
+        return;
+    }
     f32x16 acc2[TM][1];
 #pragma unroll
     for (int i = 0; i < TM; ++i) acc2[i][0] = acc[i];
@@ -235,7 +318,7 @@ int launch_regb(const woft_conv_params& p, hipStream_t s) {
     const int64_t mt = (int64_t)p.n_img * tyn * txn;
     dim3 grid((unsigned)(mt * (p.cout_pad / BN)));
 #define REGB(KY, KX, T, NB, D) \
-    hipLaunchKernelGGL((conv_regb_kernel<TY, TX, KY, KX, WM, T, NB, D, 2>), grid, dim3(256), (size_t)g_regb_dyn_lds, s, p)
+    woft_launch(0, conv_regb_kernel<TY, TX, KY, KX, WM, T, NB, D, 2>, grid, dim3(256), (size_t)g_regb_dyn_lds, s, p)
 #define REGB_TAPS(T)                                                     \
     if (p.taps_y == 3 && p.taps_x == 3) REGB(3, 3, T, 3, 2);             \
     else if (p.taps_y == 1 && p.taps_x == 5) REGB(1, 5, T, 5, 3);        \
@@ -243,7 +326,7 @@ int launch_regb(const woft_conv_params& p, hipStream_t s) {
     else if (p.taps_y == 1 && p.taps_x == 1) {    /* 1x1: three chunks per unrolled group, input tile three chunks ahead; \
                                                      64-column tiles only (the 128-column layout does not fit 256 registers) */ \
         if constexpr (WM == 2 && TY == 8)                                                                                       \
-            hipLaunchKernelGGL((conv_regb_kernel<TY, TX, 1, 1, WM, T, 3, 2, 1, 3, 3>), grid, dim3(256), (size_t)g_regb_dyn_lds, s, p); \
+            woft_launch(0, conv_regb_kernel<TY, TX, 1, 1, WM, T, 3, 2, 1, 3, 3>, grid, dim3(256), (size_t)g_regb_dyn_lds, s, p); \
         else return WOFT_EINVAL;                                                                                                \
     } else return WOFT_EINVAL
     if (p.precision == 1) { REGB_TAPS(3); } else { REGB_TAPS(1); }
@@ -260,10 +343,11 @@ int launch_regb(const woft_conv_params& p, hipStream_t s) {
 int woft_conv_regb_launch(const woft_conv_params& p, void* stream) {
     if (p.halo == 12) {
         if (p.wgt_frag == nullptr || p.in_norm != 0 || (p.in_mean != nullptr && p.in_mean != (const float*)1) || p.wh0_lookup != nullptr ||
-            p.epi == WOFT_EPI_WH_MEAN || p.tile_n != 128 || p.cout_pad % 128 != 0 || p.taps_y * p.taps_x == 1) return WOFT_EINVAL;
+            p.epi == WOFT_EPI_WH_MEAN || p.epi == WOFT_EPI_FLOWHEAD || p.tile_n != 128 || p.cout_pad % 128 != 0 || p.taps_y * p.taps_x == 1) return WOFT_EINVAL;
         return launch_regb<1, 4>(p, (hipStream_t)stream);
     }
     if (p.wgt_frag == nullptr || p.in_norm != 0 || (p.in_mean != nullptr && p.in_mean != (const float*)1) || p.wh0_lookup != nullptr || p.epi == WOFT_EPI_WH_MEAN) return WOFT_EINVAL;
+    if (p.epi == WOFT_EPI_FLOWHEAD && (p.e0 == nullptr || p.ldo < 20 || p.ldo % 4 != 0 || p.co_off != 0 || p.cout % 32 != 0)) return WOFT_EINVAL;
     if (p.tile_n == 128 && p.cout_pad % 128 == 0) return launch_regb<1>(p, (hipStream_t)stream);
     if (p.tile_n == 64 && p.cout_pad % 64 == 0) return launch_regb<2>(p, (hipStream_t)stream);
     return WOFT_EINVAL;

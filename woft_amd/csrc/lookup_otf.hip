@@ -330,7 +330,7 @@ extern "C" int woft_corr_lookup_otf(const woft_lookup_otf_params* pp, void* stre
     // 20 % more steps per workgroup: measured 110 vs 98 us at 1080p in round 1, -1.7 % frames/s in round 2 with two steps
     // per barrier -- the per-workgroup chain of K steps binds.)
     dim3 grid((unsigned)(((p.wf + 7) / 8) * ((p.hf + 7) / 8)));
-#define OTF(T, RR, KK) hipLaunchKernelGGL((corr_lookup_otf_kernel<T, RR, KK, 8>), grid, dim3(256), 0, s, p)
+#define OTF(T, RR, KK) woft_launch(0, corr_lookup_otf_kernel<T, RR, KK, 8>, grid, dim3(256), 0, s, p)
     if (p.k == 256 && p.radius == 4) { if (p.terms == 3) OTF(3, 4, 256); else OTF(1, 4, 256); }       /* full model  */
     else if (p.k == 128 && p.radius == 3) { if (p.terms == 3) OTF(3, 3, 128); else OTF(1, 3, 128); }  /* small model */
     else return WOFT_EINVAL;

@@ -29,6 +29,9 @@ EPI = _lib
 # InstanceNorm encoders: conv1's output and the downsample branch stay raw for their consumers to normalise (0: materialised)
 DEFER_NORM = os.environ.get("WOFT_DEFER_NORM", "1") != "0"
 SIDE_STREAM = os.environ.get("WOFT_SIDE_STREAM", "0") != "0"
+# flow head: the 3x3 -> 2-channel conv folded into the first conv's epilogue + a per-pixel gather (0: two convs, the
+# second on the vector ALUs in exact fp32 -- woft_flow_head_update)
+FUSE_FLOWHEAD = os.environ.get("WOFT_FUSE_FLOWHEAD", "1") != "0"
 
 
 def _ru(x, m):
@@ -128,6 +131,9 @@ class RaftEngine:
         self.convm = g("encoder.conv")
         self.fh1 = g("flow_head.conv1")
         self.fh2 = g("flow_head.conv2")
+        # second conv of the flow head as MFMA fragments: folded into the first conv's epilogue (WOFT_EPI_FLOWHEAD)
+        self.fh2_frag = (ops.pack_flowhead_frags(sd[u + "flow_head.conv2.weight"], 2 if precision == "bf16x3" else 1)
+                         if precision != "fp32" and FUSE_FLOWHEAD else None)
         if small:
             self.zr = [ops.pack_conv(cat("gru.convz", "gru.convr", ".weight"), cat("gru.convz", "gru.convr", ".bias"))]
             self.q = [g("gru.convq")]
@@ -273,6 +279,7 @@ class _Plan:
         self.hA = new_act(1, hf, wf, sp.hdim, zero=True)
         self.hB = new_act(1, hf, wf, sp.hdim, zero=True)
         self.fh = new_act(1, hf, wf, 128 if sp.small else 256, zero=True)
+        self.fh_part = None        # flow head folded into one conv launch: per-pixel partial products of its second conv
         self.delta = new_act(1, hf, wf, 2, cs=4, zero=True)
         if self.otf:
             self.lookup = ops.make_lookup_otf_params(self.f1s, self.f2s, self.dims, hf, wf, sp.fdim, self.coords,
@@ -494,6 +501,14 @@ class _Plan:
                      ("conv", cp(self.rh, q, ho, x2=self.xbuf, c_split=hd, epi=EPI.EPI_GRU_Q, e0=hi, e1=self.zbuf))]
         if len(e.zr) == 1 and not first:
             prog.append(("copy", (self.hA.t, self.hB.t)))
+        fused = None
+        if e.fh2_frag is not None and e.fh2.cout == 2:
+            if self.fh_part is None:
+                self.fh_part = torch.zeros(4 * self.P, 20, dtype=torch.float32, device="cuda")
+            fused = ops.flowhead_params(self.hB, e.fh1, self.fh_part, e.fh2_frag, precision=self.prec)
+        if fused is not None:                            # conv1 with conv2's partial products in its epilogue + the gather
+            prog += [("conv", fused, "fh1"), ("fh_gather", (fused._n_planes, e.fh2.bias[:2].contiguous()))]
+            return prog
         prog.append(("conv", cp(self.hB, e.fh1, self.fh, epi=EPI.EPI_RELU), "fh1"))
         if ops.narrow_ok(self.fh, e.fh2):                # second conv + coords1 += delta in one launch
             prog.append(("fh_update", (self.fh, e.fh2, self.delta)))
@@ -543,6 +558,10 @@ class _Plan:
                 self._lookup(a)
             elif kind == "copy":
                 a[1].copy_(a[0])
+            elif kind == "fh_gather":
+                off = self.eng.spec.flow_off
+                ops.flow_head_gather(self.fh_part, a[0], self.hf, self.wf, a[1], self.delta, self.coords, self.flow4.t,
+                                     self.xbuf.t[:, off:], self.xbuf.cs)
             elif kind == "fh_update":
                 off = self.eng.spec.flow_off
                 ops.flow_head_update(a[0], a[1], a[2], self.coords, self.flow4.t, self.xbuf.t[:, off:], self.xbuf.cs)

@@ -326,6 +326,41 @@ def pack_wh0_frags(w0, planes):
     return torch.stack(pl, dim=2).contiguous().to(DEV)
 
 
+def pack_flowhead_frags(w2, planes):
+    """FlowHead.conv2 weight (2, C, 3, 3) (update.py:11) -> bf16 MFMA B fragments [C/32 bands][2 k halves][planes][64 lanes][8]
+    for WOFT_EPI_FLOWHEAD: lane = 32 * hh + j, column j = (3 ky + kx) * 2 + o (18 of 32 used), element e = channel
+    32 band + 16 (k half) + 8 hh + e."""
+    w2 = w2.detach().float().cpu()
+    c = w2.shape[1]
+    assert w2.shape[0] == 2 and tuple(w2.shape[2:]) == (3, 3) and c % 32 == 0
+    cols = torch.zeros(32, c)
+    cols[:18] = w2.permute(2, 3, 0, 1).reshape(18, c)                 # row j = (ky * 3 + kx) * 2 + o
+    f = cols.reshape(32, c // 32, 2, 2, 8).permute(1, 2, 3, 0, 4).reshape(c // 32, 2, 64, 8)   # band, k half, (hh, j), e
+    hi = f.to(torch.bfloat16)
+    pl = [hi] + ([(f - hi.float()).to(torch.bfloat16)] if planes == 2 else [])
+    return torch.stack(pl, dim=2).contiguous().to(DEV)
+
+
+def flowhead_params(x, pc, part, frags, **kw):
+    """conv_params for FlowHead.conv1 with the second conv folded into its epilogue (WOFT_EPI_FLOWHEAD), or None when the
+    layer does not run on the register-streamed kernel (halo 8) here.  part: (planes * n_pix, >= 20) fp32."""
+    p = conv_params(x, pc, Act(part, 1, x.h, x.w, 18), epi=_lib.EPI_FLOWHEAD, **kw)
+    if p.halo != 8 or pc.cout % 32 != 0:
+        return None
+    n_planes = p.cout_pad // p.tile_n
+    assert part.shape[0] >= n_planes * x.n_pix and part.shape[1] >= 20 and x.n == 1
+    p.e0, p.lde0 = ptr(frags), 0
+    p._keep = p._keep + (part, frags)
+    p._n_planes = n_planes
+    return p
+
+
+def flow_head_gather(part, n_planes, h, w, bias2, delta, coords, flow4=None, flow_cat=None, ld_cat=0):
+    check(_lib.load().woft_flow_head_gather(ptr(part), n_planes, part.shape[1], h, w, ptr(bias2), ptr(delta.t), delta.cs,
+                                            ptr(coords), ptr(flow4), ptr(flow_cat), ld_cat, stream_ptr()),
+          "woft_flow_head_gather")
+
+
 def run_conv(p):
     check(_lib.load().woft_conv2d(C.byref(p), stream_ptr()), "woft_conv2d")
 
