@@ -197,8 +197,11 @@ def main():
     torch.cuda.synchronize()
     # the kernel with the largest share of a frame (profiles/r02_bench_kernel_stats_bf16x3.csv): the 3x3 / 64-column
     # instance of the register-streamed-weights conv kernel = the motion encoder's three 3x3 layers (update.py:83,85,86)
-    ROOF_TAGS = ("convc2", "convf2", "convm")
-    plan.lookup_events, plan.wh_events, plan.conv_events = [], [], {t: [] for t in ROOF_TAGS}
+    ROOF_TAGS = ("convc2", "convf2", "convc2+convf2", "convm")
+    # (HIP events are stream-ordered barriers: the volume-free lookup, not this mode's roofline kernel, is timed in isolation
+    #  below -- 'lookup_otf_by_flow_field' -- instead of inside the timed region)
+    plan.lookup_events = [] if corr_mode == "volume" else None
+    plan.wh_events, plan.conv_events = [], {t: [] for t in ROOF_TAGS}
     wdist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -249,24 +252,24 @@ def main():
 
     def conv_roofline(evs_by_tag, layers):
         """The kernel symbol with the largest share of a frame: conv_regb_kernel<8,16,3,3, 2 x 2 waves> (64-column tiles),
-        i.e. the motion encoder's 3x3 convs on the 1/8-resolution map -- convc2 256->192, convf2 128->64, conv 256->126
-        (update.py:83,85,86,91-96), 36 launches per frame; matrix-core bound.  HIP events around ALL its launches in the timed
+        i.e. the motion encoder's 3x3 convs on the 1/8-resolution map -- convc2 256->192 and convf2 128->64 (independent
+        branches: ONE launch, woft_conv2d_pair) and conv 256->126 (update.py:83,85,86,91-96), 24 launches per frame;
+        matrix-core bound.  HIP events around ALL its launches in the timed
         region (on the stream the kernels are enqueued on): achieved = sum of the launches' 2*M*K*N / sum of their times, so
         that avg_launch_ms is comparable with the rocprofv3 average of the same symbol."""
         tot_ms, tot_fl, tot_issued, n_l, per = 0.0, 0.0, 0.0, 0, {}
-        for tag, p in layers.items():
+        for tag, ps in layers.items():                  # (a launch may hold two layers: woft_conv2d_pair)
             ms = [s.elapsed_time(e) for s, e in evs_by_tag.get(tag, [])]
             if not ms:
                 continue
-            k = p.taps_y * p.taps_x * p.cin_pad
-            fl = 2.0 * p._m * k * p.cout
+            fl = sum(2.0 * p._m * p.taps_y * p.taps_x * p.cin_pad * p.cout for p in ps)
             tot_ms += float(np.sum(ms))
             tot_fl += fl * len(ms)
-            tot_issued += 2.0 * (p._m_tiles * 128) * k * p.cout_pad * terms * len(ms)
+            tot_issued += sum(2.0 * (p._m_tiles * 128) * p.taps_y * p.taps_x * p.cin_pad * p.cout_pad for p in ps) * terms * len(ms)
             n_l += len(ms)
-            per[tag] = {"conv": f"3x3 {p.cin_pad}->{p.cout}", "avg_launch_us": 1e3 * float(np.mean(ms)),
-                        "algorithmic_flops_per_launch": fl}
-        p0 = next(iter(layers.values()))
+            per[tag] = {"conv": " + ".join(f"3x3 {p.cin_pad}->{p.cout}" for p in ps) + (" in one launch" if len(ps) > 1 else ""),
+                        "avg_launch_us": 1e3 * float(np.mean(ms)), "algorithmic_flops_per_launch": fl}
+        p0 = next(iter(layers.values()))[0]
         kern = {8: "conv_regb_kernel<8,16,3,3> (weights streamed global -> registers)", 1: "conv_halo_bf16_kernel<8,16,3,3>",
                 4: "conv_halo_bf16_kernel<4,16,3,3>", 0: "conv_mfma_f32_kernel"}.get(p0.halo, f"halo {p0.halo}")
         t = tot_ms * 1e-3
@@ -325,10 +328,10 @@ def main():
         "per_rank": [{"rank": r, "ms_per_step": 1000.0 * float(v[0]) / K, "gpu_numa_node": (int(v[1]) if v[1] >= 0 else None),
                       "host_cores": int(v[2]), "bound": bool(v[3])} for r, v in enumerate(per_rank.tolist())],
     }
-    layers = {e[2]: e[1] for e in plan.prog_iter if len(e) > 2 and e[2] in ROOF_TAGS}
-    same = {(p_.halo, p_.tile_n, p_.taps_y, p_.taps_x) for p_ in layers.values()}
+    layers = {e[2]: (list(e[1]) if e[0] == "conv2" else [e[1]]) for e in plan.prog_iter if len(e) > 2 and e[2] in ROOF_TAGS}
+    same = {(p_.halo, p_.tile_n, p_.taps_y, p_.taps_x) for ps_ in layers.values() for p_ in ps_}
     if len(same) > 1:                    # (another resolution / precision picked different kernels: keep the largest layer)
-        layers = {"convc2": layers["convc2"]}
+        layers = {k_: v_ for k_, v_ in layers.items() if k_.startswith("convc2")}
     have_conv = bool(layers) and any(conv_events.get(t) for t in layers)
     if corr_mode == "volume":
         # the lookup reads the volume: the named HBM-roofline kernel, measured live in the timed region

@@ -136,6 +136,13 @@ typedef struct woft_conv_params {
 } woft_conv_params;
 
 int woft_conv2d(const woft_conv_params* p, void* stream);
+/* Two INDEPENDENT layers in one launch: both must select the same kernel instance -- same precision (split-bf16 only),
+ * halo mode (0 = per-tap kernel, any tap shapes; 8 / 12 = register-streamed kernel, equal tap shape), tile_m / tile_n;
+ * no InstanceNorm statistics.  The first layer's workgroups are dispatched first.  Results are those of two woft_conv2d
+ * calls; what is saved is one kernel boundary and the partly empty last round of workgroups of each launch (the motion
+ * encoder's correlation and flow branches, update.py:91-95, are independent until `conv` joins them).  WOFT_EINVAL when the
+ * layers do not share a kernel: the caller launches them one after the other. */
+int woft_conv2d_pair(const woft_conv_params* a, const woft_conv_params* b, void* stream);
 /* fp32 array (n % 4 == 0) -> bf16 planes hi = bf16(x), lo = bf16(x - hi) (lo may be NULL): the
  * split form of a dynamic B operand (fmap2 in the correlation GEMM). */
 int woft_split_bf16(const float* x, int64_t n, void* hi, void* lo, void* stream);

@@ -284,6 +284,51 @@ def test_flow_head_in_one_conv_launch(ops, cin, cmid, h, w, precision, tol):
     _close(got, d2.t[:, :2].reshape(h, w, 2).permute(2, 0, 1)[None], tol, rtol=tol, what="fused vs two launches")
 
 
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("h,w", [(135, 240), (17, 25)])
+def test_two_layers_in_one_launch(ops, h, w, precision):
+    """woft_conv2d_pair: two independent layers that select the same kernel instance share one launch -- the motion
+    encoder's branches (update.py:91-95): convc1 (1x1, 324 -> 256) with convf1 (7x7 on the 2-channel flow, flat packing) on
+    the per-tap kernel, convc2 (3x3, 256 -> 192) with convf2 (3x3, 128 -> 64) on the register-streamed kernel, each writing at
+    a channel offset of a shared buffer.  Bit-identical to the two separate launches; layers on different kernels are refused."""
+    corr = ops.act_from_nchw(_rand(1, 324, h, w, seed=80), cs=352)
+    flow = ops.act_from_nchw(_rand(1, 2, h, w, seed=81, scale=5.0), cs=4)
+    mk = lambda co, ci, k, seed, **kw: ops.pack_conv(_rand(co, ci, k, k, seed=seed, scale=1 / math.sqrt(ci * k * k)),
+                                                      _rand(co, seed=seed + 1, scale=0.1), **kw)
+    c1, f1 = mk(256, 324, 1, 82), mk(128, 2, 7, 84, flat_cs=4)
+    c2, f2 = mk(192, 256, 3, 86), mk(64, 128, 3, 88)
+    res = {}
+    for paired in (False, True):
+        a1 = ops.new_act(1, h, w, 256, zero=True)
+        b1 = ops.new_act(1, h, w, 128, zero=True)
+        cf = ops.new_act(1, h, w, 256, zero=True)
+        pa = ops.conv_params(corr, c1, a1, epi=1, precision=precision)
+        pb = ops.conv_params(flow, f1, b1, epi=1, precision=precision)
+        assert ops.pair_ok(pa, pb) and pa.halo == 0
+        if paired:
+            ops.run_conv_pair(pa, pb)
+        else:
+            ops.run_conv(pa)
+            ops.run_conv(pb)
+        qa = ops.conv_params(a1, c2, cf, co_off=0, epi=1, precision=precision)
+        qb = ops.conv_params(b1, f2, cf, co_off=192, epi=1, precision=precision)
+        assert ops.pair_ok(qa, qb) and qa.halo == 8 and qa.tile_n == qb.tile_n == 64
+        if paired:
+            ops.run_conv_pair(qa, qb)
+        else:
+            ops.run_conv(qa)
+            ops.run_conv(qb)
+        torch.cuda.synchronize()
+        res[paired] = (a1.t.clone(), b1.t.clone(), cf.t.clone())
+        assert not ops.pair_ok(pa, qa)
+        if paired:
+            with pytest.raises(Exception):
+                ops.run_conv_pair(pa, qa)
+    for x, y in zip(res[False], res[True]):
+        assert torch.equal(x, y)
+    assert float(res[True][2][:, :192].abs().max()) > 0 and float(res[True][2][:, 192:].abs().max()) > 0
+
+
 @pytest.mark.parametrize("kh,kw", [(1, 5), (5, 1), (3, 3)])
 @pytest.mark.parametrize("precision,tol", [("fp32", 1.0), ("bf16x3", 4.0)])
 def test_conv_gru_epilogues(ops, kh, kw, precision, tol):

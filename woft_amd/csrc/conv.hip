@@ -143,7 +143,11 @@ __global__ __launch_bounds__(256) void conv_mfma_f32_kernel(const woft_conv_para
 // of divisions, the per-row pixel offsets are recomputed once per TAP (32-bit), loads are unconditional (clamped
 // offset + select), the wave id is scalar so the DMA bookkeeping stays on the SALU.
 template <int BM, int BN, int TERMS>
-__global__ __launch_bounds__(256) void conv_mfma_bf16_kernel(const woft_conv_params p) {
+__global__ __launch_bounds__(256) void conv_mfma_bf16_kernel(const woft_conv_params pa, const woft_conv_params pb, const int split) {
+    // (workgroups [0, split): layer pa; the rest: layer pb of the same launch -- woft_conv2d_pair; split = gridDim.x otherwise)
+    const bool second_layer = (int)blockIdx.x >= split;
+    const woft_conv_params p = second_layer ? pb : pa;     // (a copy, not a reference: see conv_regb_kernel)
+    const int bid = second_layer ? (int)blockIdx.x - split : (int)blockIdx.x;
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int RA = BM / 32;            // float4 rows per thread (A, fp32 source)
     constexpr int NP = (TERMS == 3) ? 2 : 1;
@@ -164,7 +168,7 @@ __global__ __launch_bounds__(256) void conv_mfma_bf16_kernel(const woft_conv_par
 
     const int64_t M = (int64_t)p.n_img * p.ho * p.wo;
     int m_tile, n_tile;
-    woft::tile_of_block(blockIdx.x, (int)((M + BM - 1) / BM), p.cout_pad / BN, m_tile, n_tile);
+    woft::tile_of_block(bid, (int)((M + BM - 1) / BM), p.cout_pad / BN, m_tile, n_tile);
     const int64_t m0 = (int64_t)m_tile * BM;
     const int n0 = n_tile * BN;
     const int nchunk = p.cin_pad / BK;
@@ -926,31 +930,34 @@ __global__ void split_bf16_kernel(const float* __restrict__ x, int64_t n4, __bf1
 }
 
 template <int BM, int BN>
-int launch_conv(const woft_conv_params& p, hipStream_t s) {
-    const int64_t M = (int64_t)p.n_img * p.ho * p.wo;
-    dim3 grid((unsigned)(ceil_div64(M, BM) * (p.cout_pad / BN)));       // 1-D: see woft::tile_of_block
+int launch_conv(const woft_conv_params& p, const woft_conv_params* second, hipStream_t s) {
+    auto blocks = [](const woft_conv_params& q) { return ceil_div64((int64_t)q.n_img * q.ho * q.wo, BM) * (q.cout_pad / BN); };
+    const woft_conv_params& pb = second ? *second : p;
+    const int split = (int)blocks(p);
+    dim3 grid((unsigned)(blocks(p) + (second ? blocks(pb) : 0)));       // 1-D: see woft::tile_of_block
     if (p.precision == 0) {
+        if (second) return WOFT_EINVAL;
         woft_launch(0, conv_mfma_f32_kernel<BM, BN>, grid, dim3(256), 0, s, p);
         return woft_launch_status();
     }
     // split-bf16 kernels use 32-bit element offsets
-    const int64_t cs_max = (p.in1 != nullptr && p.cs1 > p.cs0) ? p.cs1 : p.cs0;
-    if ((int64_t)p.n_img * p.h * p.w * cs_max >= (1ll << 31)) return WOFT_EINVAL;
-    if ((int64_t)p.taps_y * p.taps_x * p.cin_pad >= (1 << 20)) return WOFT_EINVAL;
+    for (const woft_conv_params* q : {&p, &pb}) {
+        const int64_t cs_max = (q->in1 != nullptr && q->cs1 > q->cs0) ? q->cs1 : q->cs0;
+        if ((int64_t)q->n_img * q->h * q->w * cs_max >= (1ll << 31)) return WOFT_EINVAL;
+        if ((int64_t)q->taps_y * q->taps_x * q->cin_pad >= (1 << 20)) return WOFT_EINVAL;
+    }
     if (p.precision == 1)
-        woft_launch(0, conv_mfma_bf16_kernel<BM, BN, 3>, grid, dim3(256), 0, s, p);
+        woft_launch(0, conv_mfma_bf16_kernel<BM, BN, 3>, grid, dim3(256), 0, s, p, pb, split);
     else
-        woft_launch(0, conv_mfma_bf16_kernel<BM, BN, 1>, grid, dim3(256), 0, s, p);
+        woft_launch(0, conv_mfma_bf16_kernel<BM, BN, 1>, grid, dim3(256), 0, s, p, pb, split);
     return woft_launch_status();
 }
 
 }  // namespace
 
-int woft_conv_regb_launch(const woft_conv_params& p, void* stream);     // conv_regb.hip
+int woft_conv_regb_launch(const woft_conv_params& p, const woft_conv_params* second, void* stream);     // conv_regb.hip
 
-extern "C" int woft_conv2d(const woft_conv_params* pp, void* stream) {
-    if (pp == nullptr) return WOFT_EINVAL;
-    const woft_conv_params& p = *pp;
+static int conv_check(const woft_conv_params& p) {
     if (p.in0 == nullptr || p.out == nullptr) return WOFT_EINVAL;
     if (p.precision < 0 || p.precision > 2) return WOFT_EINVAL;
     if (p.precision == 0 && p.wgt == nullptr) return WOFT_EINVAL;
@@ -998,15 +1005,27 @@ extern "C" int woft_conv2d(const woft_conv_params* pp, void* stream) {
          p.in_norm != 0 || p.ho != 9 || p.wo != 9 || p.wh0_ld < 324 || p.wh0_ld % 4 != 0 || p.wh0_mean == nullptr ||
          p.wh0_w == nullptr || p.wh0_bias == nullptr))
         return WOFT_EINVAL;
+    return WOFT_OK;
+}
+
+// second != NULL: one launch for two layers that run on the same kernel instance (woft_conv2d_pair)
+static int conv_dispatch(const woft_conv_params& p, const woft_conv_params* second, void* stream) {
     hipStream_t s = (hipStream_t)stream;
-    if (p.halo != 0) {
+    if (second != nullptr && (second->precision != p.precision || second->halo != p.halo ||
+                              (p.halo == 0 && second->tile_m != p.tile_m) ||
+                              second->tile_n != p.tile_n || p.precision == 0 || (p.halo != 0 && p.halo != 8 && p.halo != 12)))
+        return WOFT_EINVAL;
+    for (const woft_conv_params* q : {&p, second}) {
+        if (q == nullptr || q->halo == 0) continue;
         // LDS-halo kernels: split-bf16 precisions, stride 1, 3x3 / 1x5 / 5x1 taps, non-flat, same-size output
-        if (p.precision == 0 || p.flat || p.stride != 1) return WOFT_EINVAL;
-        if (p.ho != p.h + 2 * p.pad_y - p.taps_y + 1 || p.wo != p.w + 2 * p.pad_x - p.taps_x + 1) return WOFT_EINVAL;
-        const int64_t cs_max = (p.in1 != nullptr && p.cs1 > p.cs0) ? p.cs1 : p.cs0;
-        if ((int64_t)p.n_img * p.h * p.w * cs_max >= (1ll << 31)) return WOFT_EINVAL;     // 32-bit element offsets
-        if ((int64_t)p.taps_y * p.taps_x * p.cin_pad >= (1 << 20)) return WOFT_EINVAL;
-        if (p.halo == 8 || p.halo == 12) return woft_conv_regb_launch(p, stream);
+        if (q->precision == 0 || q->flat || q->stride != 1) return WOFT_EINVAL;
+        if (q->ho != q->h + 2 * q->pad_y - q->taps_y + 1 || q->wo != q->w + 2 * q->pad_x - q->taps_x + 1) return WOFT_EINVAL;
+        const int64_t cs_max = (q->in1 != nullptr && q->cs1 > q->cs0) ? q->cs1 : q->cs0;
+        if ((int64_t)q->n_img * q->h * q->w * cs_max >= (1ll << 31)) return WOFT_EINVAL;     // 32-bit element offsets
+        if ((int64_t)q->taps_y * q->taps_x * q->cin_pad >= (1 << 20)) return WOFT_EINVAL;
+    }
+    if (p.halo != 0) {
+        if (p.halo == 8 || p.halo == 12) return woft_conv_regb_launch(p, second, stream);
         if (p.halo == 1 && p.tile_n == 128) return launch_halo<8, 16, 128, 2, 2>(p, s);
         if (p.halo == 1 && p.tile_n == 64) return launch_halo<8, 16, 64, 2, 2>(p, s);
         if (p.halo == 2 && p.tile_n == 128 && p.ho == 9 && p.wo == 9) return launch_halo<9, 9, 128, 1, 2>(p, s);
@@ -1016,10 +1035,25 @@ extern "C" int woft_conv2d(const woft_conv_params* pp, void* stream) {
         if (p.halo == 4 && p.tile_n == 64) return launch_halo<4, 16, 64, 2, 2>(p, s);
         return WOFT_EINVAL;
     }
-    if (p.tile_m == 128 && p.tile_n == 128) return launch_conv<128, 128>(p, s);
-    if (p.tile_m == 128 && p.tile_n == 64) return launch_conv<128, 64>(p, s);
-    if (p.tile_m == 64 && p.tile_n == 128) return launch_conv<64, 128>(p, s);
-    return launch_conv<64, 64>(p, s);
+    if (p.tile_m == 128 && p.tile_n == 128) return launch_conv<128, 128>(p, second, s);
+    if (p.tile_m == 128 && p.tile_n == 64) return launch_conv<128, 64>(p, second, s);
+    if (p.tile_m == 64 && p.tile_n == 128) return launch_conv<64, 128>(p, second, s);
+    return launch_conv<64, 64>(p, second, s);
+}
+
+extern "C" int woft_conv2d(const woft_conv_params* pp, void* stream) {
+    if (pp == nullptr) return WOFT_EINVAL;
+    const int rc = conv_check(*pp);
+    return rc != WOFT_OK ? rc : conv_dispatch(*pp, nullptr, stream);
+}
+
+extern "C" int woft_conv2d_pair(const woft_conv_params* a, const woft_conv_params* b, void* stream) {
+    if (a == nullptr || b == nullptr) return WOFT_EINVAL;
+    int rc = conv_check(*a);
+    if (rc == WOFT_OK) rc = conv_check(*b);
+    if (rc != WOFT_OK) return rc;
+    if (a->stat_sum != nullptr || b->stat_sum != nullptr) return WOFT_EINVAL;     // (statistics rows are indexed by the launch's tiles)
+    return conv_dispatch(*a, b, stream);
 }
 
 extern "C" int woft_corr_gemm_bf16(const void* a, const void* b, int64_t m, int64_t n, int64_t rows_a, int64_t rows_b,

@@ -27,8 +27,14 @@ namespace {
 
 using woft::BK;
 
-template <int TY, int TX, int KY, int KX, int WM, int TERMS, int NBUF, int DIST, int AD, int CU = 1, int HD = 1>
-__global__ __launch_bounds__(256, 2) void conv_regb_kernel(const woft_conv_params p) {
+template <int TY, int TX, int KY, int KX, int WM, int TERMS, int NBUF, int DIST, int AD, int CU = 1, int HD = 1, bool IL = true>
+__global__ __launch_bounds__(256, 2) void conv_regb_kernel(const woft_conv_params pa, const woft_conv_params pb, const int split) {
+    // (two independent layers that run on the same instance of this kernel may share ONE launch -- woft_conv2d_pair: the
+    //  workgroups [0, split) belong to the first layer, the rest to the second; split = gridDim.x for a single layer)
+    const bool second_layer = (int)blockIdx.x >= split;
+    const woft_conv_params p = second_layer ? pb : pa;     // (a copy: a REFERENCE selected between the two argument
+                                                            //  structs does not compile -- 'illegal VGPR to SGPR copy')
+    const int bid = second_layer ? (int)blockIdx.x - split : (int)blockIdx.x;
     constexpr int NWAVES = 4;
     constexpr int NPIX = TY * TX;
     constexpr int BM = (NPIX + 31) / 32 * 32;
@@ -60,7 +66,7 @@ __global__ __launch_bounds__(256, 2) void conv_regb_kernel(const woft_conv_param
 
     const int tyn = (p.ho + TY - 1) / TY, txn = (p.wo + TX - 1) / TX;
     int m_tile, n_tile;
-    woft::tile_of_block(blockIdx.x, p.n_img * tyn * txn, p.cout_pad / BN, m_tile, n_tile);
+    woft::tile_of_block(bid, p.n_img * tyn * txn, p.cout_pad / BN, m_tile, n_tile);
     const int img0 = m_tile / (tyn * txn);
     const int trem = m_tile - img0 * (tyn * txn);
     const int y0 = (trem / txn) * TY, x0 = (trem % txn) * TX;
@@ -88,21 +94,23 @@ __global__ __launch_bounds__(256, 2) void conv_regb_kernel(const woft_conv_param
 #pragma unroll
         for (int j = 0; j < RH; ++j) rh[hs][j] = *(const f32x4*)(src + (uint32_t)(hpix[j] * cs));
     };
-    auto store_halo = [&](__bf16* As, auto slot_tag) {
-        constexpr int hs = decltype(slot_tag)::value;
-#pragma unroll
-        for (int j = 0; j < RH; ++j) {
-            const int ht = r0 + 32 * j;
-            if (RH * 32 > HROWS && ht >= HROWS) continue;
-            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-            const f32x4 val = hok[j] ? rh[hs][j] : zero;
-            const bf16x4 hi = __builtin_convertvector(val, bf16x4);
-            *(bf16x4*)(As + ht * LDB + 4 * v) = hi;
-            if (NP == 2) {
-                const f32x4 rem = val - __builtin_convertvector(hi, f32x4);
-                *(bf16x4*)(As + A_PLANE + ht * LDB + 4 * v) = __builtin_convertvector(rem, bf16x4);
-            }
+    auto store_halo_row = [&](__bf16* As, auto slot_tag, auto j_tag) {      // one of this thread's RH halo rows -> LDS
+        constexpr int hs = decltype(slot_tag)::value, j = decltype(j_tag)::value;
+        const int ht = r0 + 32 * j;
+        if (RH * 32 > HROWS && ht >= HROWS) return;
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 val = hok[j] ? rh[hs][j] : zero;
+        const bf16x4 hi = __builtin_convertvector(val, bf16x4);
+        *(bf16x4*)(As + ht * LDB + 4 * v) = hi;
+        if (NP == 2) {
+            const f32x4 rem = val - __builtin_convertvector(hi, f32x4);
+            *(bf16x4*)(As + A_PLANE + ht * LDB + 4 * v) = __builtin_convertvector(rem, bf16x4);
         }
+    };
+    auto store_halo = [&](__bf16* As, auto slot_tag) {
+        [&]<int... J>(std::integer_sequence<int, J...>) {
+            (store_halo_row(As, slot_tag, std::integral_constant<int, J>{}), ...);
+        }(std::make_integer_sequence<int, RH>{});
     };
 
     // this wave's weight stream: band (n0 / 32 + wn), steps in (chunk, tap) order, STEP_ELEMS per step
@@ -134,7 +142,7 @@ __global__ __launch_bounds__(256, 2) void conv_regb_kernel(const woft_conv_param
 
     // developer probe (tools/regb_probe.py): s_memtime stamps of wave 0 -> in_rstd (unused by this kernel otherwise)
     unsigned long long* stamps = (p.in_mean == (const float*)1 && wave == 0 && lane == 0)
-                                     ? (unsigned long long*)p.in_rstd + (size_t)blockIdx.x * 32 : nullptr;
+                                     ? (unsigned long long*)p.in_rstd + (size_t)bid * 32 : nullptr;
     if (stamps) { stamps[0] = __builtin_amdgcn_s_memtime(); stamps[30] = __builtin_amdgcn_s_memrealtime(); }
     // ---- prologue: halo of chunk 0, the first DIST steps of the weight stream ---------------------------------
     [&]<int... C>(std::integer_sequence<int, C...>) {
@@ -154,6 +162,7 @@ __global__ __launch_bounds__(256, 2) void conv_regb_kernel(const woft_conv_param
     // busy while LDS, L1 and L2 were all under 30 % busy).
     constexpr int PT = TM, NQ = TAPS * PT, AR = AD + 1;                  // pairs per tap / per chunk
     static_assert(TM % 2 == 0, "row tiles are processed in pairs");
+    static_assert(!IL || NQ >= RH, "interleaved halo conversion: one thread-row per pair");
     auto run_chunk = [&](int chunk, auto more_tag, auto phase_tag) {
         constexpr bool more = decltype(more_tag)::value;
         constexpr int phase = decltype(phase_tag)::value;                // chunk % CU
@@ -185,6 +194,14 @@ __global__ __launch_bounds__(256, 2) void conv_regb_kernel(const woft_conv_param
                 }
                 if constexpr (q + AD < NQ) load_a(std::integral_constant<int, q + AD>{});
                 __builtin_amdgcn_sched_barrier(0);
+                // IL: the next chunk's halo (requested at the first tap of this chunk) is converted and written to the other
+                // buffer ONE thread-row per pair over the last RH pairs of the chunk, its ~20 vector / LDS instructions
+                // placed in the issue gaps between this pair's MFMAs (sched_group_barrier: 1 MFMA, then up to 4 others)
+                // instead of as one block after the last MFMA, where the matrix pipe idled for the whole conversion
+                constexpr bool il_row = IL && more && q >= NQ - RH;
+                if constexpr (il_row)
+                    store_halo_row(smem + ((chunk + 1) & 1) * A_ELEMS, std::integral_constant<int, (phase + 1) % HD>{},
+                                   std::integral_constant<int, q - (NQ - RH)>{});
                 if (NP == 2) {
                     acc[i0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[as][0][NP - 1], bq[slot][0][s2], acc[i0], 0, 0, 0);
                     acc[i0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[as][1][NP - 1], bq[slot][0][s2], acc[i0 + 1], 0, 0, 0);
@@ -193,10 +210,18 @@ __global__ __launch_bounds__(256, 2) void conv_regb_kernel(const woft_conv_param
                 }
                 acc[i0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[as][0][0], bq[slot][0][s2], acc[i0], 0, 0, 0);
                 acc[i0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[as][1][0], bq[slot][0][s2], acc[i0 + 1], 0, 0, 0);
+                if constexpr (il_row) {
+#pragma unroll
+                    for (int g = 0; g < (NP == 2 ? 6 : 2); ++g) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);      // up to three VALU
+                        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // up to one LDS write
+                    }
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 // next chunk's halo -> the other buffer (free since the barrier that ended the previous chunk); late
                 // in the chunk so that its loads had the whole chunk to land
-                if constexpr (q == NQ - 1) {
+                if constexpr (q == NQ - 1 && !IL) {
                     if (more) store_halo(smem + ((chunk + 1) & 1) * A_ELEMS, std::integral_constant<int, (phase + 1) % HD>{});
                 }
             }(), ...);
@@ -312,13 +337,17 @@ __global__ __launch_bounds__(256, 2) void conv_regb_kernel(const woft_conv_param
 }
 
 template <int WM, int TY = 8>
-int launch_regb(const woft_conv_params& p, hipStream_t s) {
+int launch_regb(const woft_conv_params& p, const woft_conv_params* second, hipStream_t s) {
     constexpr int TX = 16, BN = 128 / WM;
-    const int tyn = (p.ho + TY - 1) / TY, txn = (p.wo + TX - 1) / TX;
-    const int64_t mt = (int64_t)p.n_img * tyn * txn;
-    dim3 grid((unsigned)(mt * (p.cout_pad / BN)));
+    auto blocks = [](const woft_conv_params& q) {
+        const int tyn = (q.ho + TY - 1) / TY, txn = (q.wo + TX - 1) / TX;
+        return (int64_t)q.n_img * tyn * txn * (q.cout_pad / BN);
+    };
+    const woft_conv_params& pb = second ? *second : p;
+    const int split = (int)blocks(p);
+    dim3 grid((unsigned)(blocks(p) + (second ? blocks(pb) : 0)));
 #define REGB(KY, KX, T, NB, D) \
-    woft_launch(0, conv_regb_kernel<TY, TX, KY, KX, WM, T, NB, D, 2>, grid, dim3(256), (size_t)g_regb_dyn_lds, s, p)
+    woft_launch(0, conv_regb_kernel<TY, TX, KY, KX, WM, T, NB, D, 2>, grid, dim3(256), (size_t)g_regb_dyn_lds, s, p, pb, split)
 #define REGB_TAPS(T)                                                     \
     if (p.taps_y == 3 && p.taps_x == 3) REGB(3, 3, T, 3, 2);             \
     else if (p.taps_y == 1 && p.taps_x == 5) REGB(1, 5, T, 5, 3);        \
@@ -326,7 +355,7 @@ int launch_regb(const woft_conv_params& p, hipStream_t s) {
     else if (p.taps_y == 1 && p.taps_x == 1) {    /* 1x1: three chunks per unrolled group, input tile three chunks ahead; \
                                                      64-column tiles only (the 128-column layout does not fit 256 registers) */ \
         if constexpr (WM == 2 && TY == 8)                                                                                       \
-            woft_launch(0, conv_regb_kernel<TY, TX, 1, 1, WM, T, 3, 2, 1, 3, 3>, grid, dim3(256), (size_t)g_regb_dyn_lds, s, p); \
+            woft_launch(0, conv_regb_kernel<TY, TX, 1, 1, WM, T, 3, 2, 1, 3, 3, false>, grid, dim3(256), (size_t)g_regb_dyn_lds, s, p, pb, split); \
         else return WOFT_EINVAL;                                                                                                \
     } else return WOFT_EINVAL
     if (p.precision == 1) { REGB_TAPS(3); } else { REGB_TAPS(1); }
@@ -340,15 +369,23 @@ int launch_regb(const woft_conv_params& p, hipStream_t s) {
 // Called by woft_conv2d for p.halo == 8 (8 x 16-pixel tiles) and 12 (4 x 16 pixels x 128 columns: four waves = four column
 // bands of 64 rows -- the per-wave work of the 8 x 16 x 64 layout with the weights fetched once per workgroup), after its
 // argument checks.
-int woft_conv_regb_launch(const woft_conv_params& p, void* stream) {
+int woft_conv_regb_launch(const woft_conv_params& p, const woft_conv_params* second, void* stream) {
+    if (second != nullptr) {            // one launch for two layers: the same kernel instance, no probe
+        const woft_conv_params& b = *second;
+        if (b.halo != p.halo || b.tile_n != p.tile_n || b.taps_y != p.taps_y || b.taps_x != p.taps_x || b.precision != p.precision ||
+            b.wgt_frag == nullptr || b.in_norm != 0 || b.in_mean != nullptr || p.in_mean != nullptr || b.wh0_lookup != nullptr ||
+            b.epi == WOFT_EPI_WH_MEAN || b.cout_pad % b.tile_n != 0 || (p.taps_y * p.taps_x == 1))
+            return WOFT_EINVAL;
+        if (b.epi == WOFT_EPI_FLOWHEAD && (b.e0 == nullptr || b.ldo < 20 || b.ldo % 4 != 0 || b.co_off != 0 || b.cout % 32 != 0)) return WOFT_EINVAL;
+    }
     if (p.halo == 12) {
         if (p.wgt_frag == nullptr || p.in_norm != 0 || (p.in_mean != nullptr && p.in_mean != (const float*)1) || p.wh0_lookup != nullptr ||
             p.epi == WOFT_EPI_WH_MEAN || p.epi == WOFT_EPI_FLOWHEAD || p.tile_n != 128 || p.cout_pad % 128 != 0 || p.taps_y * p.taps_x == 1) return WOFT_EINVAL;
-        return launch_regb<1, 4>(p, (hipStream_t)stream);
+        return launch_regb<1, 4>(p, second, (hipStream_t)stream);
     }
     if (p.wgt_frag == nullptr || p.in_norm != 0 || (p.in_mean != nullptr && p.in_mean != (const float*)1) || p.wh0_lookup != nullptr || p.epi == WOFT_EPI_WH_MEAN) return WOFT_EINVAL;
     if (p.epi == WOFT_EPI_FLOWHEAD && (p.e0 == nullptr || p.ldo < 20 || p.ldo % 4 != 0 || p.co_off != 0 || p.cout % 32 != 0)) return WOFT_EINVAL;
-    if (p.tile_n == 128 && p.cout_pad % 128 == 0) return launch_regb<1>(p, (hipStream_t)stream);
-    if (p.tile_n == 64 && p.cout_pad % 64 == 0) return launch_regb<2>(p, (hipStream_t)stream);
+    if (p.tile_n == 128 && p.cout_pad % 128 == 0) return launch_regb<1>(p, second, (hipStream_t)stream);
+    if (p.tile_n == 64 && p.cout_pad % 64 == 0) return launch_regb<2>(p, second, (hipStream_t)stream);
     return WOFT_EINVAL;
 }

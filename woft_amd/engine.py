@@ -32,6 +32,9 @@ SIDE_STREAM = os.environ.get("WOFT_SIDE_STREAM", "0") != "0"
 # flow head: the 3x3 -> 2-channel conv folded into the first conv's epilogue + a per-pixel gather (0: two convs, the
 # second on the vector ALUs in exact fp32 -- woft_flow_head_update)
 FUSE_FLOWHEAD = os.environ.get("WOFT_FUSE_FLOWHEAD", "1") != "0"
+# motion encoder: the correlation branch (convc1 -> convc2) and the flow branch (convf1 -> convf2) are independent until
+# `conv` joins them (update.py:89-97): first layers in one launch, second layers in one launch (woft_conv2d_pair)
+PAIR_BRANCHES = os.environ.get("WOFT_PAIR", "1") != "0"
 
 
 def _ru(x, m):
@@ -480,6 +483,12 @@ class _Plan:
                    ("conv", cp(self.c1, e.convc2, self.cf, co_off=0, epi=EPI.EPI_RELU), "convc2")]
             if SIDE_STREAM:     # the flow branch (reads flow4, writes fl1 and cf[:, 192:]) beside lookup + correlation branch
                 prog = [("fork", flo)] + prog + cor + [("join", None)]
+            elif PAIR_BRANCHES:
+                for c_, f_ in zip(cor, flo):             # (larger layer first: its workgroups are dispatched first)
+                    if ops.pair_ok(c_[1], f_[1]):
+                        prog.append(("conv2", (c_[1], f_[1]), c_[2] + "+" + f_[2]))
+                    else:
+                        prog += [c_, f_]
             else:
                 prog += cor + flo
             prog.append(("conv", cp(self.cf, e.convm, self.xbuf, co_off=sp.cdim, epi=EPI.EPI_RELU), "convm"))
@@ -520,7 +529,17 @@ class _Plan:
     def run(self, prog):
         for ent in prog:
             kind, a = ent[0], ent[1]
-            if kind == "conv":
+            if kind == "conv2":
+                ev = self.conv_events
+                if ev is not None and len(ent) > 2 and ent[2] in ev:
+                    s, t = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    s.record()
+                    ops.run_conv_pair(*a)
+                    t.record()
+                    ev[ent[2]].append((s, t))
+                else:
+                    ops.run_conv_pair(*a)
+            elif kind == "conv":
                 ev = self.conv_events
                 if ev is not None and len(ent) > 2 and ent[2] in ev:
                     s, t = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

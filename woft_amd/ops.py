@@ -361,6 +361,23 @@ def flow_head_gather(part, n_planes, h, w, bias2, delta, coords, flow4=None, flo
           "woft_flow_head_gather")
 
 
+def pair_ok(a, b):
+    """True when woft_conv2d_pair takes the two layers in one launch (they select the same kernel instance)."""
+    if a.precision == 0 or a.precision != b.precision or a.halo != b.halo or a.tile_n != b.tile_n:
+        return False
+    if a.halo == 0 and a.tile_m != b.tile_m:                  # (the pixel-tile kernels ignore tile_m)
+        return False
+    if a.stat_sum or b.stat_sum or a.in_norm or b.in_norm:
+        return False
+    if a.halo == 0:
+        return True
+    return a.halo in (8, 12) and (a.taps_y, a.taps_x) == (b.taps_y, b.taps_x) and a.taps_y * a.taps_x > 1
+
+
+def run_conv_pair(a, b):
+    check(_lib.load().woft_conv2d_pair(C.byref(a), C.byref(b), stream_ptr()), "woft_conv2d_pair")
+
+
 def run_conv(p):
     check(_lib.load().woft_conv2d(C.byref(p), stream_ptr()), "woft_conv2d")
 
