@@ -105,7 +105,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--iters", type=int, default=12)
-    ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16x3", "bf16"],
+    ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16x3", "bf16", "fp16"],
                     help="conv / correlation-GEMM arithmetic: exact fp32 MFMA, split-bf16 (fp32-emulating, default), bf16")
     ap.add_argument("--corr", default="otf", choices=["volume", "otf"],
                     help="correlation: volume-free on-the-fly lookup (default in the split-bf16 precisions) or the "
@@ -222,7 +222,7 @@ def main():
     peak_gb = torch.cuda.max_memory_allocated() / 2 ** 30        # every device buffer of the path is a torch tensor
 
     mask_region = not args.full_weight_head
-    terms = {"fp32": 1, "bf16x3": 3, "bf16": 1}[args.precision]
+    terms = {"fp32": 1, "bf16x3": 3, "bf16": 1, "fp16": 1}[args.precision]
     mfma_peak = 157.3 if args.precision == "fp32" else 2500.0      # TFLOP/s dense: f32-input MFMA / bf16 MFMA (MI355X_MICROARCH.md)
 
     def lookup_roofline(evs, P, storage="fp32"):
@@ -313,7 +313,9 @@ def main():
         "value": world * K / elapsed, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
         "ms_per_step": 1000.0 * elapsed / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": {"fp32": "f32", "bf16x3": "bf16x3 (split-bf16 MFMA operands emulating fp32, fp32 accumulate)",
-                  "bf16": "bf16 (fp32 accumulate)"}[args.precision], "data": "synthetic",
+                  "bf16": "bf16 (fp32 accumulate)",
+                  "fp16": "fp16 convolutions (fp32 accumulate) in the encoders and the update block, bf16x3 correlation and "
+                          "weight head: the reference's mixed_precision scoping"}[args.precision], "data": "synthetic",
         "config": {"workload": f"{H}x{W} synthetic sequence per GPU ({CLIP}-frame clips): WeightedRAFT-full {args.iters} iters + "
                                + ("weighted LSq homography on Sobol-500 correspondences (reference default config WOFT.py)"
                                 if args.tracker_config == "WOFT" else
@@ -406,7 +408,7 @@ def main():
         # the other arithmetic modes on the same sequence, each its own engine + buffers.  The STRICT fp32 operating
         # point (exact fp32 MFMA products, all-pairs volume: the reference's precision class) runs the full K steps.
         alt = {}
-        for prec in ("fp32", "bf16x3", "bf16"):
+        for prec in ("fp32", "bf16x3", "bf16", "fp16"):
             if prec == args.precision:
                 continue
             r, trk, pl, _ = side_run(K2 if prec == "fp32" else min(K, 8), precision=prec)

@@ -73,9 +73,11 @@ typedef struct woft_conv_params {
     int32_t cin_pad;       /* GEMM-K per tap, multiple of 32                                   */
     int32_t flat;          /* 1: the 32-float K chunk of a tap runs along x over 32/cs0 pixels */
     const float* wgt;      /* [cout_pad][taps_y*taps_x*cin_pad] fp32, K contiguous (precision 0) */
-    const void* wgt_hi;    /* same shape, bf16: hi = bf16(w)          (precision 1, 2)         */
+    const void* wgt_hi;    /* same shape, bf16: hi = bf16(w)          (precision 1, 2); fp16(w) (precision 3) */
     const void* wgt_lo;    /* same shape, bf16: lo = bf16(w - hi)     (precision 1)            */
-    int32_t precision;     /* 0: fp32 MFMA; 1: split-bf16 x3 (fp32-emulating); 2: bf16         */
+    int32_t precision;     /* 0: fp32 MFMA; 1: split-bf16 x3 (fp32-emulating); 2: bf16; 3: fp16 operands, fp32
+                              accumulation (the reference's mixed_precision autocast, weighted_raft.py:204,215,233;
+                              not for the 9 x 9 weight-head windows, which the reference keeps in fp32)   */
     const float* bias;     /* [cout_pad] or NULL                                               */
     float alpha;           /* scale applied to the accumulator                                 */
     int32_t cout;          /* valid output channels                                            */

@@ -163,10 +163,13 @@ def test_operator_tc_boundary(golden_dir):
 
 
 @torch.no_grad()
-@pytest.mark.parametrize("precision,epe_mean,epe_max,wtol", [("bf16x3", 1e-3, 1e-2, 1e-4), ("bf16", 5e-2, 0.5, 5e-3)])
+@pytest.mark.parametrize("precision,epe_mean,epe_max,wtol", [("bf16x3", 1e-3, 1e-2, 1e-4), ("bf16", 5e-2, 0.5, 5e-3),
+                                                               ("fp16", 1e-2, 0.1, 1e-3)])
 def test_reduced_precision_operating_points(golden_dir, precision, epe_mean, epe_max, wtol):
-    """Split-bf16 (fp32-emulating) and plain bf16 MFMA paths against the reference's golden flow.
-    Stated budgets: bf16x3 keeps the fp32 tolerances; bf16 EPE mean <= 0.05 px."""
+    """Split-bf16 (fp32-emulating), plain bf16 and fp16 MFMA paths against the reference's golden flow.
+    Stated budgets: bf16x3 keeps the fp32 tolerances; bf16 EPE mean <= 0.05 px; fp16 -- the reference's
+    `mixed_precision` scoping: fp16 convolutions in the encoders and the update block, fp32-class correlation, weight head
+    and upsampling (weighted_raft.py:204-219,233-234,258-290) -- EPE mean <= 0.01 px, max <= 0.1 px, sigmoid(w) <= 1e-3."""
     g = np.load(golden_dir / "flow_full_136x200_it12.npz")
     sd = synth.make_state_dict(seed=int(g["seed"]))
     fc = _flow_config(sd, int(g["iters"]), precision=precision)
@@ -182,12 +185,13 @@ def test_reduced_precision_operating_points(golden_dir, precision, epe_mean, epe
 @torch.no_grad()
 @pytest.mark.parametrize("precision,corr,epe_mean,epe_max,wtol", [
     ("fp32", "volume", 1e-3, 1e-2, 1e-4), ("bf16x3", "otf", 1e-3, 1e-2, 1e-4), ("bf16x3", "volume", 1e-3, 1e-2, 1e-4),
-    ("bf16", "otf", 0.15, 1.0, 5e-3), ("bf16", "volume", 0.15, 1.0, 5e-3)])
+    ("bf16", "otf", 0.15, 1.0, 5e-3), ("bf16", "volume", 0.15, 1.0, 5e-3), ("fp16", "otf", 0.03, 0.3, 2e-3),
+    ("fp16", "volume", 0.03, 0.3, 2e-3)])
 def test_32_iterations_vs_reference_golden(golden_dir, precision, corr, epe_mean, epe_max, wtol):
     """BASELINE config 3 (32 refinement iterations; bf16 operating point) against the REFERENCE's flow at 32
     iterations (weighted_raft.py:228-237 run 32 times; tests/golden/flow_full_136x200_it32.npz).  Budgets of SURVEY
     8d: fp32-class arithmetic (fp32, bf16x3) EPE mean <= 1e-3 px / max <= 1e-2 px; bf16 EPE mean <= 0.15 px @ 32 it,
-    sigmoid(w) <= 5e-3."""
+    sigmoid(w) <= 5e-3; fp16 (mixed_precision scoping) EPE mean <= 0.03 px @ 32 it, sigmoid(w) <= 2e-3."""
     g = np.load(golden_dir / "flow_full_136x200_it32.npz")
     assert int(g["iters"]) == 32
     sd = synth.make_state_dict(seed=int(g["seed"]))
@@ -244,6 +248,25 @@ def test_cached_flow_wire_format(tmp_path):
     for i in (10, 11, 12, 13):
         _, dst4, w4 = prov.compute_flow(img, img, mode="TC", src_img_identifier=("ds", "seq", i), numpy_out=True)
         assert np.array_equal(dst4, dst3) and np.array_equal(w4, w3), i
+
+
+@torch.no_grad()
+def test_mixed_precision_key_selects_the_fp16_operating_point():
+    """class_params.mixed_precision = True (weighted_raft.py:204,215,233: autocast around fnet, cnet, update block) ->
+    fp16 convolutions there, fp32-class correlation and weight head; `precision` / WOFT_PRECISION override it."""
+    sd = synth.make_state_dict(seed=3)
+    c = _flow_config(sd, 2)
+    c.class_params.mixed_precision = True
+    prov = c.of_class(c)
+    e = prov.engine
+    assert (prov.precision, e.precision, e.prec_corr, e.prec_wh, e.corr) == ("fp16", "fp16", "bf16x3", "bf16x3", "otf")
+    plan = e.plan(128, 160)
+    convs = [ent[1] for ent in plan.prog_iter if ent[0] == "conv"] + [p for ent in plan.prog_iter if ent[0] == "conv2" for p in ent[1]]
+    assert convs and all(p.precision == 3 for p in convs) and all(p.precision == 3 for p in plan.prog_mask)
+    assert all(p.precision == 1 for p in plan.prog_wh) and plan.lookup.terms == 3
+    c2 = _flow_config(sd, 2, precision="bf16x3")
+    c2.class_params.mixed_precision = True
+    assert c2.of_class(c2).precision == "bf16x3"
 
 
 @torch.no_grad()
@@ -378,7 +401,7 @@ def test_graph_replay_matches_eager(precision, small):
 
 @torch.no_grad()
 @pytest.mark.parametrize("precision,epe_mean,epe_max,wtol", [("fp32", 1e-3, 1e-2, 2e-4), ("bf16x3", 1e-3, 1e-2, 2e-4),
-                                                               ("bf16", 5e-2, 0.5, 1e-2)])
+                                                               ("bf16", 5e-2, 0.5, 1e-2), ("fp16", 1e-2, 0.1, 2e-3)])
 @pytest.mark.parametrize("name", ["constant", "constant_vs_texture", "saturated", "identical"])
 def test_degenerate_inputs_vs_reference(golden_dir, name, precision, epe_mean, epe_max, wtol):
     """Constant image (InstanceNorm variance 0, extractor.py:28-32: rstd = 1/sqrt(eps) = 316 on a channel that holds
@@ -400,7 +423,7 @@ def test_degenerate_inputs_vs_reference(golden_dir, name, precision, epe_mean, e
 
 @torch.no_grad()
 @pytest.mark.parametrize("precision,corr,epe_mean,epe_max,wtol", [("bf16x3", "otf", 1e-3, 1e-2, 1e-4), ("fp32", "volume", 1e-3, 1e-2, 1e-4),
-                                                                    ("bf16", "otf", 5e-2, 0.5, 5e-3)])
+                                                                    ("bf16", "otf", 5e-2, 0.5, 5e-3), ("fp16", "otf", 1e-2, 0.1, 1e-3)])
 def test_real_frames_720p_vs_reference(golden_dir, precision, corr, epe_mean, epe_max, wtol):
     """BASELINE config 2 at its REAL size on REAL frames: a 720 x 1280 pair of the reference's demo sequence (decoded
     frames stored in tests/golden/real_720p.npz), 12 iterations, against the reference's flow and weight logits -- 1/8

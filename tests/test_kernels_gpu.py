@@ -44,7 +44,7 @@ def _close(a, b, atol, rtol=0.0, what=""):
     (256, 2, 3, 1, 17, 25, None),
     (64, 96, 1, 2, 20, 28, None),
 ])
-@pytest.mark.parametrize("precision,tol", [("fp32", 2e-5), ("bf16x3", 1e-4), ("bf16", 3e-2)])
+@pytest.mark.parametrize("precision,tol", [("fp32", 2e-5), ("bf16x3", 1e-4), ("bf16", 3e-2), ("fp16", 4e-3)])
 def test_conv_plain(ops, cin, cout, k, stride, h, w, tiles, precision, tol):
     x = _rand(2, cin, h, w, seed=1)
     wt = _rand(cout, cin, k, k, seed=2, scale=1.0 / math.sqrt(cin * k * k))
@@ -239,7 +239,7 @@ def test_flow_head_update_one_launch(ops, cin, h, w):
     assert bool((res[1][3][:, :6] == -5.0).all()) and bool((res[1][3][:, 8:] == -5.0).all())
 
 
-@pytest.mark.parametrize("precision,tol", [("bf16x3", 3e-5), ("bf16", 2e-2)])
+@pytest.mark.parametrize("precision,tol", [("bf16x3", 3e-5), ("bf16", 2e-2), ("fp16", 3e-3)])
 @pytest.mark.parametrize("cin,cmid,h,w", [(128, 256, 135, 240), (128, 256, 17, 25), (96, 128, 40, 64)])
 def test_flow_head_in_one_conv_launch(ops, cin, cmid, h, w, precision, tol):
     """FlowHead (update.py:10-17) = conv2(relu(conv1(h))) with the 3x3 -> 2-channel conv2 folded into conv1's epilogue
@@ -254,7 +254,7 @@ def test_flow_head_in_one_conv_launch(ops, cin, cmid, h, w, precision, tol):
     b2 = _rand(2, seed=74, scale=0.1)
     pc1, pc2 = ops.pack_conv(w1, b1), ops.pack_conv(w2, b2)
     xa = ops.act_from_nchw(x, cs=(cin + 31) // 32 * 32)
-    frags = ops.pack_flowhead_frags(w2, 2 if precision == "bf16x3" else 1)
+    frags = ops.pack_flowhead_frags(w2, 2 if precision == "bf16x3" else 1, f16=precision == "fp16")
     part = torch.full((4 * h * w, 20), float("nan"), device="cuda")
     p = ops.flowhead_params(xa, pc1, part, frags, precision=precision)
     assert p is not None and p.halo == 8
@@ -284,7 +284,7 @@ def test_flow_head_in_one_conv_launch(ops, cin, cmid, h, w, precision, tol):
     _close(got, d2.t[:, :2].reshape(h, w, 2).permute(2, 0, 1)[None], tol, rtol=tol, what="fused vs two launches")
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16", "fp16"])
 @pytest.mark.parametrize("h,w", [(135, 240), (17, 25)])
 def test_two_layers_in_one_launch(ops, h, w, precision):
     """woft_conv2d_pair: two independent layers that select the same kernel instance share one launch -- the motion

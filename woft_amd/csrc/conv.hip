@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void conv_mfma_bf16_kernel(const woft_conv_par
         for (int j = 0; j < RA; ++j) {
             const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
             const f32x4 val = rok[j] ? ra[j] : zero;
-            const bf16x4 hi = __builtin_convertvector(val, bf16x4);
+            const bf16x4 hi = cvt16<TERMS>(val);
             *(bf16x4*)(As + (r0 + 32 * j) * LDB + 4 * v) = hi;
             if (NP == 2) {
                 const f32x4 rem = val - __builtin_convertvector(hi, f32x4);
@@ -300,10 +300,10 @@ __global__ __launch_bounds__(256) void conv_mfma_bf16_kernel(const woft_conv_par
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     if (NP == 2) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[NP - 1][i], b[0][j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[NP - 1][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = mma16<TERMS>(a[NP - 1][i], b[0][j], acc[i][j]);
+                        acc[i][j] = mma16<TERMS>(a[0][i], b[NP - 1][j], acc[i][j]);
                     }
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = mma16<TERMS>(a[0][i], b[0][j], acc[i][j]);
                 }
         }
     };
@@ -469,10 +469,10 @@ __global__ __launch_bounds__(256, (STAGES == 1 ? 4 : (TY == 9 ? 3 : 1))) void co
 #pragma unroll
             for (int s3 = 0; s3 < 3; ++s3) {
                 if (NP == 2) {
-                    c0acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c0w[s3][NP - 1], c0x[s3][0], c0acc, 0, 0, 0);
-                    c0acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c0w[s3][0], c0x[s3][NP - 1], c0acc, 0, 0, 0);
+                    c0acc = mma16<TERMS>(c0w[s3][NP - 1], c0x[s3][0], c0acc);
+                    c0acc = mma16<TERMS>(c0w[s3][0], c0x[s3][NP - 1], c0acc);
                 }
-                c0acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c0w[s3][0], c0x[s3][0], c0acc, 0, 0, 0);
+                c0acc = mma16<TERMS>(c0w[s3][0], c0x[s3][0], c0acc);
             }
         }
     };
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(256, (STAGES == 1 ? 4 : (TY == 9 ? 3 : 1))) void co
                 }
             }
             const f32x4 val = hok[j] ? x : zero;
-            const bf16x4 hi = __builtin_convertvector(val, bf16x4);
+            const bf16x4 hi = cvt16<TERMS>(val);
             *(bf16x4*)(As + ht * LDB + 4 * v) = hi;
             if (NP == 2) {
                 const f32x4 rem = val - __builtin_convertvector(hi, f32x4);
@@ -664,10 +664,10 @@ __global__ __launch_bounds__(256, (STAGES == 1 ? 4 : (TY == 9 ? 3 : 1))) void co
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     if (NP == 2) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[n & 1][NP - 1], bq[s2 & 1][0][j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[n & 1][0], bq[s2 & 1][NP - 1][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = mma16<TERMS>(aq[n & 1][NP - 1], bq[s2 & 1][0][j], acc[i][j]);
+                        acc[i][j] = mma16<TERMS>(aq[n & 1][0], bq[s2 & 1][NP - 1][j], acc[i][j]);
                     }
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[n & 1][0], bq[s2 & 1][0][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = mma16<TERMS>(aq[n & 1][0], bq[s2 & 1][0][j], acc[i][j]);
                 }
             }
             if (STAGES == 2) {
@@ -742,7 +742,10 @@ int launch_halo(const woft_conv_params& p, hipStream_t s) {
     else if (p.taps_y == 1 && p.taps_x == 5) HALO_LAUNCH(1, 5, T, false);                       \
     else if (p.taps_y == 5 && p.taps_x == 1) HALO_LAUNCH(5, 1, T, false);                       \
     else return WOFT_EINVAL
-    if (p.precision == 1) { HALO_TAPS(3); } else { HALO_TAPS(1); }
+    if (p.precision == 1) { HALO_TAPS(3); } else if (p.precision == 3) {
+        if constexpr (TY == 9) return WOFT_EINVAL;       /* (the weight head keeps the split-bf16 arithmetic) */
+        else { HALO_TAPS(16); }
+    } else { HALO_TAPS(1); }
 #undef HALO_TAPS
 #undef HALO_LAUNCH
     return woft_launch_status();
@@ -948,6 +951,8 @@ int launch_conv(const woft_conv_params& p, const woft_conv_params* second, hipSt
     }
     if (p.precision == 1)
         woft_launch(0, conv_mfma_bf16_kernel<BM, BN, 3>, grid, dim3(256), 0, s, p, pb, split);
+    else if (p.precision == 3)
+        woft_launch(0, conv_mfma_bf16_kernel<BM, BN, 16>, grid, dim3(256), 0, s, p, pb, split);
     else
         woft_launch(0, conv_mfma_bf16_kernel<BM, BN, 1>, grid, dim3(256), 0, s, p, pb, split);
     return woft_launch_status();
@@ -959,7 +964,7 @@ int woft_conv_regb_launch(const woft_conv_params& p, const woft_conv_params* sec
 
 static int conv_check(const woft_conv_params& p) {
     if (p.in0 == nullptr || p.out == nullptr) return WOFT_EINVAL;
-    if (p.precision < 0 || p.precision > 2) return WOFT_EINVAL;
+    if (p.precision < 0 || p.precision > 3) return WOFT_EINVAL;
     if (p.precision == 0 && p.wgt == nullptr) return WOFT_EINVAL;
     if (p.precision >= 1 && p.wgt_hi == nullptr) return WOFT_EINVAL;
     if (p.precision == 1 && p.wgt_lo == nullptr) return WOFT_EINVAL;

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256, 2) void conv_regb_kernel(const woft_conv_param
         if (RH * 32 > HROWS && ht >= HROWS) return;
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
         const f32x4 val = hok[j] ? rh[hs][j] : zero;
-        const bf16x4 hi = __builtin_convertvector(val, bf16x4);
+        const bf16x4 hi = cvt16<TERMS>(val);
         *(bf16x4*)(As + ht * LDB + 4 * v) = hi;
         if (NP == 2) {
             const f32x4 rem = val - __builtin_convertvector(hi, f32x4);
@@ -203,13 +203,13 @@ __global__ __launch_bounds__(256, 2) void conv_regb_kernel(const woft_conv_param
                     store_halo_row(smem + ((chunk + 1) & 1) * A_ELEMS, std::integral_constant<int, (phase + 1) % HD>{},
                                    std::integral_constant<int, q - (NQ - RH)>{});
                 if (NP == 2) {
-                    acc[i0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[as][0][NP - 1], bq[slot][0][s2], acc[i0], 0, 0, 0);
-                    acc[i0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[as][1][NP - 1], bq[slot][0][s2], acc[i0 + 1], 0, 0, 0);
-                    acc[i0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[as][0][0], bq[slot][NP - 1][s2], acc[i0], 0, 0, 0);
-                    acc[i0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[as][1][0], bq[slot][NP - 1][s2], acc[i0 + 1], 0, 0, 0);
+                    acc[i0] = mma16<TERMS>(aq[as][0][NP - 1], bq[slot][0][s2], acc[i0]);
+                    acc[i0 + 1] = mma16<TERMS>(aq[as][1][NP - 1], bq[slot][0][s2], acc[i0 + 1]);
+                    acc[i0] = mma16<TERMS>(aq[as][0][0], bq[slot][NP - 1][s2], acc[i0]);
+                    acc[i0 + 1] = mma16<TERMS>(aq[as][1][0], bq[slot][NP - 1][s2], acc[i0 + 1]);
                 }
-                acc[i0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[as][0][0], bq[slot][0][s2], acc[i0], 0, 0, 0);
-                acc[i0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[as][1][0], bq[slot][0][s2], acc[i0 + 1], 0, 0, 0);
+                acc[i0] = mma16<TERMS>(aq[as][0][0], bq[slot][0][s2], acc[i0]);
+                acc[i0 + 1] = mma16<TERMS>(aq[as][1][0], bq[slot][0][s2], acc[i0 + 1]);
                 if constexpr (il_row) {
 #pragma unroll
                     for (int g = 0; g < (NP == 2 ? 6 : 2); ++g) {
@@ -288,8 +288,9 @@ __global__ __launch_bounds__(256, 2) void conv_regb_kernel(const woft_conv_param
                     const f32x4 b4 = bv[2 * s2 + q];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) yv[e] = fmaxf(p.alpha * yv[e] + b4[e], 0.f);
-                    const bf16x4 hi = __builtin_convertvector(yv, bf16x4);
-                    const bf16x4 lo = __builtin_convertvector(yv - __builtin_convertvector(hi, f32x4), bf16x4);
+                    const bf16x4 hi = cvt16<TERMS>(yv);
+                    bf16x4 lo = hi;
+                    if constexpr (NP == 2) lo = __builtin_convertvector(yv - __builtin_convertvector(hi, f32x4), bf16x4);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { ah[s2][4 * q + e] = hi[e]; al[s2][4 * q + e] = lo[e]; }
                 }
@@ -299,10 +300,10 @@ __global__ __launch_bounds__(256, 2) void conv_regb_kernel(const woft_conv_param
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 if (NP == 2) {
-                    sacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[s2], w2[s2][0], sacc[i], 0, 0, 0);
-                    sacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s2], w2[s2][NP - 1], sacc[i], 0, 0, 0);
+                    sacc[i] = mma16<TERMS>(al[s2], w2[s2][0], sacc[i]);
+                    sacc[i] = mma16<TERMS>(ah[s2], w2[s2][NP - 1], sacc[i]);
                 }
-                sacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s2], w2[s2][0], sacc[i], 0, 0, 0);
+                sacc[i] = mma16<TERMS>(ah[s2], w2[s2][0], sacc[i]);
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -358,7 +359,7 @@ int launch_regb(const woft_conv_params& p, const woft_conv_params* second, hipSt
             woft_launch(0, conv_regb_kernel<TY, TX, 1, 1, WM, T, 3, 2, 1, 3, 3, false>, grid, dim3(256), (size_t)g_regb_dyn_lds, s, p, pb, split); \
         else return WOFT_EINVAL;                                                                                                \
     } else return WOFT_EINVAL
-    if (p.precision == 1) { REGB_TAPS(3); } else { REGB_TAPS(1); }
+    if (p.precision == 1) { REGB_TAPS(3); } else if (p.precision == 3) { REGB_TAPS(16); } else { REGB_TAPS(1); }
 #undef REGB_TAPS
 #undef REGB
     return woft_launch_status();

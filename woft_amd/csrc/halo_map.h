@@ -9,6 +9,28 @@ constexpr int LDB = 40;      // bf16 tiles: elements per row (80 B: 16-B aligned
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
+// ---- fp16 operating point (precision 3; the reference's `mixed_precision`: autocast = fp16 on its CUDA devices,
+// weighted_raft.py:204,215,233) -- the split-bf16 kernels instantiated with TERMS = 16 run ONE product per MFMA on fp16
+// operands (v_mfma_f32_32x32x16_f16: bf16's rate, 3 more mantissa bits).  LDS tiles, weight planes and fragments are the
+// same 16-bit containers; only the two type-specific operations differ: the fp32 -> 16-bit conversion of the activations
+// and the MFMA opcode.  (fp16 saturates at 65504: the activations of this network -- normalised images, ReLU / tanh /
+// sigmoid outputs, correlations / sqrt(D), flow in pixels -- stay orders of magnitude below; weights are converted on the
+// host, which checks their range.)
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+template <int TERMS>
+__device__ __forceinline__ bf16x4 cvt16(const f32x4 v) {
+    if constexpr (TERMS == 16) return __builtin_bit_cast(bf16x4, __builtin_convertvector(v, f16x4));
+    else return __builtin_convertvector(v, bf16x4);
+}
+template <int TERMS>
+__device__ __forceinline__ f32x16 mma16(const bf16x8 a, const bf16x8 b, const f32x16 c) {
+    if constexpr (TERMS == 16)
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
 // ---- which pixel of the TY x TX patch each MFMA tile row holds ----------------------------------
 // ds_read_b128 serves a wave in four groups of 16 lanes -- {0-3,12-15,20-27}, {4-11,16-19,28-31} and the same +32
 // -- one LDS cycle per group when the 16 addresses fall into 16 different 16-byte slots of a 256-byte line.  The

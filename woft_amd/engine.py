@@ -98,7 +98,10 @@ class _Enc:
 
 class RaftEngine:
     def __init__(self, state_dict, small=False, weighted=True, precision="fp32", corr="volume", volume_storage=None):
-        """precision: "fp32" (exact fp32 MFMA), "bf16x3" (split-bf16, fp32-emulating) or "bf16".
+        """precision: "fp32" (exact fp32 MFMA), "bf16x3" (split-bf16, fp32-emulating), "bf16", or "fp16" = the reference's
+        `mixed_precision` scoping (weighted_raft.py:204-219,233-234,258-290: autocast around fnet, cnet and the update block
+        only): those convolutions on fp16 operands with fp32 accumulation, the correlation, the weight head and both
+        upsamplings in fp32-class arithmetic (bf16x3 here).
         corr: "volume" (all-pairs volume + pyramid in HBM, corr.py:13-69) or "otf" (volume-free lookup from the
         feature maps, the reference's alternate_corr idea, corr.py:72-100; split-bf16 precisions only).
         volume_storage: element type of the volume in HBM, "fp32" or "bf16" (fp32 accumulators rounded once at the GEMM's
@@ -111,6 +114,8 @@ class RaftEngine:
         if corr == "otf" and precision == "fp32":
             raise ValueError("corr='otf' runs on the split-bf16 matrix-core path: precision 'bf16x3' or 'bf16'")
         self.precision = precision
+        # arithmetic of the correlation (volume GEMM / volume-free lookup) and of the weight head's convolutions
+        self.prec_corr = self.prec_wh = "bf16x3" if precision == "fp16" else precision
         self.corr = corr
         self.volume_storage = volume_storage or ("bf16" if precision == "bf16" else "fp32")
         if self.volume_storage not in ("fp32", "bf16") or (self.volume_storage == "bf16" and precision == "fp32"):
@@ -135,7 +140,8 @@ class RaftEngine:
         self.fh1 = g("flow_head.conv1")
         self.fh2 = g("flow_head.conv2")
         # second conv of the flow head as MFMA fragments: folded into the first conv's epilogue (WOFT_EPI_FLOWHEAD)
-        self.fh2_frag = (ops.pack_flowhead_frags(sd[u + "flow_head.conv2.weight"], 2 if precision == "bf16x3" else 1)
+        self.fh2_frag = (ops.pack_flowhead_frags(sd[u + "flow_head.conv2.weight"], 2 if precision == "bf16x3" else 1,
+                                                 f16=precision == "fp16")
                          if precision != "fp32" and FUSE_FLOWHEAD else None)
         if small:
             self.zr = [ops.pack_conv(cat("gru.convz", "gru.convr", ".weight"), cat("gru.convz", "gru.convr", ".bias"))]
@@ -181,7 +187,7 @@ class RaftEngine:
             self.wh2 = ops.pack_conv(sd[w + "2.weight"], sd[w + "2.bias"])
             self.wh4 = ops.pack_conv(sd[w + "4.weight"], sd[w + "4.bias"])
             # first conv as MFMA fragments for the fused two-layer launch (split-bf16 precisions, 9x9 windows)
-            self.wh0_frag = (ops.pack_wh0_frags(sd[w + "0.weight"], 2 if precision == "bf16x3" else 1)
+            self.wh0_frag = (ops.pack_wh0_frags(sd[w + "0.weight"], 2 if self.prec_wh == "bf16x3" else 1)
                              if precision != "fp32" and self.spec.nwin == 9 else None)
             self.wh6_w = sd[w + "6.weight"].reshape(-1).contiguous().cuda()
             self.wh6_b = float(sd[w + "6.bias"].item())
@@ -222,7 +228,8 @@ class _Plan:
         # source features: rows padded to the 128-row GEMM tile (pad rows stay zero), + their bf16 hi/lo planes
         self.f1rows = z(_ru(P, 128), sp.fdim)
         self.f1 = Act(self.f1rows[:P], 1, hf, wf, sp.fdim)
-        x3 = self.prec == "bf16x3"
+        self.prec_corr, self.prec_wh = eng.prec_corr, eng.prec_wh
+        x3 = self.prec_corr == "bf16x3"
         bf = lambda rows: (torch.zeros(rows.shape[0], rows.shape[1] * (2 if x3 else 1), dtype=torch.bfloat16, device=dev)
                            if self.prec != "fp32" else None)       # GEMM operand: [hi|lo] lines / bf16 plane
         self.f1s = bf(self.f1rows)
@@ -308,7 +315,7 @@ class _Plan:
             # windows (woft_wh_conv0), the generic conv on the packed x8 patches otherwise
             self.wh0_direct = n in (7, 9)
             self.wh0_fused = (eng.wh0_frag is not None and os.environ.get("WOFT_WH0_FUSED", "1") != "0"
-                              and cp(self.a2, eng.wh2, self.a2, epi=EPI.EPI_RELU).halo == 2)
+                              and cp(self.a2, eng.wh2, self.a2, epi=EPI.EPI_RELU, precision=self.prec_wh).halo == 2)
             # (with the first layer AND the tail fused into the two 128->128 launches only ONE activation exists)
             self.a1 = self.a2 if self.wh0_fused else new_act(P, n, n, 128)
             self.wh0_t = eng.wh0.wgt[:128].t().contiguous()          # [ky*32 + kx*8 + ci][co]
@@ -323,7 +330,8 @@ class _Plan:
         """Launch list of the head's 128->128 layers on n_win windows (all source pixels, or those listed in the
         int32 tensor `index`) -> (program, fused): fused = the last layer runs on the whole-window kernel with
         ReLU + 1x1 conv + window mean in its epilogue."""
-        eng, cp, n = self.eng, self._cp, self.eng.spec.nwin
+        eng, n = self.eng, self.eng.spec.nwin
+        cp = lambda *a, **kw: self._cp(*a, precision=self.prec_wh, **kw)          # (fp32-class also in the fp16 mode)
         a1 = Act(self.a1.t[:n_win * n * n], n_win, n, n, 128)
         a2 = Act(self.a2.t[:n_win * n * n], n_win, n, n, 128)
         prog = ([] if self.wh0_direct else [cp(self.x8, eng.wh0, a1, epi=EPI.EPI_RELU)]) + [
@@ -449,7 +457,7 @@ class _Plan:
         sp = self.eng.spec
         prog = []
         alpha = 1.0 / math.sqrt(float(sp.fdim))
-        x3 = self.prec == "bf16x3"
+        x3 = self.prec_corr == "bf16x3"
         for l in range(sp.levels):
             if l > 0:
                 prog.append(("pool", (self.f2act[l - 1], self.f2act[l])))
@@ -604,7 +612,7 @@ class _Plan:
 
     def _split(self, rows, out):
         """fp32 rows -> the correlation GEMM's bf16 operand: [hi | lo] lines (bf16x3) or the bf16 plane (bf16)."""
-        if self.prec == "bf16x3":
+        if self.prec_corr == "bf16x3":
             ops.split_bf16_lines(rows, out)
         else:
             ops.split_bf16(rows, out, None)

@@ -64,10 +64,11 @@ class RAFTWrapper:
         weighted = self.C.raft_type == "weighted"
         small = bool(cp.small)
         # arithmetic of the convolutions / correlation GEMM: "fp32" (exact fp32 MFMA, the reference's
-        # precision class), "bf16x3" (split-bf16 operands, fp32 accumulation: fp32-emulating) or "bf16".
-        # `mixed_precision=True` (autocast in the reference, weighted_raft.py:204,215,233) selects "bf16".
+        # precision class), "bf16x3" (split-bf16 operands, fp32 accumulation: fp32-emulating), "bf16", or "fp16".
+        # `mixed_precision=True` selects "fp16" with the reference's scoping (autocast = fp16 around fnet, cnet and the
+        # update block only, weighted_raft.py:204-219,233-234; correlation, weight head and upsampling stay fp32-class).
         self.precision = os.environ.get("WOFT_PRECISION") or self.C.precision or \
-            ("bf16" if cp.mixed_precision else "fp32")
+            ("fp16" if cp.mixed_precision else "fp32")
         # correlation: "volume" (all-pairs volume + pyramid in HBM, corr.py:13-69) or "otf" (volume-free lookup, what
         # the reference's `alternate_corr` switch selects, corr.py:72-100).  Bit-identical results in the split-bf16
         # precisions, where "otf" is faster and needs no P x P buffer: it is the default there.

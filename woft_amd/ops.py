@@ -80,19 +80,33 @@ class PackedConv:
     wgt_hi: torch.Tensor = None   # bf16 split of wgt: hi = bf16(w), lo = bf16(w - hi)
     wgt_lo: torch.Tensor = None
     _frag: dict = None            # planes -> weights in MFMA-fragment order (woft_conv_params.wgt_frag), built on demand
+    _f16: torch.Tensor = None     # fp16(w) in a bf16-typed container (precision "fp16"), built on demand
 
-    def frag(self, planes):
-        """[cout_pad/32 bands][chunks][taps][planes][2 k halves][64 lanes][8] bf16 (see woft_conv_params.wgt_frag)."""
+    def wgt_f16(self):
+        if self._f16 is None:
+            w = self.wgt.detach().cpu()
+            if float(w.abs().max()) >= 65504.0:
+                raise ValueError("precision 'fp16': a weight exceeds the fp16 range")
+            self._f16 = w.to(torch.float16).view(torch.bfloat16).to(self.wgt.device)
+        return self._f16
+
+    def frag(self, planes, f16=False):
+        """[cout_pad/32 bands][chunks][taps][planes][2 k halves][64 lanes][8] bf16 (see woft_conv_params.wgt_frag);
+        f16: one plane of fp16 values in the same 16-bit containers (precision "fp16")."""
         if self._frag is None:
             self._frag = {}
-        if planes not in self._frag:
+        key = "f16" if f16 else planes
+        if key not in self._frag:
             taps, nchunk = self.taps_y * self.taps_x, self.cin_pad // 32
             w = self.wgt.detach().cpu().reshape(self.cout_pad // 32, 32, taps, nchunk, 2, 2, 8)
             w = w.permute(0, 3, 2, 4, 5, 1, 6).contiguous()        # band, chunk, tap, k half, lane half, row, e
-            hi = w.to(torch.bfloat16)
-            pl = [hi] + ([(w - hi.float()).to(torch.bfloat16)] if planes == 2 else [])
-            self._frag[planes] = torch.stack(pl, dim=3).contiguous().to(self.wgt.device)
-        return self._frag[planes]
+            if f16:
+                pl = [w.to(torch.float16).view(torch.bfloat16)]
+            else:
+                hi = w.to(torch.bfloat16)
+                pl = [hi] + ([(w - hi.float()).to(torch.bfloat16)] if planes == 2 else [])
+            self._frag[key] = torch.stack(pl, dim=3).contiguous().to(self.wgt.device)
+        return self._frag[key]
 
     def __post_init__(self):
         if self.wgt is not None and self.wgt_hi is None and self.wgt.dtype == torch.float32:
@@ -153,7 +167,7 @@ def fold_bn(weight, bias, bn_w, bn_b, mean, var, eps=1e-5):
     return w, b
 
 
-PRECISION = {"fp32": 0, "bf16x3": 1, "bf16": 2}
+PRECISION = {"fp32": 0, "bf16x3": 1, "bf16": 2, "fp16": 3}
 USE_HALO = os.environ.get("WOFT_HALO", "1") != "0"
 USE_REGB = os.environ.get("WOFT_REGB", "1") != "0"
 USE_REGB1 = os.environ.get("WOFT_REGB1", "0") != "0"      # (measured: 45 vs 37 us on convc1 -- the 64 x 64 gather tiles win)
@@ -199,6 +213,8 @@ def conv_params(x, pc, out, co_off=0, epi=_lib.EPI_LINEAR, x2=None, c_split=0, e
     p.cin_pad, p.flat = pc.cin_pad, pc.flat
     p.wgt, p.bias, p.alpha = ptr(pc.wgt), ptr(pc.bias), alpha
     p.wgt_hi, p.wgt_lo, p.precision = ptr(pc.wgt_hi), ptr(pc.wgt_lo), PRECISION.get(precision, precision)
+    if p.precision == 3:                # fp16 operands: the weight plane holds fp16 values
+        p.wgt_hi, p.wgt_lo = ptr(pc.wgt_f16()), None
     p.cout, p.cout_pad = (cout or pc.cout), pc.cout_pad
     p.out, p.ldo, p.co_off = ptr(out.t), out.cs, co_off
     p.out_w, p.out_pitch = 0, 0
@@ -233,7 +249,7 @@ def conv_params(x, pc, out, co_off=0, epi=_lib.EPI_LINEAR, x2=None, c_split=0, e
                 # 8x16 by 1.5-3x): take the 8x16 pixel tile only while it still yields ~2 workgroups per CU, else 4x16.
                 b816 = x.n * math.ceil(ho / 8) * math.ceil(wo / 16)
                 auto = tiles is None
-                if auto and p.precision == PRECISION["bf16"]:
+                if auto and p.precision in (PRECISION["bf16"], PRECISION["fp16"]):
                     # plain bf16 (one LDS plane, fewer registers): 64-channel column tiles win throughout --
                     # 8x16 x 64 for the 256-wide layers (~1000 workgroups), 4x16 x 64 for the narrower ones
                     tn = 64
@@ -279,7 +295,7 @@ def conv_params(x, pc, out, co_off=0, epi=_lib.EPI_LINEAR, x2=None, c_split=0, e
     if halo in (8, 12):                 # weights streamed to registers in MFMA-fragment order (conv_regb.hip)
         assert p.precision != 0 and not pc.flat and pc.stride == 1 and not in_norm
         assert (pc.taps_y, pc.taps_x) in ((3, 3), (1, 5), (5, 1), (1, 1)) and (ho, wo) == (x.h, x.w)
-        frag = pc.frag(2 if p.precision == 1 else 1)
+        frag = pc.frag(2 if p.precision == 1 else 1, f16=p.precision == 3)
         p.wgt_frag = ptr(frag)
         if tiles is None and p.tile_n not in (64, 128):
             p.tile_n = 128 if pc.cout_pad % 128 == 0 else 64
@@ -326,7 +342,7 @@ def pack_wh0_frags(w0, planes):
     return torch.stack(pl, dim=2).contiguous().to(DEV)
 
 
-def pack_flowhead_frags(w2, planes):
+def pack_flowhead_frags(w2, planes, f16=False):
     """FlowHead.conv2 weight (2, C, 3, 3) (update.py:11) -> bf16 MFMA B fragments [C/32 bands][2 k halves][planes][64 lanes][8]
     for WOFT_EPI_FLOWHEAD: lane = 32 * hh + j, column j = (3 ky + kx) * 2 + o (18 of 32 used), element e = channel
     32 band + 16 (k half) + 8 hh + e."""
@@ -336,6 +352,8 @@ def pack_flowhead_frags(w2, planes):
     cols = torch.zeros(32, c)
     cols[:18] = w2.permute(2, 3, 0, 1).reshape(18, c)                 # row j = (ky * 3 + kx) * 2 + o
     f = cols.reshape(32, c // 32, 2, 2, 8).permute(1, 2, 3, 0, 4).reshape(c // 32, 2, 64, 8)   # band, k half, (hh, j), e
+    if f16:                             # precision "fp16": one plane of fp16 values in the 16-bit containers
+        return f.to(torch.float16).view(torch.bfloat16).reshape(c // 32, 2, 1, 64, 8).contiguous().to(DEV)
     hi = f.to(torch.bfloat16)
     pl = [hi] + ([(f - hi.float()).to(torch.bfloat16)] if planes == 2 else [])
     return torch.stack(pl, dim=2).contiguous().to(DEV)
