@@ -164,7 +164,8 @@ int woft_flow_head_update(const float* in, int32_t cs, int32_t h, int32_t w, int
                           float* flow_cat, int32_t ld_cat, void* stream);
 /* Second half of the flow head when its first conv ran with WOFT_EPI_FLOWHEAD: delta[q][o] = bias2[o] + sum over the
  * 3x3 taps (ky, kx) and the n_planes column-tile planes of part[(plane * h * w + q + (ky-1) * w + (kx-1)) * ld +
- * (ky * 3 + kx) * 2 + o] (pixels outside the image contribute nothing: zero padding, update.py:14), in a fixed order;
+ * (ky * 3 + kx) * 2 + o] (ld >= 20, % 4 == 0; pixels outside the image contribute nothing: zero padding, update.py:14; planes
+ * first, then taps, in a fixed order);
  * then, exactly as woft_flow_head_update: delta stored, coords1 += delta, flow = coords1 - grid written to flow4 /
  * flow_cat (optional).  One image of h x w pixels. */
 int woft_flow_head_gather(const float* part, int32_t n_planes, int32_t ld, int32_t h, int32_t w, const float* bias2,

@@ -134,41 +134,56 @@ __global__ __launch_bounds__(256) void conv3x3_narrow_kernel(const float* __rest
     }
 }
 
-// woft_flow_head_gather: one thread per pixel; 9 taps x n_planes 8-byte loads (both output channels of a tap)
-__global__ __launch_bounds__(256) void flow_head_gather_kernel(const float* __restrict__ part, int n_planes, int ld, int h, int w,
-                                                               const float* __restrict__ bias2, float* __restrict__ delta,
-                                                               int64_t ld_delta, float* __restrict__ coords1,
-                                                               float* __restrict__ flow4, float* __restrict__ flow_cat,
-                                                               int ld_cat) {
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= h * w) return;
-    const int y = i / w, x = i - y * w;
-    float dx = bias2 ? bias2[0] : 0.f, dy = bias2 ? bias2[1] : 0.f;
+// woft_flow_head_gather: a workgroup owns a run of GT pixels of one image row.  The partial products of the run's 3 x (GT + 2)
+// neighbourhood are summed over the column-tile planes while they are copied to LDS with fully coalesced 16-byte loads (a
+// pixel's 18 values are 80 contiguous bytes: read per pixel from 9 neighbours they were 9 x planes scattered 8-byte loads per
+// thread, 10.5 us for 5 MB), then every thread adds its 9 taps from LDS in a fixed order.
+constexpr int GT = 128;
+__global__ __launch_bounds__(GT) void flow_head_gather_kernel(const float* __restrict__ part, int n_planes, int ld, int h, int w,
+                                                              const float* __restrict__ bias2, float* __restrict__ delta,
+                                                              int64_t ld_delta, float* __restrict__ coords1,
+                                                              float* __restrict__ flow4, float* __restrict__ flow_cat,
+                                                              int ld_cat) {
+    constexpr int LD = 20;                               // floats kept per pixel (18 + 2)
+    __shared__ __attribute__((aligned(16))) float nb[3][(GT + 2) * LD];
+    const int runs = (w + GT - 1) / GT;
+    const int y = blockIdx.x / runs, x0 = (blockIdx.x - y * runs) * GT;
     const int64_t plane = (int64_t)h * w * ld;
+    for (int i = threadIdx.x; i < 3 * (GT + 2) * (LD / 4); i += GT) {
+        const int r = i / ((GT + 2) * (LD / 4)), rem = i - r * ((GT + 2) * (LD / 4));
+        const int px = rem / (LD / 4), c4 = (rem - px * (LD / 4)) * 4;
+        const int yy = y + r - 1, xx = x0 + px - 1;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (yy >= 0 && yy < h && xx >= 0 && xx < w) {    // (outside the image: zero padding, update.py:14)
+            const float* src = part + ((int64_t)yy * w + xx) * ld + c4;
+            v = *(const f32x4*)src;
+            for (int t = 1; t < n_planes; ++t) v += *(const f32x4*)(src + t * plane);
+        }
+        *(f32x4*)(&nb[r][px * LD + c4]) = v;
+    }
+    __syncthreads();
+    const int x = x0 + threadIdx.x;
+    if (x >= w) return;
+    float dx = bias2 ? bias2[0] : 0.f, dy = bias2 ? bias2[1] : 0.f;
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
-            const int yy = y + ky - 1, xx = x + kx - 1;
-            if (yy < 0 || yy >= h || xx < 0 || xx >= w) continue;
-            const float* src = part + ((int64_t)yy * w + xx) * ld + (ky * 3 + kx) * 2;
-            for (int t = 0; t < n_planes; ++t) {
-                const f32x2 v = *(const f32x2*)(src + t * plane);
-                dx += v[0];
-                dy += v[1];
-            }
+            const float* v = &nb[ky][(threadIdx.x + kx) * LD + (ky * 3 + kx) * 2];
+            dx += v[0];
+            dy += v[1];
         }
+    const int64_t i = (int64_t)y * w + x;
     delta[i * ld_delta] = dx;
     delta[i * ld_delta + 1] = dy;
     const float cx = coords1[i * 2] + dx, cy = coords1[i * 2 + 1] + dy;
     coords1[i * 2] = cx;
     coords1[i * 2 + 1] = cy;
     const float fx = cx - (float)x, fy = cy - (float)y;
-    if (flow4 != nullptr) *(f32x4*)(flow4 + (int64_t)i * 4) = f32x4{fx, fy, 0.f, 0.f};
+    if (flow4 != nullptr) *(f32x4*)(flow4 + i * 4) = f32x4{fx, fy, 0.f, 0.f};
     if (flow_cat != nullptr) {
-        flow_cat[(int64_t)i * ld_cat] = fx;
-        flow_cat[(int64_t)i * ld_cat + 1] = fy;
+        flow_cat[i * ld_cat] = fx;
+        flow_cat[i * ld_cat + 1] = fy;
     }
 }
 
@@ -177,10 +192,10 @@ __global__ __launch_bounds__(256) void flow_head_gather_kernel(const float* __re
 extern "C" int woft_flow_head_gather(const float* part, int32_t n_planes, int32_t ld, int32_t h, int32_t w, const float* bias2,
                                      float* delta, int64_t ld_delta, float* coords1, float* flow4, float* flow_cat,
                                      int32_t ld_cat, void* stream) {
-    if (!part || !delta || !coords1 || n_planes < 1 || ld < 18 || ld % 2 != 0 || h <= 0 || w <= 0 || ld_delta < 2 ||
+    if (!part || !delta || !coords1 || n_planes < 1 || ld < 20 || ld % 4 != 0 || h <= 0 || w <= 0 || ld_delta < 2 ||
         (flow_cat != nullptr && ld_cat < 2) || (int64_t)h * w >= (1ll << 31))
         return WOFT_EINVAL;
-    hipLaunchKernelGGL(flow_head_gather_kernel, dim3((unsigned)ceil_div64((int64_t)h * w, 256)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(flow_head_gather_kernel, dim3((unsigned)((int64_t)h * ((w + GT - 1) / GT))), dim3(GT), 0, (hipStream_t)stream,
                        part, n_planes, ld, h, w, bias2, delta, ld_delta, coords1, flow4, flow_cat, ld_cat);
     return woft_launch_status();
 }

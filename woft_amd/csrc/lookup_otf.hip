@@ -20,6 +20,17 @@
 #include "common.h"
 #include "dma.h"
 
+// build-time switches of two round-3 experiments (compile this file with -DOTF_IL=0/1 -DOTF_SAMPLE_UNROLL=n).  Measured at
+// 1080p feature size (tools/bench_lookup_otf.py, one GPU call): round-2 kernel 85.4 us; centre read before the A fragments +
+// no spilled LDS addresses 82.0 us (per-level set-up 2.8 k -> 0.6 k cycles); the same with OTF_IL = 1: 88.3 us -- the
+// pieces of group g + 2 then leave up to a group later and the stream's lead shrinks; sampling unroll 3 vs 21: +-0
+#ifndef OTF_IL
+#define OTF_IL 0                 // 1: DMA pieces issued one per k sub-step instead of four in a row after the barrier
+#endif
+#ifndef OTF_SAMPLE_UNROLL
+#define OTF_SAMPLE_UNROLL 3      // unroll factor of the sampling loop (21: fully unrolled)
+#endif
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -49,6 +60,7 @@ __global__ __launch_bounds__(TW * 32, 2) void corr_lookup_otf_kernel(const woft_
     __shared__ __attribute__((aligned(16))) float Wn[NPX * WLD];                     // the windows of the source pixels at the current level
     __shared__ int2 s_w0[NPX];                          // window origin (x, y) of every source pixel at the current level
     __shared__ float s_fx[NPX], s_fy[NPX];
+    __shared__ float2 s_cc[NPX];                         // lookup centre of every source pixel (level 0 units)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -74,6 +86,19 @@ __global__ __launch_bounds__(TW * 32, 2) void corr_lookup_otf_kernel(const woft_
         if (!__syncthreads_or(any)) return;
     }
 
+    // lookup centre of source pixel `tid` (threads < NPX), read once: it is the same at every level.  Requested BEFORE the
+    // A fragments (loads return in order: waiting for it must not wait for the 64 KB of source features behind it) and kept
+    // in LDS, not in registers: across the level loop the compiler spilled it to scratch -- four scratch reloads per level,
+    // each followed by s_waitcnt vmcnt(0) (round-3 reading of the ISA: ~2 k cycles of every level's set-up)
+    if (tid < NPX) {
+        const int y = py0 + (tid >> TSH), x = px0 + (tid & (TW - 1));
+        float cx = 0.f, cy = 0.f;
+        if (y < p.hf && x < p.wf) {
+            cx = p.coords[((int64_t)y * p.wf + x) * 2];
+            cy = p.coords[((int64_t)y * p.wf + x) * 2 + 1];
+        }
+        s_cc[tid] = make_float2(cx, cy);
+    }
     // The block's source features stay in REGISTERS for the whole kernel, as the MFMA A fragments of this wave's
     // 32 rows (lane (r32, hh): row r32, k = 8 (2 s + hh) .. + 7 of every line; hi and lo halves of the line) -- the
     // first version re-fetched the A tile with every 64-column chunk and was bound by that L2 -> LDS traffic.
@@ -113,23 +138,19 @@ __global__ __launch_bounds__(TW * 32, 2) void corr_lookup_otf_kernel(const woft_
     const bool pvalid = gy < p.hf && gx < p.wf;
     constexpr int NS = (N2 + 3) / 4;                    // samples per thread
 
-    // lookup centre of source pixel `tid` (threads < NPX), read once: it is the same at every level
-    float ccx = 0.f, ccy = 0.f;
-    bool cvalid = false;
-    if (tid < NPX) {
-        const int y = py0 + (tid >> TSH), x = px0 + (tid & (TW - 1));
-        cvalid = y < p.hf && x < p.wf;
-        if (cvalid) {
-            ccx = p.coords[((int64_t)y * p.wf + x) * 2];
-            ccy = p.coords[((int64_t)y * p.wf + x) * 2 + 1];
-        }
-    }
-
     for (int l = 0; l < p.levels; ++l) {
         const int W = p.w[l], H = p.h[l];
         if (tid < NPX) {
             int wx0 = 0x3fffffff, wy0 = 0x3fffffff;     // (outside the grid: excluded from the box)
             float fx = 0.f, fy = 0.f;
+            // (the index is laundered so that the four LDS addresses below are recomputed here -- one shift each, the array
+            //  bases are instruction immediates: hoisted out of the level loop at 256 registers they were SPILLED, and every
+            //  level began with four scratch reloads, each behind an s_waitcnt vmcnt(0))
+            int t = tid;
+            asm volatile("" : "+v"(t));
+            const float2 cc = s_cc[t];                   // (written by this same thread)
+            const float ccx = cc.x, ccy = cc.y;
+            const bool cvalid = py0 + (t >> TSH) < p.hf && px0 + (t & (TW - 1)) < p.wf;
             if (cvalid) {
                 const float sc = 1.0f / (float)(1 << l);
                 const float xs = ccx * sc, ys = ccy * sc;
@@ -141,7 +162,7 @@ __global__ __launch_bounds__(TW * 32, 2) void corr_lookup_otf_kernel(const woft_
                 wx0 = (int)flx - R;
                 wy0 = (int)fly - R;
             }
-            s_w0[tid] = make_int2(wx0, wy0); s_fx[tid] = fx; s_fy[tid] = fy;
+            s_w0[t] = make_int2(wx0, wy0); s_fx[t] = fx; s_fy[t] = fy;
         }
         stamp();
         __syncthreads();
@@ -189,21 +210,25 @@ __global__ __launch_bounds__(TW * 32, 2) void corr_lookup_otf_kernel(const woft_
         const int S = nchunk * nk;
         uint32_t b_off[2] = {0u, 0u};
         int is_c = 0, is_k = 0;                          // (chunk, k step) of the next step to request
-        auto issue = [&](int s_idx) {
-            if (is_k == 0) {                             // new chunk: rows of the box positions c0 .. c0 + 63
+        // one DMA piece (t of QPW) of step s_idx; the pieces of a step are issued in order, t = 0 first
+        auto issue_piece = [&](int s_idx, int t) {
+            if (t == 0 && is_k == 0) {                   // new chunk: rows of the box positions c0 .. c0 + 63
 #pragma unroll
-                for (int t = 0; t < QPW; ++t) {
-                    int pos = is_c * 64 + (wave + NWV * t) * 8 + (lane >> 3);
+                for (int tt = 0; tt < QPW; ++tt) {
+                    int pos = is_c * 64 + (wave + NWV * tt) * 8 + (lane >> 3);
                     pos = pos < N ? pos : N - 1;        // (columns past the box repeat its last position; never read)
                     const int by = pos / bw, bx = pos - by * bw;
-                    b_off[t] = (uint32_t)((by0 + by) * W + bx0 + bx) * (uint32_t)(ld * 2) + chunk_off;
+                    b_off[tt] = (uint32_t)((by0 + by) * W + bx0 + bx) * (uint32_t)(ld * 2) + chunk_off;
                 }
             }
             const uint32_t st = st_addr + (uint32_t)(s_idx % NST) * 8192u;
             if (!(p.ablate & 1) || s_idx < NST)
+                lds_dma16(f2 + is_k * 128, b_off[t], st + (uint32_t)(wave + NWV * t) * 1024u);
+            if (t == QPW - 1 && ++is_k == nk) { is_k = 0; ++is_c; }
+        };
+        auto issue = [&](int s_idx) {
 #pragma unroll
-            for (int t = 0; t < QPW; ++t) lds_dma16(f2 + is_k * 128, b_off[t], st + (uint32_t)(wave + NWV * t) * 1024u);
-            if (++is_k == nk) { is_k = 0; ++is_c; }
+            for (int t = 0; t < QPW; ++t) issue_piece(s_idx, t);
         };
         const int G = S / GS;                            // groups of GS steps (S = nchunk * NK, NK % GS == 0)
         for (int g = 0; g < DEPTH && g < G; ++g)
@@ -223,7 +248,10 @@ __global__ __launch_bounds__(TW * 32, 2) void corr_lookup_otf_kernel(const woft_
                 if (rem >= DEPTH - 1) dma_wait<(DEPTH - 1) * GS * QPW>();
                 else dma_wait<0>();
                 __syncthreads();                         // ... for every wave; and group g - 1 is fully consumed
-                if (g + DEPTH < G) {                     // into the stages of group g - 1
+                // the GS * QPW pieces of group g + DEPTH go into the stages of group g - 1, all of them right after the barrier
+                // (OTF_IL = 1, one per k sub-step between the fragment reads and the MFMAs, measured 6 us slower: see above)
+                const bool feed = g + DEPTH < G;
+                if (feed && (!OTF_IL || (p.ablate & 2))) {
 #pragma unroll
                     for (int e = 0; e < GS; ++e) issue((g + DEPTH) * GS + e);
                 }
@@ -247,6 +275,11 @@ __global__ __launch_bounds__(TW * 32, 2) void corr_lookup_otf_kernel(const woft_
                             const int ks = kg * GS + e;
                             if constexpr (u + 1 < NU) load_b(std::integral_constant<int, u + 1>{});
                             __builtin_amdgcn_sched_barrier(0);
+                            constexpr int NPC = GS * QPW;          // pieces per group, spread evenly over the NU sub-steps
+                            if constexpr (u % (NU / NPC) == 0) {
+                                constexpr int pc = u / (NU / NPC);
+                                if (OTF_IL && feed) issue_piece((g + DEPTH) * GS + pc / QPW, pc % QPW);
+                            }
                             const bf16x8 bh = bq[u & 1][0];
                             if (TERMS == 3) {
                                 const bf16x8 bl = bq[u & 1][TERMS == 3 ? 1 : 0];
@@ -294,7 +327,7 @@ __global__ __launch_bounds__(TW * 32, 2) void corr_lookup_otf_kernel(const woft_
             const float fx = s_fx[mypix], fy = s_fy[mypix];
             const float* wq = Wn + mypix * WLD;
             float* o = p.out + ((int64_t)gy * p.wf + gx) * p.ldo + l * N2;
-#pragma unroll
+#pragma unroll OTF_SAMPLE_UNROLL                        // (fully unrolled, its 21 x 2 hoisted offsets cost spills at 256 registers)
             for (int k = 0; k < NS; ++k) {
                 const int s = part + 4 * k;
                 if (s >= N2) break;
