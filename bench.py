@@ -183,12 +183,20 @@ def main():
     plan = tracker.flower.engine.plan(H, W)
     corr_mode = tracker.flower.engine.corr
 
-    def track_all(trk, first, n):
-        """Track frames[first : first + n] (0-based index i = frame t - 1; a new clip starts where i % CLIP == 0)."""
+    EVENT_EVERY = 4        # frames between two frames whose dominant-kernel launches carry HIP events (see below)
+
+    def track_all(trk, first, n, timed=None):
+        """Track frames[first : first + n] (0-based index i = frame t - 1; a new clip starts where i % CLIP == 0).
+        timed = (plan, wh_events, conv_events): the per-launch HIP events of the roofline fields are recorded on every
+        EVENT_EVERY-th frame of the span only -- an event record is a stream barrier packet (kernel trace: 6-8 us of idle
+        matrix pipes per timed launch, 38 timed launches per frame = 3 % of the frame time the events are there to explain)."""
         res = []
         for i in range(first, first + n):
             if i > 0 and i % CLIP == 0:
                 restart_clip(trk)
+            if timed is not None:
+                on = (i - first) % EVENT_EVERY == 0
+                timed[0].wh_events, timed[0].conv_events = (timed[1], timed[2]) if on else (None, None)
             res.append(trk.track(frames[i % CLIP]))
         return res
 
@@ -201,11 +209,11 @@ def main():
     # (HIP events are stream-ordered barriers: the volume-free lookup, not this mode's roofline kernel, is timed in isolation
     #  below -- 'lookup_otf_by_flow_field' -- instead of inside the timed region)
     plan.lookup_events = [] if corr_mode == "volume" else None
-    plan.wh_events, plan.conv_events = [], {t: [] for t in ROOF_TAGS}
+    wh_events, conv_events = [], {t: [] for t in ROOF_TAGS}
     wdist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    results += track_all(tracker, Wm, K)
+    results += track_all(tracker, Wm, K, timed=(plan, wh_events, conv_events))
     tracks = wdist.gather_tracks(results[Wm:])
     torch.cuda.synchronize()
     wdist.barrier()
@@ -213,7 +221,7 @@ def main():
     per_rank = wdist.gather_floats([elapsed, binding.get("numa_node") if binding.get("numa_node") is not None else -1,
                                     binding.get("cores") or 0, float(bool(binding.get("bound")))])
     elapsed = wdist.max_over_ranks(elapsed)
-    events, wh_events, conv_events = plan.lookup_events, plan.wh_events, plan.conv_events
+    events = plan.lookup_events
     plan.lookup_events = plan.wh_events = plan.conv_events = None
 
     if rank != 0:
@@ -344,6 +352,8 @@ def main():
         # volume-free correlation: no HBM-bound lookup on the path; the dominant kernel is a matrix-core conv
         # (the volume lookup's HBM roofline is measured in the 'alt_corr' pass below -> 'roofline_lookup')
         out["roofline"] = conv_roofline(conv_events, layers)
+    if "roofline" in out and corr_mode != "volume":
+        out["roofline"]["events_on_every_nth_frame"] = EVENT_EVERY
     if bool(getattr(plan, "prog_wh", None)) and wh_events:
         out["roofline_weight_head"] = wh_roofline(wh_events, plan.prog_wh[0], plan.P)
     tc_gpu = {}

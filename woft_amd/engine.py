@@ -303,6 +303,13 @@ class _Plan:
             self.mk = new_act(1, hf, wf, 256, zero=True)
             self.mask = new_act(1, hf, wf, 576, zero=True)
             self.prog_mask = [cp(self.hB, eng.mk1, self.mk, epi=EPI.EPI_RELU), cp(self.mk, eng.mk2, self.mask)]
+            # last iteration: the flow head's conv and the mask head's first conv both read the final GRU state and are
+            # independent (update.py:132-135) -> one launch when they select the same kernel instance (woft_conv2d_pair)
+            self.prog_iter_last = None
+            k = next((i for i, ent in enumerate(self.prog_iter) if len(ent) > 2 and ent[2] == "fh1"), None)
+            if PAIR_BRANCHES and k is not None and ops.pair_ok(self.prog_iter[k][1], self.prog_mask[0]):
+                self.prog_iter_last = (self.prog_iter[:k] + [("conv2", (self.prog_iter[k][1], self.prog_mask[0]), "fh1+mk1")]
+                                       + self.prog_iter[k + 1:])
         if eng.weighted:
             n = sp.nwin
             self.x8 = new_act(P, n, n, 5, cs=8, zero=True)
@@ -641,11 +648,12 @@ class _Plan:
         self.run(self.prog_volume)
         off = sp.flow_off
         ops.coords_init(self.coords, self.hf, self.wf, self.flow4.t, self.xbuf.t[:, off:], self.xbuf.cs)
+        last = getattr(self, "prog_iter_last", None) if iters > 1 else None
         for it in range(iters):
-            self.run(self.prog_iter_first if it == 0 else self.prog_iter)
+            self.run(self.prog_iter_first if it == 0 else (last if (last is not None and it == iters - 1) else self.prog_iter))
             if trace is not None:
                 trace(self, it)
-        for p in self.prog_mask:
+        for p in (self.prog_mask[1:] if last is not None else self.prog_mask):
             ops.run_conv(p)
         wlow = None
         if defer_wh:

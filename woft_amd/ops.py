@@ -605,8 +605,7 @@ def warp_perspective_u8(img, Hmat, out=None, valid=None, nearest=False):
     """img: (H,W,C) or (H,W) uint8 CUDA tensor; Hmat: 3x3 numpy (src -> dst).  dst(x) = src(H^-1 x)."""
     h, w = img.shape[:2]
     c = 1 if img.dim() == 2 else img.shape[2]
-    hinv = np.ascontiguousarray(np.linalg.inv(np.asarray(Hmat, dtype=np.float64)).reshape(9))
-    arr = (C.c_double * 9)(*hinv.tolist())
+    arr = (C.c_double * 9)(*np.linalg.inv(np.asarray(Hmat, dtype=np.float64)).ravel().tolist())
     check(_lib.load().woft_warp_perspective_u8(ptr(img), h, w, c, arr, ptr(out), ptr(valid), int(nearest),
                                                stream_ptr()), "woft_warp_perspective_u8")
 

@@ -257,8 +257,13 @@ class YAOFTrackerSingleControl:
         if np.array_equal(prewarp_H, _EYE):
             prewarped = frame                                        # identity warp: same image, every pixel filled
         else:
-            prewarped = torch.empty_like(frame)
-            valid = torch.empty(frame.shape[:2], dtype=torch.uint8, device=self.device)
+            # (two per-size buffers, reused: consumed by the flow / the selection before the next frame's warp is enqueued on
+            #  the same stream; allocating them per frame was ~15 us of host time in front of the frame's first kernel)
+            key = tuple(frame.shape)
+            if getattr(self, "_pw_key", None) != key:
+                self._pw_buf = (torch.empty_like(frame), torch.empty(frame.shape[:2], dtype=torch.uint8, device=self.device))
+                self._pw_key = key
+            prewarped, valid = self._pw_buf
             ops.warp_perspective_u8(frame, prewarp_H, prewarped, valid)
         if self.C.do_not_mask_TCs_by_prewarped:
             valid = None
@@ -312,11 +317,18 @@ class YAOFTrackerSingleControl:
         ops.hfit(b["pa"], b["pb"], b["w"], res[0:9], ires[10:11], count=ires[12:13], reweight=F["reweight"],
                  huber_k=F["huber_k"], n_irls=F["n_irls"], ws=b["fit_ws"])
         ops.inlier_frac(b["pa"], b["pb"], res[0:9], res[9:10], thr=F["thr"], count=ires[12:13])
-        host = res.cpu()                                             # the flow's single device->host read
+        # the flow's single device->host read: into a pinned buffer (no staging copy, no allocation), then wait for it
+        if getattr(self, "_host_res", None) is None:
+            self._host_res = torch.empty(16, dtype=torch.float32).pin_memory()
+            self._host_ev = torch.cuda.Event()
+        host = self._host_res
+        host.copy_(res, non_blocking=True)
+        self._host_ev.record()
+        self._host_ev.synchronize()
         ih = host.view(torch.int32)
         if int(ih[10]) == 1:
             raise AssertionError(torch.Size([1, int(ih[12]), 2]))    # least_squares_H.py:162 (fewer than 4 points)
-        return _Fit(H=host[0:9].numpy().astype(np.float64).reshape(3, 3), success=bool(float(host[9]) > F["min_frac"]))
+        return _Fit(H=host[0:9].numpy().astype(np.float64).reshape(3, 3), success=bool(float(host[9]) > F["min_frac"]))   # (astype: a copy)
 
     def _solve_callables(self, src_xy, dst_xy, w, grid, frame_hw, src_mask_u8, dst_valid_u8, bounds, judge):
         C = self.C
