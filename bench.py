@@ -203,7 +203,7 @@ def main():
     results = track_all(tracker, 0, Wm)
     wdist.gather_tracks(results[:1])        # untimed: creates the RCCL communicator / warms the collective
     torch.cuda.synchronize()
-    # the kernel with the largest share of a frame (profiles/r02_bench_kernel_stats_bf16x3.csv): the 3x3 / 64-column
+    # the kernel with the largest share of a frame (profiles/r03_bench_kernel_stats_bf16x3.csv): the 3x3 / 64-column
     # instance of the register-streamed-weights conv kernel = the motion encoder's three 3x3 layers (update.py:83,85,86)
     ROOF_TAGS = ("convc2", "convf2", "convc2+convf2", "convm")
     # (HIP events are stream-ordered barriers: the volume-free lookup, not this mode's roofline kernel, is timed in isolation
@@ -236,14 +236,14 @@ def main():
     def lookup_roofline(evs, P, storage="fp32"):
         """Correlation lookup in the volume (the named HBM-roofline kernel): algorithmic bytes / live time.
         `traffic` = HBM bytes per launch from PMC passes (FETCH_SIZE with the guide's gfx950 correction + WRITE_SIZE), which
-        need their own rocprofv3 runs: tools/lookup_pmc.sh regenerates profiles/r02_lookup_pmc.json on the GPU box."""
+        need their own rocprofv3 runs: tools/lookup_pmc.sh regenerates profiles/r03_lookup_pmc.json on the GPU box."""
         lk_ms = [s.elapsed_time(e) for s, e in evs]
         lk_avg = float(np.mean(lk_ms)) if lk_ms else float("nan")
         # (2r+2)^2 volume elements in, (2r+1)^2 fp32 samples out, per level: 2896 B with the fp32 volume, 2096 B with the
         # bf16-storage volume of the plain-bf16 operating point (SURVEY 8d)
         algo_bytes = (LOOKUP_ALGO_BYTES_PER_PIXEL if storage == "fp32" else 4 * (10 * 10 * 2 + 9 * 9 * 4)) * P
         traffic, src = None, None
-        for name in (("r02_lookup_pmc.json", "r01_lookup_pmc.json") if storage == "fp32" else ()):   # (PMC passes: fp32 volume;
+        for name in (("r03_lookup_pmc.json", "r02_lookup_pmc.json", "r01_lookup_pmc.json") if storage == "fp32" else ()):   # (PMC passes: fp32 volume;
                                                         # FETCH_SIZE is uncalibrated for the bf16 volume's 8-B-per-lane loads)
             try:
                 pmc = json.loads((ROOT / "profiles" / name).read_text())

@@ -249,6 +249,17 @@ typedef struct woft_lookup_otf_params {
     int32_t ldo;
     int32_t ablate;         /* developer knob of tools/bench_lookup_otf.py (1: no target-row stream after the first steps,
                                2: no MFMAs, 4: no window scatter, 8: no interpolation / output); 0 in production */
+    /* Optional (fh_part != NULL): the previous refinement iteration's woft_flow_head_gather, folded into this launch.
+       Before a workgroup reads the lookup centres of its 8 x 8 source pixels it finishes the flow head for exactly those
+       pixels -- delta = fh_bias + 3x3 sum of the partial products (same operations and order as woft_flow_head_gather) --
+       and writes coords += delta (coords is then read-write), fh_delta, fh_flow4 and fh_flow_cat as that call does.  No
+       other workgroup reads these pixels' coordinates, and every later launch on the stream sees the updated flow.       */
+    const float* fh_part;   /* [fh_planes][hf*wf][fh_ld] (fh_ld >= 20, % 4 == 0)                     */
+    const float* fh_bias;   /* [2] or NULL                                                          */
+    float* fh_delta;        /* [hf*wf][fh_ld_delta]                                                 */
+    float* fh_flow4;        /* [hf*wf][4] or NULL                                                   */
+    float* fh_flow_cat;     /* [hf*wf][fh_ld_cat] (2 values written) or NULL                        */
+    int32_t fh_planes, fh_ld, fh_ld_delta, fh_ld_cat;
 } woft_lookup_otf_params;
 int woft_corr_lookup_otf(const woft_lookup_otf_params* p, void* stream);
 /* NHWC map [h][w][c] -> its rows in (4 x tile_w)-tile order [(ceil(h/4)*ceil(w/tile_w)*4*tile_w)][c], zero rows outside

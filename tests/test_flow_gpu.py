@@ -445,3 +445,32 @@ def test_real_frames_720p_vs_reference(golden_dir, precision, corr, epe_mean, ep
           f"(mean |flow| {float(np.sqrt((g['flow_up_s4'] ** 2).sum(1)).mean()):.2f} px)")
     assert m < epe_mean and mx < epe_max, (m, mx)
     assert rm < epe_max and dws < wtol            # (wtol: on the sigmoid, the quantity SURVEY 8d states the budget for)
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("small", [False, True])
+def test_launch_merging_switches_are_bit_identical(monkeypatch, small):
+    """Round-3 launch merging -- the motion encoder's branches in shared launches (woft_conv2d_pair), the last iteration's
+    flow-head and mask-head convs in one launch, the flow-head gather of iteration k inside the lookup launch of iteration
+    k + 1 -- changes which launch does the work, not the operations or their order: flows and weights are bit-identical
+    with every switch off."""
+    from woft_amd import engine
+    sd = synth.make_state_dict(seed=21, small=small, weighted=not small)
+    rt = "orig" if small else "weighted"
+    a = synth.make_template(136, 200, seq_id=6)
+    b = synth.make_frame(a, 3)
+    outs = []
+    for pair, fold in ((True, True), (False, True), (True, False), (False, False)):
+        monkeypatch.setattr(engine, "PAIR_BRANCHES", pair)
+        monkeypatch.setattr(engine, "FOLD_GATHER", fold)
+        c = _flow_config(sd, 5, raft_type=rt, padding_mode="nopad", small=small, precision="bf16x3")
+        prov = c.of_class(c)
+        flow, w = prov.compute_flow(a, b, mode="flow")
+        plan = prov.engine.plan(136, 200)
+        assert (plan._fold is not None) == (fold and plan.prog_iter[-1][0] == "fh_gather")
+        n_launch = len(plan._fold[id(plan.prog_iter)]) if plan._fold is not None else len(plan.prog_iter)
+        outs.append((flow.clone(), None if w is None else w.clone(), n_launch))
+    for f, w, _ in outs[1:]:
+        assert torch.equal(f, outs[0][0]) and (w is None or torch.equal(w, outs[0][1]))
+    if not small:
+        assert outs[0][2] == 9 and outs[3][2] == 12        # launches per refinement iteration: merged / one per layer

@@ -48,6 +48,8 @@ class LookupOtfParams(C.Structure):
         ("f1", vp), ("f2", vp * 4), ("h", i32 * 4), ("w", i32 * 4),
         ("levels", i32), ("radius", i32), ("terms", i32), ("hf", i32), ("wf", i32), ("k", i32),
         ("alpha", f32), ("coords", vp), ("out", vp), ("need", vp), ("ldo", i32), ("ablate", i32),
+        ("fh_part", vp), ("fh_bias", vp), ("fh_delta", vp), ("fh_flow4", vp), ("fh_flow_cat", vp),
+        ("fh_planes", i32), ("fh_ld", i32), ("fh_ld_delta", i32), ("fh_ld_cat", i32),
     ]
 
 

@@ -94,8 +94,42 @@ __global__ __launch_bounds__(TW * 32, 2) void corr_lookup_otf_kernel(const woft_
         const int y = py0 + (tid >> TSH), x = px0 + (tid & (TW - 1));
         float cx = 0.f, cy = 0.f;
         if (y < p.hf && x < p.wf) {
-            cx = p.coords[((int64_t)y * p.wf + x) * 2];
-            cy = p.coords[((int64_t)y * p.wf + x) * 2 + 1];
+            const int64_t i = (int64_t)y * p.wf + x;
+            cx = p.coords[i * 2];
+            cy = p.coords[i * 2 + 1];
+            if (p.fh_part != nullptr) {
+                // the previous iteration's flow-head gather for this pixel (woft_flow_head_gather's operations, in its
+                // order: planes first, then the 9 taps), then coords1 += delta and the flow operands of this iteration
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                float dx = p.fh_bias ? p.fh_bias[0] : 0.f, dy = p.fh_bias ? p.fh_bias[1] : 0.f;
+                const int64_t plane = (int64_t)p.hf * p.wf * p.fh_ld;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int yy = y + ky - 1, xx = x + kx - 1;
+                        f32x2 v = {0.f, 0.f};
+                        if (yy >= 0 && yy < p.hf && xx >= 0 && xx < p.wf) {
+                            const float* src = p.fh_part + ((int64_t)yy * p.wf + xx) * p.fh_ld + (ky * 3 + kx) * 2;
+                            v = *(const f32x2*)src;
+                            for (int t = 1; t < p.fh_planes; ++t) v += *(const f32x2*)(src + t * plane);
+                        }
+                        dx += v[0];
+                        dy += v[1];
+                    }
+                p.fh_delta[i * p.fh_ld_delta] = dx;
+                p.fh_delta[i * p.fh_ld_delta + 1] = dy;
+                cx += dx;
+                cy += dy;
+                ((float*)p.coords)[i * 2] = cx;
+                ((float*)p.coords)[i * 2 + 1] = cy;
+                const float fx = cx - (float)x, fy = cy - (float)y;
+                if (p.fh_flow4 != nullptr) *(f32x4*)(p.fh_flow4 + i * 4) = f32x4{fx, fy, 0.f, 0.f};
+                if (p.fh_flow_cat != nullptr) {
+                    p.fh_flow_cat[i * p.fh_ld_cat] = fx;
+                    p.fh_flow_cat[i * p.fh_ld_cat + 1] = fy;
+                }
+            }
         }
         s_cc[tid] = make_float2(cx, cy);
     }
@@ -358,6 +392,9 @@ extern "C" int woft_corr_lookup_otf(const woft_lookup_otf_params* pp, void* stre
         if (!p.f2[l] || p.h[l] <= 0 || p.w[l] <= 0 || (int64_t)p.h[l] * p.w[l] * row_bytes >= (1ll << 32)) return WOFT_EINVAL;
     const int nout = p.levels * (2 * p.radius + 1) * (2 * p.radius + 1);
     if (p.ldo < nout) return WOFT_EINVAL;
+    if (p.fh_part != nullptr && (p.fh_delta == nullptr || p.fh_planes < 1 || p.fh_ld < 20 || p.fh_ld % 4 != 0 || p.fh_ld_delta < 2 ||
+                                 (p.fh_flow_cat != nullptr && p.fh_ld_cat < 2) || p.need != nullptr))
+        return WOFT_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     // 8 x 8 source pixels per workgroup.  (TW = 16: 40 % less target-row traffic, but one 8-wave workgroup per CU and
     // 20 % more steps per workgroup: measured 110 vs 98 us at 1080p in round 1, -1.7 % frames/s in round 2 with two steps

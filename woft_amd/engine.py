@@ -35,6 +35,9 @@ FUSE_FLOWHEAD = os.environ.get("WOFT_FUSE_FLOWHEAD", "1") != "0"
 # motion encoder: the correlation branch (convc1 -> convc2) and the flow branch (convf1 -> convf2) are independent until
 # `conv` joins them (update.py:89-97): first layers in one launch, second layers in one launch (woft_conv2d_pair)
 PAIR_BRANCHES = os.environ.get("WOFT_PAIR", "1") != "0"
+# the flow-head gather of iteration k runs inside the lookup launch of iteration k + 1 (volume-free lookup; the last
+# iteration's as its own launch): one launch fewer per iteration, same operations in the same order (0: always its own launch)
+FOLD_GATHER = os.environ.get("WOFT_FOLD_GATHER", "1") != "0"
 
 
 def _ru(x, m):
@@ -310,6 +313,7 @@ class _Plan:
             if PAIR_BRANCHES and k is not None and ops.pair_ok(self.prog_iter[k][1], self.prog_mask[0]):
                 self.prog_iter_last = (self.prog_iter[:k] + [("conv2", (self.prog_iter[k][1], self.prog_mask[0]), "fh1+mk1")]
                                        + self.prog_iter[k + 1:])
+        self._fold = self._fold_gather_programs()
         if eng.weighted:
             n = sp.nwin
             self.x8 = new_act(P, n, n, 5, cs=8, zero=True)
@@ -332,6 +336,26 @@ class _Plan:
             self.wh_region = None                        # None = every source pixel
             self._wh_regions = {}
             self._wh_dyn = {}                            # per region: (dynamic window list, its programs, scratch)
+
+    def _fold_gather_programs(self):
+        """Variants of the iteration programs in which the flow-head gather that ends iteration k is done by the lookup
+        launch that starts iteration k + 1 (woft_lookup_otf_params.fh_*): {id(program): variant, "gather": the last one}."""
+        progs = [self.prog_iter_first, self.prog_iter] + ([self.prog_iter_last] if getattr(self, "prog_iter_last", None) else [])
+        if not (FOLD_GATHER and self.otf and all(p and p[-1][0] == "fh_gather" and p[0][0] == "lookup" for p in progs)):
+            return None
+        n_planes, bias2 = self.prog_iter[-1][1]
+        lk = type(self.lookup).from_buffer_copy(self.lookup)
+        off = self.eng.spec.flow_off
+        flow_cat = self.xbuf.t[:, off:]
+        lk.fh_part, lk.fh_bias, lk.fh_delta = _lib.ptr(self.fh_part), _lib.ptr(bias2), _lib.ptr(self.delta.t)
+        lk.fh_flow4, lk.fh_flow_cat = _lib.ptr(self.flow4.t), flow_cat.data_ptr()
+        lk.fh_planes, lk.fh_ld, lk.fh_ld_delta, lk.fh_ld_cat = n_planes, self.fh_part.shape[1], self.delta.cs, self.xbuf.cs
+        lk._keep = (self.lookup._keep, bias2, self.fh_part)
+        out = {"gather": [self.prog_iter[-1]]}
+        for p in progs:
+            head = p[0] if p is self.prog_iter_first else ("lookup", lk)
+            out[id(p)] = [head] + p[1:-1]
+        return out
 
     def _wh_program(self, n_win, index):
         """Launch list of the head's 128->128 layers on n_win windows (all source pixels, or those listed in the
@@ -649,10 +673,16 @@ class _Plan:
         off = sp.flow_off
         ops.coords_init(self.coords, self.hf, self.wf, self.flow4.t, self.xbuf.t[:, off:], self.xbuf.cs)
         last = getattr(self, "prog_iter_last", None) if iters > 1 else None
+        fold = self._fold if trace is None else None        # (a trace reads the coordinates after every iteration)
         for it in range(iters):
-            self.run(self.prog_iter_first if it == 0 else (last if (last is not None and it == iters - 1) else self.prog_iter))
+            prog = self.prog_iter_first if it == 0 else (last if (last is not None and it == iters - 1) else self.prog_iter)
+            if fold is not None:
+                prog = fold[id(prog)]
+            self.run(prog)
             if trace is not None:
                 trace(self, it)
+        if fold is not None:
+            self.run(fold["gather"])
         for p in (self.prog_mask[1:] if last is not None else self.prog_mask):
             ops.run_conv(p)
         wlow = None
