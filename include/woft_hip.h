@@ -145,6 +145,13 @@ int woft_conv2d(const woft_conv_params* p, void* stream);
  * encoder's correlation and flow branches, update.py:91-95, are independent until `conv` joins them).  WOFT_EINVAL when the
  * layers do not share a kernel: the caller launches them one after the other. */
 int woft_conv2d_pair(const woft_conv_params* a, const woft_conv_params* b, void* stream);
+/* One SepConvGRU half step (update.py:45-60) in one launch: zr and q are the argument structs the two launches of the step
+ * take -- zr: the z|r conv (1x5 or 5x1, in0 = e0 = h, in1 = motion features, c_split 128, cin_pad 256, cout 256 = z | r,
+ * wgt_frag, bias_map = the context features' share); q: the q conv (same taps, in1 = the same motion features, wgt_frag,
+ * bias_map, e0 = h, out = the new state; its in0 -- r*h -- is NOT read: r*h is recomputed on the conv's halo and kept in
+ * LDS, z stays in registers).  One image; split-bf16 / fp16 precisions.  Bit-identical to woft_conv2d(zr with
+ * WOFT_EPI_GRU_ZR) followed by woft_conv2d(q with WOFT_EPI_GRU_Q).  One 4-wave workgroup per 8 x 16 pixels and per CU. */
+int woft_gru_halfstep(const woft_conv_params* zr, const woft_conv_params* q, void* stream);
 /* fp32 array (n % 4 == 0) -> bf16 planes hi = bf16(x), lo = bf16(x - hi) (lo may be NULL): the
  * split form of a dynamic B operand (fmap2 in the correlation GEMM). */
 int woft_split_bf16(const float* x, int64_t n, void* hi, void* lo, void* stream);

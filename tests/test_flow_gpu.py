@@ -452,17 +452,18 @@ def test_real_frames_720p_vs_reference(golden_dir, precision, corr, epe_mean, ep
 def test_launch_merging_switches_are_bit_identical(monkeypatch, small):
     """Round-3 launch merging -- the motion encoder's branches in shared launches (woft_conv2d_pair), the last iteration's
     flow-head and mask-head convs in one launch, the flow-head gather of iteration k inside the lookup launch of iteration
-    k + 1 -- changes which launch does the work, not the operations or their order: flows and weights are bit-identical
-    with every switch off."""
+    k + 1, each SepConvGRU half step (z|r -> q) in one launch -- changes which launch does the work, not the operations or
+    their order: flows and weights are bit-identical with every switch off."""
     from woft_amd import engine
     sd = synth.make_state_dict(seed=21, small=small, weighted=not small)
     rt = "orig" if small else "weighted"
     a = synth.make_template(136, 200, seq_id=6)
     b = synth.make_frame(a, 3)
     outs = []
-    for pair, fold in ((True, True), (False, True), (True, False), (False, False)):
+    for pair, fold, gru in ((True, True, "1"), (False, True, "0"), (True, False, "1"), (False, False, "0"), (True, True, "0")):
         monkeypatch.setattr(engine, "PAIR_BRANCHES", pair)
         monkeypatch.setattr(engine, "FOLD_GATHER", fold)
+        monkeypatch.setattr(engine, "GRU_FUSE", gru)
         c = _flow_config(sd, 5, raft_type=rt, padding_mode="nopad", small=small, precision="bf16x3")
         prov = c.of_class(c)
         flow, w = prov.compute_flow(a, b, mode="flow")
@@ -473,4 +474,6 @@ def test_launch_merging_switches_are_bit_identical(monkeypatch, small):
     for f, w, _ in outs[1:]:
         assert torch.equal(f, outs[0][0]) and (w is None or torch.equal(w, outs[0][1]))
     if not small:
-        assert outs[0][2] == 9 and outs[3][2] == 12        # launches per refinement iteration: merged / one per layer
+        # launches per refinement iteration: everything merged (GRU half steps in one launch each) / one per layer / merged
+        # without the GRU fusion
+        assert outs[0][2] == 7 and outs[3][2] == 12 and outs[4][2] == 9

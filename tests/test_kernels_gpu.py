@@ -373,6 +373,54 @@ def test_conv_gru_epilogues(ops, kh, kw, precision, tol):
             assert torch.equal(z2.t, zb.t) and torch.equal(rh2.t, rh.t) and torch.equal(h2.t, hn.t), (halo, tiles)
 
 
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16", "fp16"])
+@pytest.mark.parametrize("kh,kw", [(1, 5), (5, 1)])
+@pytest.mark.parametrize("h,w", [(135, 240), (19, 37), (8, 16)])
+def test_gru_half_step_in_one_launch(ops, h, w, kh, kw, precision):
+    """woft_gru_halfstep: z|r -> q of a SepConvGRU half step (update.py:45-60) in one launch -- r*h recomputed on the q conv's
+    halo and kept in LDS, z in registers, the context features' share as per-pixel bias maps and the motion features as the
+    second source, exactly as the engine drives the two-launch path (EPI_GRU_ZR, then EPI_GRU_Q): bit-identical new state,
+    also on ragged tiles and on a map of a single tile; and close to torch."""
+    hprev = torch.tanh(_rand(1, 128, h, w, seed=4))
+    inp = F.relu(_rand(1, 128, h, w, seed=9))
+    mot = F.relu(_rand(1, 128, h, w, seed=5))
+    mk = lambda s: (_rand(128, 384, kh, kw, seed=s, scale=1 / math.sqrt(384 * kh * kw)), _rand(128, seed=s + 50, scale=0.1))
+    (wz, bz), (wr, br), (wq, bq) = mk(6), mk(7), mk(8)
+    pad = (kh // 2, kw // 2)
+    hx = torch.cat([hprev, inp, mot], 1)
+    z = torch.sigmoid(F.conv2d(hx, wz, bz, padding=pad))
+    r = torch.sigmoid(F.conv2d(hx, wr, br, padding=pad))
+    q = torch.tanh(F.conv2d(torch.cat([r * hprev, inp, mot], 1), wq, bq, padding=pad))
+    ref = (1 - z) * hprev + z * q
+    dyn, ctx = [(0, 128, 0), (256, 384, 128)], [(128, 256, 0)]
+    wzr, bzr = torch.cat([wz, wr], 0), torch.cat([bz, br], 0)
+    zr_dyn, q_dyn = ops.pack_conv(wzr, None, padding=pad, cin_layout=dyn), ops.pack_conv(wq, None, padding=pad, cin_layout=dyn)
+    zr_inp, q_inp = ops.pack_conv(wzr, bzr, padding=pad, cin_layout=ctx), ops.pack_conv(wq, bq, padding=pad, cin_layout=ctx)
+    ha, ia = ops.act_from_nchw(hprev), ops.act_from_nchw(inp)
+    xbuf = ops.new_act(1, h, w, 256, zero=True)                  # [inp | motion] as in the engine; the convs read from channel 128
+    xbuf.t[:, 128:256] = ops.act_from_nchw(mot).t
+    gz, gq = ops.new_act(1, h, w, 256, zero=True), ops.new_act(1, h, w, 128, zero=True)
+    ops.run_conv(ops.conv_params(ia, zr_inp, gz, precision=precision))
+    ops.run_conv(ops.conv_params(ia, q_inp, gq, precision=precision))
+    zb, rh, h2, h1 = (ops.new_act(1, h, w, 128, zero=True) for _ in range(4))
+    pzr = ops.conv_params(ha, zr_dyn, zb, x2=xbuf, x2_off=128, c_split=128, epi=ops._lib.EPI_GRU_ZR, split=128, e0=ha, out1=rh,
+                          bias_map=gz, precision=precision)
+    pq2 = ops.conv_params(rh, q_dyn, h2, x2=xbuf, x2_off=128, c_split=128, epi=ops._lib.EPI_GRU_Q, e0=ha, e1=zb, bias_map=gq,
+                          precision=precision)
+    ops.run_conv(pzr)
+    ops.run_conv(pq2)
+    pq1 = ops.conv_params(rh, q_dyn, h1, x2=xbuf, x2_off=128, c_split=128, epi=ops._lib.EPI_GRU_Q, e0=ha, e1=zb, bias_map=gq,
+                          precision=precision)
+    assert ops.gru_ok(pzr, pq1)
+    rh.t.fill_(float("nan"))                                     # (the one-launch path must not read r*h or z from memory)
+    zb.t.fill_(float("nan"))
+    ops.run_gru_halfstep(pzr, pq1)
+    torch.cuda.synchronize()
+    assert torch.equal(h1.t, h2.t)
+    tol = {"bf16x3": 2e-4, "bf16": 4e-2, "fp16": 6e-3}[precision]
+    _close(h1.nchw(), ref, tol, what=f"gru half step {precision}")
+
+
 @pytest.mark.parametrize("precision,tol", [("bf16x3", 2e-4), ("bf16", 5e-2)])
 def test_conv_halo_patches_and_fallback(ops, precision, tol):
     """3x3 128->128 on batches of 9x9 patches (weight head layers 2/3, weighted_raft.py:336-340): the

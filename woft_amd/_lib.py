@@ -59,6 +59,7 @@ _SIGS = {
     "woft_set_tuning": (i32, [i32, i32]),
     "woft_conv2d": (i32, [C.POINTER(ConvParams), vp]),
     "woft_conv2d_pair": (i32, [C.POINTER(ConvParams), C.POINTER(ConvParams), vp]),
+    "woft_gru_halfstep": (i32, [C.POINTER(ConvParams), C.POINTER(ConvParams), vp]),
     "woft_split_bf16": (i32, [vp, i64, vp, vp, vp]),
     "woft_split_bf16_lines": (i32, [vp, i64, vp, vp]),
     "woft_flow_to_tc": (i32, [vp, vp, i32, i32, vp, vp, i32, vp]),

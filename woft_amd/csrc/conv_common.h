@@ -142,6 +142,7 @@ struct EpiRegs {
     int ldo1, lde0, lde1, ld_bias_map, co_off, cout, split, epi;
     float alpha;
     bool no_store;
+    bool fast;             // gate functions on the hardware exp2 / rcp (split-bf16 / fp16 precisions), see common.h
 };
 
 // One row group (8 rows x 32 columns of a transposed tile) in two steps, so that a caller can issue the operand loads of
@@ -164,7 +165,7 @@ __device__ __forceinline__ EpiOps epi_load(const EpiRegs& a, const int64_t m, co
     return o;
 }
 // v = this lane's 4 consecutive channels of pixel m; returns y = alpha * v + bias (the value the statistics are taken of)
-template <int EPI>
+template <int EPI, bool FAST>
 __device__ __forceinline__ f32x4 epi_finish(const EpiRegs& a, const f32x4 v, const EpiOps& o, const int64_t m, const int n,
                                             const bool nok, const int nrag) {
     f32x4 y, ypre;
@@ -178,11 +179,11 @@ __device__ __forceinline__ f32x4 epi_finish(const EpiRegs& a, const f32x4 v, con
             break;
         case WOFT_EPI_SIGMOID:
 #pragma unroll
-            for (int e = 0; e < 4; ++e) y[e] = sigmoidf_(y[e]);
+            for (int e = 0; e < 4; ++e) y[e] = sigmoid_t<FAST>(y[e]);
             break;
         case WOFT_EPI_TANH:
 #pragma unroll
-            for (int e = 0; e < 4; ++e) y[e] = tanhf(y[e]);
+            for (int e = 0; e < 4; ++e) y[e] = tanh_t<FAST>(y[e]);
             break;
         case WOFT_EPI_RELU_RES_RELU:
 #pragma unroll
@@ -190,7 +191,7 @@ __device__ __forceinline__ f32x4 epi_finish(const EpiRegs& a, const f32x4 v, con
             break;
         case WOFT_EPI_GRU_ZR:
 #pragma unroll
-            for (int e = 0; e < 4; ++e) y[e] = sigmoidf_(y[e]);
+            for (int e = 0; e < 4; ++e) y[e] = sigmoid_t<FAST>(y[e]);
             if (n >= a.split) {                        // split % 4 == 0 (validated): whole vector is r
 #pragma unroll
                 for (int e = 0; e < 4; ++e) y[e] *= o.o0[e];
@@ -200,7 +201,7 @@ __device__ __forceinline__ f32x4 epi_finish(const EpiRegs& a, const f32x4 v, con
             break;
         case WOFT_EPI_GRU_Q:
 #pragma unroll
-            for (int e = 0; e < 4; ++e) y[e] = (1.f - o.o1[e]) * o.o0[e] + o.o1[e] * tanhf(y[e]);
+            for (int e = 0; e < 4; ++e) y[e] = (1.f - o.o1[e]) * o.o0[e] + o.o1[e] * tanh_t<FAST>(y[e]);
             break;
         default: break;
     }
@@ -220,7 +221,7 @@ __device__ __forceinline__ f32x4 epi_finish(const EpiRegs& a, const f32x4 v, con
 // run-time `switch (epi)` inside eight unrolled row groups, every group jumped over the unused kinds' sigmoid / tanh
 // expansions -- two or three instruction-cache misses per group: 660 cycles per group of pure ALU work, stamped.)
 // Inside a batch ALL operand loads are issued before the first store (see epi_load).
-template <int EPI, int TM, int WROWS, int LP, typename RowMap>
+template <int EPI, bool FAST, int TM, int WROWS, int LP, typename RowMap>
 __device__ __forceinline__ void epi_tiles(const EpiRegs& a, const float* stage, const RowMap& rowmap, const int t_first,
                                           const int nst, const int ncol0, const int wm, const int rr, const int c4,
                                           const bool stats, float (&ssum)[4], float (&ssq)[4]) {
@@ -253,7 +254,7 @@ __device__ __forceinline__ void epi_tiles(const EpiRegs& a, const float* stage, 
             for (int ps = 0; ps < 4; ++ps) {
                 const f32x4 v = *(const f32x4*)(stage + (u0 + d) * STAGE_FLOATS + (rr + 8 * ps) * STAGE_LD + c4);
                 if (mm[d][ps] < 0) continue;
-                const f32x4 y = epi_finish<EPI>(a, v, ops[d][ps], mm[d][ps], nn[d], nk[d], nrag);
+                const f32x4 y = epi_finish<EPI, FAST>(a, v, ops[d][ps], mm[d][ps], nn[d], nk[d], nrag);
                 if (stats) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { ssum[e] += y[e]; ssq[e] += y[e] * y[e]; }
@@ -266,17 +267,31 @@ __device__ __forceinline__ void epi_tiles(const EpiRegs& a, const float* stage, 
 template <int TM, int WROWS, int LP, typename RowMap>
 __device__ __forceinline__ void epi_dispatch(const EpiRegs& a, const float* stage, const RowMap& rowmap, int t_first, int nst,
                                              int ncol0, int wm, int rr, int c4, bool stats, float (&ssum)[4], float (&ssq)[4]) {
-#define WOFT_EPI_CASE(E) \
-    case E: epi_tiles<E, TM, WROWS, LP>(a, stage, rowmap, t_first, nst, ncol0, wm, rr, c4, stats, ssum, ssq); break
+#define WOFT_EPI_CASE(E, F) \
+    case E: epi_tiles<E, F, TM, WROWS, LP>(a, stage, rowmap, t_first, nst, ncol0, wm, rr, c4, stats, ssum, ssq); break
+    if (a.fast) {            // (the kinds with a sigmoid / tanh exist in two versions; the others do not depend on it)
+        switch (a.epi) {
+            WOFT_EPI_CASE(WOFT_EPI_SIGMOID, true);
+            WOFT_EPI_CASE(WOFT_EPI_TANH, true);
+            WOFT_EPI_CASE(WOFT_EPI_GRU_ZR, true);
+            WOFT_EPI_CASE(WOFT_EPI_GRU_Q, true);
+            default: break;
+        }
+    }
     switch (a.epi) {
-        WOFT_EPI_CASE(WOFT_EPI_LINEAR);
-        WOFT_EPI_CASE(WOFT_EPI_RELU);
-        WOFT_EPI_CASE(WOFT_EPI_SIGMOID);
-        WOFT_EPI_CASE(WOFT_EPI_TANH);
-        WOFT_EPI_CASE(WOFT_EPI_RELU_RES_RELU);
-        WOFT_EPI_CASE(WOFT_EPI_GRU_ZR);
-        WOFT_EPI_CASE(WOFT_EPI_GRU_Q);
+        WOFT_EPI_CASE(WOFT_EPI_LINEAR, false);
+        WOFT_EPI_CASE(WOFT_EPI_RELU, false);
+        WOFT_EPI_CASE(WOFT_EPI_RELU_RES_RELU, false);
         default: break;
+    }
+    if (!a.fast) {
+        switch (a.epi) {
+            WOFT_EPI_CASE(WOFT_EPI_SIGMOID, false);
+            WOFT_EPI_CASE(WOFT_EPI_TANH, false);
+            WOFT_EPI_CASE(WOFT_EPI_GRU_ZR, false);
+            WOFT_EPI_CASE(WOFT_EPI_GRU_Q, false);
+            default: break;
+        }
     }
 #undef WOFT_EPI_CASE
 }
@@ -299,6 +314,7 @@ __device__ __forceinline__ void conv_epilogue_t(const woft_conv_params& p, f32x1
     a.ld_bias_map = keep_sgpr(p.ld_bias_map); a.co_off = keep_sgpr(p.co_off); a.cout = keep_sgpr(p.cout);
     a.split = keep_sgpr(p.split); a.epi = keep_sgpr(p.epi); a.alpha = keep_sgpr(p.alpha);
     a.no_store = p.out_w == -12345;                            // (micro-benchmark ablation, tools/bench_conv.py)
+    a.fast = p.precision != 0 && p.out_w != -12346;            // (-12346: developer ablation, library gate functions)
     const GPtr stat_sum = keep_gptr(p.stat_sum), stat_sq = keep_gptr(p.stat_sq);
     const int cout_pad = keep_sgpr(p.cout_pad);
     const bool do_stats = !stat_sum.null();

@@ -38,6 +38,9 @@ PAIR_BRANCHES = os.environ.get("WOFT_PAIR", "1") != "0"
 # the flow-head gather of iteration k runs inside the lookup launch of iteration k + 1 (volume-free lookup; the last
 # iteration's as its own launch): one launch fewer per iteration, same operations in the same order (0: always its own launch)
 FOLD_GATHER = os.environ.get("WOFT_FOLD_GATHER", "1") != "0"
+# SepConvGRU half step z|r -> q in one launch (woft_gru_halfstep: r*h recomputed on the q conv's halo and kept in LDS, z in
+# registers; one workgroup per 8 x 16 tile and per CU, so it is taken only where the tiles fill whole rounds of the 256 CUs)
+GRU_FUSE = os.environ.get("WOFT_GRU_FUSE", "0")          # "1": always, "auto": where the tiles fill whole rounds of the CUs
 
 
 def _ru(x, m):
@@ -539,10 +542,16 @@ class _Plan:
             hi, ho = states[k], states[k + 1]
             if self.gate_bias is not None:      # [h | motion] only; the inp term is the per-pixel bias (see RaftEngine)
                 gz, gq = self.gate_bias[k]
-                prog += [("conv", cp(hi, e.zr_dyn[k], self.zbuf, x2=self.xbuf, x2_off=sp.cdim, c_split=hd,
-                                     epi=EPI.EPI_GRU_ZR, split=hd, e0=hi, out1=self.rh, bias_map=gz), f"gru_zr{k}"),
-                         ("conv", cp(self.rh, e.q_dyn[k], ho, x2=self.xbuf, x2_off=sp.cdim, c_split=hd,
-                                     epi=EPI.EPI_GRU_Q, e0=hi, e1=self.zbuf, bias_map=gq), f"gru_q{k}")]
+                pzr = cp(hi, e.zr_dyn[k], self.zbuf, x2=self.xbuf, x2_off=sp.cdim, c_split=hd,
+                         epi=EPI.EPI_GRU_ZR, split=hd, e0=hi, out1=self.rh, bias_map=gz)
+                pq = cp(self.rh, e.q_dyn[k], ho, x2=self.xbuf, x2_off=sp.cdim, c_split=hd,
+                        epi=EPI.EPI_GRU_Q, e0=hi, e1=self.zbuf, bias_map=gq)
+                tiles = math.ceil(self.hf / 8) * math.ceil(self.wf / 16)
+                full_rounds = tiles % 256 == 0 or tiles % 256 >= 224     # (one workgroup per CU: a last round that fills)
+                if (GRU_FUSE == "1" or (GRU_FUSE == "auto" and full_rounds)) and ops.gru_ok(pzr, pq):
+                    prog.append(("gru", (pzr, pq), f"gru{k}"))
+                else:
+                    prog += [("conv", pzr, f"gru_zr{k}"), ("conv", pq, f"gru_q{k}")]
                 continue
             prog += [("conv", cp(hi, zr, self.zbuf, x2=self.xbuf, c_split=hd, epi=EPI.EPI_GRU_ZR, split=hd, e0=hi,
                                  out1=self.rh)),
@@ -568,7 +577,9 @@ class _Plan:
     def run(self, prog):
         for ent in prog:
             kind, a = ent[0], ent[1]
-            if kind == "conv2":
+            if kind == "gru":
+                ops.run_gru_halfstep(*a)
+            elif kind == "conv2":
                 ev = self.conv_events
                 if ev is not None and len(ent) > 2 and ent[2] in ev:
                     s, t = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -168,6 +168,7 @@ def fold_bn(weight, bias, bn_w, bn_b, mean, var, eps=1e-5):
 
 
 PRECISION = {"fp32": 0, "bf16x3": 1, "bf16": 2, "fp16": 3}
+SLOW_GATES = os.environ.get("WOFT_SLOW_GATES", "0") != "0"     # developer A/B: libm sigmoid / tanh in the conv epilogues
 USE_HALO = os.environ.get("WOFT_HALO", "1") != "0"
 USE_REGB = os.environ.get("WOFT_REGB", "1") != "0"
 USE_REGB1 = os.environ.get("WOFT_REGB1", "0") != "0"      # (measured: 45 vs 37 us on convc1 -- the 64 x 64 gather tiles win)
@@ -217,7 +218,7 @@ def conv_params(x, pc, out, co_off=0, epi=_lib.EPI_LINEAR, x2=None, c_split=0, e
         p.wgt_hi, p.wgt_lo = ptr(pc.wgt_f16()), None
     p.cout, p.cout_pad = (cout or pc.cout), pc.cout_pad
     p.out, p.ldo, p.co_off = ptr(out.t), out.cs, co_off
-    p.out_w, p.out_pitch = 0, 0
+    p.out_w, p.out_pitch = (-12346 if SLOW_GATES else 0), 0
     p.epi, p.split = epi, split
     p.e0, p.lde0 = (ptr(e0.t), e0.cs) if e0 is not None else (None, 0)
     p.e1, p.lde1 = (ptr(e1.t), e1.cs) if e1 is not None else (None, 0)
@@ -390,6 +391,18 @@ def pair_ok(a, b):
     if a.halo == 0:
         return True
     return a.halo in (8, 12) and (a.taps_y, a.taps_x) == (b.taps_y, b.taps_x) and a.taps_y * a.taps_x > 1
+
+
+def gru_ok(zr, q):
+    """True when woft_gru_halfstep takes this z|r conv / q conv pair (one SepConvGRU half step in one launch)."""
+    return (zr.precision in (1, 2, 3) and q.precision == zr.precision and (zr.taps_y, zr.taps_x) in ((1, 5), (5, 1))
+            and (q.taps_y, q.taps_x) == (zr.taps_y, zr.taps_x) and zr.n_img == 1 and zr.cin_pad == 256 == q.cin_pad
+            and zr.c_split == 128 == q.c_split and zr.cout == 256 and q.cout == 128 and bool(zr.wgt_frag) and bool(q.wgt_frag)
+            and bool(zr.bias_map) and bool(q.bias_map) and bool(zr.in1) and zr.in1 == q.in1 and zr.e0 == zr.in0 == q.e0)
+
+
+def run_gru_halfstep(zr, q):
+    check(_lib.load().woft_gru_halfstep(C.byref(zr), C.byref(q), stream_ptr()), "woft_gru_halfstep")
 
 
 def run_conv_pair(a, b):
