@@ -102,7 +102,11 @@ typedef struct woft_conv_params {
                               statistics / in_norm; in plain-bf16 mode 10-17 % faster than 8x16 x 128, but 8x16 x 64
                               is faster still: not chosen by the Python host), 2 = one 9x9 image per workgroup (weight-head patches;
                               ho = wo = 9).  (Larger tiles / several patches per workgroup were measured
-                              1.5-3x slower: one workgroup per CU cannot hide its own latencies.) */
+                              1.5-3x slower: one workgroup per CU cannot hide its own latencies.)
+                              7 = the encoders' first layer (extractor.py:127-129: 7x7, stride 2, pad 3) on its own kernel:
+                              flat packing of an NHWC4 image (cs0 = 4, taps_y = 7, taps_x = 1, cin_pad = 32), split-bf16
+                              precisions, cout_pad % 64 == 0, 8x16 output pixels x 64 channels per tile, statistics rows
+                              indexed by those tiles; results bit-identical to halo = 0 */
     int32_t in_norm;       /* halo != 0 only: 0 = use in0 as is; 1 / 2 = in0 holds a RAW conv output whose
                               InstanceNorm is applied while loading (extractor.py:44-47: x = (x - in_mean[c]) *
                               in_rstd[c], 2: followed by ReLU), zero padding applied after it; in1 must be NULL */
@@ -215,6 +219,13 @@ int woft_preprocess_bgr_u8(const uint8_t* img, int32_t h, int32_t w, float* out,
 /* 2x2 stride-2 average pool of an NHWC feature map, floor sizes (corr.py:25-27 applied to
  * fmap2 instead of the volume: identical by linearity, as corr.py:77-81 does). */
 int woft_avgpool2_nhwc(const float* in, int32_t h, int32_t w, int32_t c, float* out, void* stream);
+
+/* The target feature pyramid of the volume-free correlation (corr.py:25-27,77-81) in ONE launch: from the level-0 map
+ * in [h*w][c] fp32, the (levels - 1) pooled maps pooled[l-1] = woft_avgpool2_nhwc applied l times (floor sizes, fp32,
+ * bit-identical to the chained calls) and every level's split operand split[l] -- terms = 3: woft_split_bf16_lines of
+ * level l, terms = 1: woft_split_bf16's hi plane.  c % 32 == 0, 1 <= levels <= 4. */
+int woft_feature_pyramid(const float* in, int32_t h, int32_t w, int32_t c, int32_t levels, float* const* pooled,
+                         void* const* split, int32_t terms, void* stream);
 
 /* Correlation lookup, corr.py:29-59 + utils/utils.py:59-73.
  * vol[l]: level l of the pyramid as [P][ht_l][wt_l][4][4] fp32: the target plane of each source pixel

@@ -495,6 +495,43 @@ def test_conv_flat_first_layer(ops, precision, tol):
     _close(out.nchw(), ref, 5e-5 * tol, what="conv3x3 patches flat")
 
 
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16", "fp16"])
+@pytest.mark.parametrize("h,w", [(75, 91), (64, 128), (272, 480), (13, 9)])
+def test_conv_stem_kernel_equals_gather_kernel(ops, h, w, precision):
+    """The encoders' 7x7 / stride-2 first layer on its own kernel (conv_stem.hip, halo 7: 8x16-pixel tiles, patch in LDS
+    once, weights in registers) against the per-tap gather kernel: every output bit-identical (extractor.py:127-129,168);
+    with InstanceNorm partial statistics (fnet) and with the BatchNorm-folded bias + ReLU epilogue (cnet)."""
+    x = _rand(1, 3, h, w, seed=90)
+    wt = _rand(64, 3, 7, 7, seed=91, scale=0.1)
+    b = _rand(64, seed=92, scale=0.1)
+    pc = ops.pack_conv(wt, b, stride=2, padding=3, flat_cs=4)
+    xa = ops.act_from_nchw(x, cs=4)
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    outs, means = [], []
+    for halo in (None, 0):
+        for epi, with_stats in ((ops._lib.EPI_LINEAR, True), (ops._lib.EPI_RELU, False)):
+            out = ops.new_act(1, ho, wo, 64, zero=True)
+            stats = (torch.zeros(4096 * pc.cout_pad, device="cuda"), torch.zeros(4096 * pc.cout_pad, device="cuda")) if with_stats else None
+            cp = ops.conv_params(xa, pc, out, epi=epi, stats=stats, precision=precision, halo=halo)
+            assert cp.halo == (7 if halo is None else 0)
+            ops.run_conv(cp)
+            if with_stats:
+                mean, rstd = torch.zeros(64, device="cuda"), torch.zeros(64, device="cuda")
+                ops.inorm_finalize(stats, 2 * cp._m_tiles, pc.cout_pad, 64, ho * wo, mean, rstd)
+                means.append((mean.clone(), rstd.clone()))
+            outs.append(out.t.clone())
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[2]), f"raw: max diff {float((outs[0] - outs[2]).abs().max()):.3e}"
+    assert torch.equal(outs[1], outs[3]), f"relu: max diff {float((outs[1] - outs[3]).abs().max()):.3e}"
+    # (the partial sums are grouped by the kernels' own tiles: equal up to fp32 summation order)
+    _close(means[0][0], means[1][0], 1e-6, what="mean")
+    _close(means[0][1], means[1][1], 0.0, rtol=1e-5, what="rstd")
+    ref = F.conv2d(x, wt, b, stride=2, padding=3)
+    y = ops.Act(outs[0], 1, ho, wo, 64).nchw() if hasattr(ops, "Act") else None
+    if y is not None:
+        _close(y, ref, {"bf16x3": 1e-4, "bf16": 3e-2, "fp16": 4e-3}[precision], what="stem vs torch")
+
+
 def test_residual_epilogue_and_bn_fold(ops):
     x = _rand(1, 64, 16, 24, seed=18)
     res = _rand(1, 64, 16, 24, seed=19)
@@ -580,6 +617,35 @@ def test_preprocess_and_pool(ops):
     ops.avgpool2(fa, o)
     torch.cuda.synchronize()
     _close(o.nchw(), F.avg_pool2d(f, 2, stride=2), 1e-6, what="avgpool")
+
+
+@pytest.mark.parametrize("terms", [3, 1])
+@pytest.mark.parametrize("h,w,c,levels", [(135, 240, 256, 4), (17, 25, 256, 4), (30, 44, 128, 4), (9, 8, 64, 3), (16, 16, 32, 1)])
+def test_feature_pyramid_one_launch(ops, h, w, c, levels, terms):
+    """woft_feature_pyramid (pooled maps + split operands of all levels in one launch) against the chained
+    woft_avgpool2_nhwc / woft_split_bf16(_lines) calls it replaces: bit-identical (corr.py:25-27,77-81)."""
+    f = _rand(1, c, h, w, seed=31, scale=3.0)
+    split_of = lambda t: torch.zeros(t.shape[0], t.shape[1] * (2 if terms == 3 else 1), dtype=torch.bfloat16, device="cuda")
+    ref_maps, hh, ww = [ops.act_from_nchw(f)], h, w
+    for l in range(1, levels):
+        hh, ww = hh // 2, ww // 2
+        ref_maps.append(ops.new_act(1, hh, ww, c, zero=True))
+        ops.avgpool2(ref_maps[l - 1], ref_maps[l])
+    ref_split = [split_of(m.t) for m in ref_maps]
+    for m, sp in zip(ref_maps, ref_split):
+        if terms == 3:
+            ops.split_bf16_lines(m.t, sp)
+        else:
+            ops.split_bf16(m.t, sp, None)
+    maps = [ref_maps[0]] + [ops.new_act(1, m.h, m.w, c, zero=True) for m in ref_maps[1:]]
+    splits = [split_of(m.t) for m in maps]
+    ops.feature_pyramid(ops.PyramidArgs(maps, splits, terms))
+    torch.cuda.synchronize()
+    for l in range(levels):
+        assert torch.equal(maps[l].t, ref_maps[l].t), f"pooled map of level {l}"
+        assert torch.equal(splits[l].view(torch.int16), ref_split[l].view(torch.int16)), f"split operand of level {l}"
+    _close(maps[-1].nchw(), F.avg_pool2d(f, 2 ** (levels - 1)) if levels > 1 else f, 1e-5, what="pyramid top vs torch") \
+        if (h % (2 ** (levels - 1)) == 0 and w % (2 ** (levels - 1)) == 0) else None
 
 
 # ------------------------------------------------------------------------------------------

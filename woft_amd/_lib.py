@@ -73,6 +73,7 @@ _SIGS = {
     "woft_inorm_apply": (i32, [vp, vp, vp, vp, vp, vp, i32, vp, i64, i32, i32, vp]),
     "woft_preprocess_bgr_u8": (i32, [vp, i32, i32, vp, i32, i32, i32, i32, vp]),
     "woft_avgpool2_nhwc": (i32, [vp, i32, i32, i32, vp, vp]),
+    "woft_feature_pyramid": (i32, [vp, i32, i32, i32, i32, vp, vp, i32, vp]),
     "woft_corr_lookup": (i32, [C.POINTER(LookupParams), vp]),
     "woft_tile_rows": (i32, [vp, i32, i32, i32, i32, vp, vp]),
     "woft_coords_update": (i32, [vp, vp, i32, i32, i64, vp, vp, i32, vp]),

@@ -961,6 +961,7 @@ int launch_conv(const woft_conv_params& p, const woft_conv_params* second, hipSt
 }  // namespace
 
 int woft_conv_regb_launch(const woft_conv_params& p, const woft_conv_params* second, void* stream);     // conv_regb.hip
+int woft_conv_stem_launch(const woft_conv_params& p, void* stream);                                     // conv_stem.hip
 
 static int conv_check(const woft_conv_params& p) {
     if (p.in0 == nullptr || p.out == nullptr) return WOFT_EINVAL;
@@ -1020,6 +1021,8 @@ static int conv_dispatch(const woft_conv_params& p, const woft_conv_params* seco
                               (p.halo == 0 && second->tile_m != p.tile_m) ||
                               second->tile_n != p.tile_n || p.precision == 0 || (p.halo != 0 && p.halo != 8 && p.halo != 12)))
         return WOFT_EINVAL;
+    if (p.halo == 7)                      // the encoders' 7x7 / stride-2 first layer on its own kernel (conv_stem.hip)
+        return second != nullptr ? WOFT_EINVAL : woft_conv_stem_launch(p, stream);
     for (const woft_conv_params* q : {&p, second}) {
         if (q == nullptr || q->halo == 0) continue;
         // LDS-halo kernels: split-bf16 precisions, stride 1, 3x3 / 1x5 / 5x1 taps, non-flat, same-size output

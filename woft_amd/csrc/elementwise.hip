@@ -163,6 +163,92 @@ __global__ void avgpool2_kernel(const float* __restrict__ in, int h, int w, int 
     *(f32x4*)(out + pix * c + cc * 4) = o;
 }
 
+// ---- target feature pyramid in ONE launch (corr = "otf": pooled maps + their split operands) -------------------------
+// avgpool2_kernel x (levels - 1) and split_bf16(_lines) x levels were 7 launches of 5-12 us each per frame for 45 MB of
+// traffic.  A workgroup takes an 8 x 8 block of level-0 pixels: thread (sub-block s of 4 x 4 pixels, channel quad q) reads
+// its 16 float4s, forms the level-1 (2 x 2) and level-2 (1) averages in registers with avgpool2_kernel's own expression
+// ((p00 + p01 + p10 + p11) * 0.25 of the level below: bit-identical), level 3 from the four sub-blocks through LDS, and
+// writes every level's fp32 map (levels >= 1) and split operand (TERMS 3: [hi | lo] lines of 32 channels; 1: the bf16 plane).
+typedef __bf16 pbf16x4 __attribute__((ext_vector_type(4)));
+struct PyrArgs {
+    const float* in;
+    float* pooled[3];
+    __bf16* split[4];
+    int h, w, c, levels;
+};
+template <int TERMS>
+__device__ __forceinline__ void pyr_split(__bf16* out, int64_t pix, int c, int q, const f32x4 v) {
+    const pbf16x4 hi = __builtin_convertvector(v, pbf16x4);
+    if (TERMS == 3) {
+        __bf16* line = out + pix * (2 * (int64_t)c) + (q >> 3) * 64 + (q & 7) * 4;
+        *(pbf16x4*)line = hi;
+        *(pbf16x4*)(line + 32) = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), pbf16x4);
+    } else {
+        *(pbf16x4*)(out + pix * (int64_t)c + q * 4) = hi;
+    }
+}
+template <int TERMS>
+__global__ __launch_bounds__(256) void feature_pyramid_kernel(const PyrArgs a) {
+    __shared__ f32x4 l2s[4][64];
+    const int bxn = (a.w + 7) / 8;
+    const int by = (int)blockIdx.x / bxn, bx = (int)blockIdx.x - by * bxn;
+    const int sub = threadIdx.x >> 6, q0 = threadIdx.x & 63;
+    const int c4 = a.c / 4;
+    const int y0 = by * 8 + (sub >> 1) * 4, x0 = bx * 8 + (sub & 1) * 4;
+    const int h1 = a.h / 2, w1 = a.w / 2, h2 = h1 / 2, w2 = w1 / 2, h3 = h2 / 2, w3 = w2 / 2;
+    for (int qb = 0; qb < c4; qb += 64) {                  // (uniform trip count: the barriers below are reached by all)
+        const int q = qb + q0;
+        const bool qok = q < c4;
+        f32x4 p[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int y = y0 + i, x = x0 + j;
+                const bool ok = qok && y < a.h && x < a.w;
+                p[i][j] = ok ? *(const f32x4*)(a.in + ((int64_t)y * a.w + x) * a.c + q * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+                if (ok) pyr_split<TERMS>(a.split[0], (int64_t)y * a.w + x, a.c, q, p[i][j]);
+            }
+        f32x4 o1[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    o1[i][j][k] = (p[2 * i][2 * j][k] + p[2 * i][2 * j + 1][k] + p[2 * i + 1][2 * j][k] + p[2 * i + 1][2 * j + 1][k]) * 0.25f;
+                const int y = y0 / 2 + i, x = x0 / 2 + j;
+                if (a.levels > 1 && qok && y < h1 && x < w1) {
+                    const int64_t pix = (int64_t)y * w1 + x;
+                    *(f32x4*)(a.pooled[0] + pix * a.c + q * 4) = o1[i][j];
+                    pyr_split<TERMS>(a.split[1], pix, a.c, q, o1[i][j]);
+                }
+            }
+        f32x4 o2;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o2[k] = (o1[0][0][k] + o1[0][1][k] + o1[1][0][k] + o1[1][1][k]) * 0.25f;
+        {
+            const int y = y0 / 4, x = x0 / 4;
+            if (a.levels > 2 && qok && y < h2 && x < w2) {
+                const int64_t pix = (int64_t)y * w2 + x;
+                *(f32x4*)(a.pooled[1] + pix * a.c + q * 4) = o2;
+                pyr_split<TERMS>(a.split[2], pix, a.c, q, o2);
+            }
+        }
+        __syncthreads();                                   // (l2s of the previous channel pass is consumed)
+        l2s[sub][q0] = o2;
+        __syncthreads();
+        if (sub == 0 && a.levels > 3 && qok && by < h3 && bx < w3) {
+            f32x4 o3;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o3[k] = (l2s[0][q0][k] + l2s[1][q0][k] + l2s[2][q0][k] + l2s[3][q0][k]) * 0.25f;
+            const int64_t pix = (int64_t)by * w3 + bx;
+            *(f32x4*)(a.pooled[2] + pix * a.c + q * 4) = o3;
+            pyr_split<TERMS>(a.split[3], pix, a.c, q, o3);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int woft_abi_version(void) { return 10000 * 0 + 100 * 1 + 0; }
@@ -218,4 +304,25 @@ extern "C" int woft_sizeof(int which) {
     if (which == 1) return (int)sizeof(woft_lookup_params);
     if (which == 2) return (int)sizeof(woft_lookup_otf_params);
     return -1;
+}
+
+extern "C" int woft_feature_pyramid(const float* in, int32_t h, int32_t w, int32_t c, int32_t levels, float* const* pooled,
+                                    void* const* split, int32_t terms, void* stream) {
+    if (!in || !pooled || !split || h <= 0 || w <= 0 || c <= 0 || c % 32 != 0 || levels < 1 || levels > 4 ||
+        (terms != 1 && terms != 3))
+        return WOFT_EINVAL;
+    PyrArgs a;
+    a.in = in; a.h = h; a.w = w; a.c = c; a.levels = levels;
+    for (int l = 0; l < 4; ++l) {
+        a.split[l] = l < levels ? (__bf16*)split[l] : nullptr;
+        if (l < levels && a.split[l] == nullptr) return WOFT_EINVAL;
+        if (l >= 1) {
+            a.pooled[l - 1] = l < levels ? pooled[l - 1] : nullptr;
+            if (l < levels && a.pooled[l - 1] == nullptr) return WOFT_EINVAL;
+        }
+    }
+    const dim3 grid((unsigned)(((h + 7) / 8) * ((w + 7) / 8)));
+    if (terms == 3) hipLaunchKernelGGL(feature_pyramid_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(feature_pyramid_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    return woft_launch_status();
 }

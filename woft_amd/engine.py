@@ -35,6 +35,7 @@ FUSE_FLOWHEAD = os.environ.get("WOFT_FUSE_FLOWHEAD", "1") != "0"
 # motion encoder: the correlation branch (convc1 -> convc2) and the flow branch (convf1 -> convf2) are independent until
 # `conv` joins them (update.py:89-97): first layers in one launch, second layers in one launch (woft_conv2d_pair)
 PAIR_BRANCHES = os.environ.get("WOFT_PAIR", "1") != "0"
+PYRAMID_ONE_LAUNCH = os.environ.get("WOFT_PYRAMID", "1") != "0"    # target pyramid (pool + split of all levels) in one launch
 # the flow-head gather of iteration k runs inside the lookup launch of iteration k + 1 (volume-free lookup; the last
 # iteration's as its own launch): one launch fewer per iteration, same operations in the same order (0: always its own launch)
 FOLD_GATHER = os.environ.get("WOFT_FOLD_GATHER", "1") != "0"
@@ -492,6 +493,9 @@ class _Plan:
         prog = []
         alpha = 1.0 / math.sqrt(float(sp.fdim))
         x3 = self.prec_corr == "bf16x3"
+        if self.otf and PYRAMID_ONE_LAUNCH and sp.fdim % 32 == 0 and self.f2act[0].cs == sp.fdim and sp.levels <= 4:
+            # pooled maps and split operands of all levels in one launch (was 2 * levels - 1 launches)
+            return [("pyramid", ops.PyramidArgs(self.f2act[:sp.levels], self.f2s[:sp.levels], 3 if x3 else 1))]
         for l in range(sp.levels):
             if l > 0:
                 prog.append(("pool", (self.f2act[l - 1], self.f2act[l])))
@@ -613,6 +617,8 @@ class _Plan:
                     self._join_ev.record()
             elif kind == "join":
                 torch.cuda.current_stream().wait_event(self._join_ev)
+            elif kind == "pyramid":
+                ops.feature_pyramid(a)
             elif kind == "pool":
                 ops.avgpool2(a[0], a[1])
             elif kind == "split":

@@ -173,7 +173,8 @@ USE_HALO = os.environ.get("WOFT_HALO", "1") != "0"
 USE_REGB = os.environ.get("WOFT_REGB", "1") != "0"
 USE_REGB1 = os.environ.get("WOFT_REGB1", "0") != "0"      # (measured: 45 vs 37 us on convc1 -- the 64 x 64 gather tiles win)
 REGB_TY4 = os.environ.get("WOFT_REGB_TY4", "1") != "0"
-HALO_TILES = {1: (8, 16, 1), 2: (9, 9, 1), 4: (4, 16, 1), 6: (6, 16, 1), 8: (8, 16, 1), 12: (4, 16, 1)}     # (TY, TX, images per workgroup)
+USE_STEM = os.environ.get("WOFT_STEM", "1") != "0"        # 7x7 / stride-2 first layer on conv_stem.hip (0: gather kernel)
+HALO_TILES = {1: (8, 16, 1), 2: (9, 9, 1), 4: (4, 16, 1), 6: (6, 16, 1), 7: (8, 16, 1), 8: (8, 16, 1), 12: (4, 16, 1)}     # (TY, TX, images per workgroup)
 HALO_MIN_BLOCKS = int(os.environ.get("WOFT_HALO_MIN_BLOCKS", "400"))
 WH_HALO = int(os.environ.get("WOFT_WH_HALO", "2"))
 
@@ -270,6 +271,14 @@ def conv_params(x, pc, out, co_off=0, epi=_lib.EPI_LINEAR, x2=None, c_split=0, e
                             p.cout_pad = _round_up(p.cout, 64)
                     halo = 1 if b816 * (p.cout_pad // tn) >= HALO_MIN_BLOCKS else 4
                 p.tile_n = tn
+    # the encoders' first layer (7x7, stride 2, 3 -> 64 on the NHWC4 image, flat packing): its own kernel (conv_stem.hip, halo 7)
+    # -- bit-identical to the gather kernel, 8x16-pixel tiles (the statistics rows follow them)
+    if USE_STEM and auto_halo and halo == 0 and tiles is None and p.precision != 0 and pc.flat and x.cs == 4 and x2 is None \
+            and (pc.taps_y, pc.taps_x, pc.stride, pc.pad_y, pc.pad_x, pc.cin_pad) == (7, 1, 2, 3, 3, 32) \
+            and pc.cout_pad % 64 == 0 and not in_norm and bias_map is None and wh0 is None \
+            and (ho, wo) == ((x.h - 1) // 2 + 1, (x.w - 1) // 2 + 1):
+        halo = 7
+        p.tile_n = tn = 64
     # stride-1 multi-tap layers without InstanceNorm plumbing: the kernel that streams the weights global -> registers
     # (conv_regb.hip, halo 8) -- bit-identical, 1-8 % faster per layer on the update block's shapes (tools/regb_check.py)
     if USE_REGB and auto_halo and halo in (1, 4) and tiles is None and stats is None and not in_norm and p.precision != 0:
@@ -439,6 +448,26 @@ def inorm_apply(x, mean, rstd, out, mode, res=None, res_stats=None, res_mode=0):
     check(_lib.load().woft_inorm_apply(ptr(x.t), ptr(mean), ptr(rstd), ptr(res.t) if res is not None else None,
                                        ptr(rm), ptr(rr), res_mode, ptr(out.t), x.n_pix, x.cs, mode, stream_ptr()),
           "woft_inorm_apply")
+
+
+class PyramidArgs:
+    """Pointer tables of woft_feature_pyramid, built once (kept alive with the tensors they point to)."""
+    def __init__(self, maps, splits, terms):
+        import ctypes
+        self.maps, self.splits, self.terms = maps, splits, terms
+        self.levels = len(maps)
+        assert 1 <= self.levels <= 4 and len(splits) == self.levels and all(m.cs == maps[0].cs == m.c for m in maps)
+        for l in range(1, self.levels):
+            assert (maps[l].h, maps[l].w) == (maps[l - 1].h // 2, maps[l - 1].w // 2)
+        self.pooled = (ctypes.c_void_p * 3)(*[maps[l].t.data_ptr() if l < self.levels else None for l in range(1, 4)])
+        self.split = (ctypes.c_void_p * 4)(*[splits[l].data_ptr() if l < self.levels else None for l in range(4)])
+
+
+def feature_pyramid(a):
+    """maps[0] -> pooled maps[1:] (avgpool2 chained) and every level's split correlation operand, one launch."""
+    m = a.maps[0]
+    check(_lib.load().woft_feature_pyramid(ptr(m.t), m.h, m.w, m.cs, a.levels, a.pooled, a.split, a.terms, stream_ptr()),
+          "woft_feature_pyramid")
 
 
 def preprocess(img_u8, out, hp, wp, pad_top, pad_left):
