@@ -110,7 +110,7 @@ def main():
     ap.add_argument("--corr", default="otf", choices=["volume", "otf"],
                     help="correlation: volume-free on-the-fly lookup (default in the split-bf16 precisions) or the "
                          "all-pairs volume in HBM whose lookup is the HBM-roofline kernel (bit-identical results; "
-                         "fp32 precision always uses the volume)")
+                         "the exact-fp32 passes are volume-free too since round 3: WOFT_FP32_CORR=volume for the A/B)")
     ap.add_argument("--full-weight-head", action="store_true",
                     help="evaluate the weight head on every template pixel, as the reference's network does, instead of "
                          "only where the tracker reads the weights (its template mask: the tracker's default; identical "
@@ -172,7 +172,8 @@ def main():
         conf.flow_config.iters = args.iters
         conf.flow_config.precision = precision
         conf.flow_config.graph = graph
-        conf.flow_config.corr = (corr or args.corr) if precision != "fp32" else "volume"
+        # (exact fp32: volume-free since round 3 -- bit-identical to the volume path, no P x P buffer; WOFT_FP32_CORR=volume: A/B)
+        conf.flow_config.corr = (corr or args.corr) if precision != "fp32" else (corr or os.environ.get("WOFT_FP32_CORR", "otf"))
         trk = conf.tracker_class(conf)
         trk.init(template, mask)
         if args.no_template_cache:
@@ -469,7 +470,7 @@ def main():
     if world == 1 and not args.no_ladder:
         # ---- like-for-like ladder: the flow operator doing the reference's FULL work (weight head on every pixel, as
         # WeightedRAFT.forward evaluates it) in the fp32-emulating arithmetic of the headline and in the reference's own
-        # arithmetic class (exact fp32 MFMA products, all-pairs volume); same sequence, same step count each
+        # arithmetic class (exact fp32 MFMA products); same sequence, same step count each
         ladder = {}
         for name, kw in (("bf16x3_full_weight_head", dict(precision="bf16x3", mask_wh=False)),
                          ("fp32_full_weight_head", dict(precision="fp32", mask_wh=False))):

@@ -250,8 +250,9 @@ int woft_corr_lookup(const woft_lookup_params* p, void* stream);
  * extension): the same samples as woft_corr_lookup computed directly from the feature maps,
  * corr_l(p, q) = alpha * <f1[p], f2_l[q]>, f2_l = fmap2 average-pooled l times -- no P x P volume in memory.
  * f1 / f2[l]: row-major split operands in the format of woft_corr_gemm_bf16 (terms = 3: woft_split_bf16_lines,
- * terms = 1: the bf16 plane), one row of k features per pixel; every correlation value is the one that GEMM
- * would have produced (same products, same order).  Cost grows with the spread of the flow inside each 8 x 8
+ * terms = 1: the bf16 plane; terms = 0, exact fp32: the fp32 feature rows themselves, k % 32 == 0, products on
+ * v_mfma_f32_32x32x2_f32 in the order of woft_conv2d's fp32 kernel), one row of k features per pixel; every correlation
+ * value is the one that GEMM would have produced (same products, same order).  Cost grows with the spread of the flow inside each 8 x 8
  * block of source pixels (bounding box of their windows); results do not depend on it. */
 typedef struct woft_lookup_otf_params {
     const void* f1;         /* [hf*wf][k] source features (split)                                  */

@@ -50,7 +50,7 @@ def test_bench_line_carries_ladder_and_lost_frames():
     d = json.loads([l for l in out.stdout.splitlines() if l.lstrip().startswith("{")][-1])
     lad = d["reference_work"]
     assert lad["bf16x3_full_weight_head"]["tracks_identical_to_timed_run"] is True
-    assert lad["fp32_full_weight_head"]["correlation"] == "volume" and lad["fp32_full_weight_head"]["steps"] >= 20
+    assert lad["fp32_full_weight_head"]["correlation"] == "otf" and lad["fp32_full_weight_head"]["steps"] >= 20
     lf = d["lost_frame"]
     assert lf["lost_frames"] == lf["frames"] // lf["forced_every"] > 0
     assert lf["lost_frame_ms"] > lf["normal_frame_ms"] > 0 and lf["frame_after_lost_ms"] > 0

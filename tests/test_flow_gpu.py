@@ -184,7 +184,8 @@ def test_reduced_precision_operating_points(golden_dir, precision, epe_mean, epe
 
 @torch.no_grad()
 @pytest.mark.parametrize("precision,corr,epe_mean,epe_max,wtol", [
-    ("fp32", "volume", 1e-3, 1e-2, 1e-4), ("bf16x3", "otf", 1e-3, 1e-2, 1e-4), ("bf16x3", "volume", 1e-3, 1e-2, 1e-4),
+    ("fp32", "volume", 1e-3, 1e-2, 1e-4), ("fp32", "otf", 1e-3, 1e-2, 1e-4), ("bf16x3", "otf", 1e-3, 1e-2, 1e-4),
+    ("bf16x3", "volume", 1e-3, 1e-2, 1e-4),
     ("bf16", "otf", 0.15, 1.0, 5e-3), ("bf16", "volume", 0.15, 1.0, 5e-3), ("fp16", "otf", 0.03, 0.3, 2e-3),
     ("fp16", "volume", 0.03, 0.3, 2e-3)])
 def test_32_iterations_vs_reference_golden(golden_dir, precision, corr, epe_mean, epe_max, wtol):
@@ -323,7 +324,7 @@ def test_weights_postprocessing_fn_and_backbone_model(tmp_path):
 
 
 @torch.no_grad()
-@pytest.mark.parametrize("precision,small", [("bf16x3", False), ("bf16", False), ("bf16x3", True)])
+@pytest.mark.parametrize("precision,small", [("bf16x3", False), ("bf16", False), ("bf16x3", True), ("fp32", False), ("fp32", True)])
 def test_volume_free_correlation_matches_volume(precision, small):
     """corr='otf' (the lookup computed from the feature maps, no P x P volume; what the reference's alternate_corr
     selects, corr.py:72-100) gives the same flow and weights as the volume path of the same precision."""
@@ -344,7 +345,7 @@ def test_volume_free_correlation_matches_volume(precision, small):
     assert np.array_equal(outs["otf"][0], outs["volume"][0])
     if not small:
         assert np.array_equal(outs["otf"][1], outs["volume"][1])
-    # it is the default in these precisions; fp32 keeps the volume
+    # it is the default in every precision (exact fp32 since round 3: fp32-MFMA instantiation of the volume-free lookup)
     c = _flow_config(sd, 5, raft_type=rt, padding_mode="RAFT", small=small, precision=precision)
     assert c.of_class(c).engine.corr == "otf"
     if precision == "bf16":
@@ -360,7 +361,7 @@ def test_volume_free_correlation_matches_volume(precision, small):
         print(f"bf16-storage volume vs fp32-storage volume: EPE mean {d.mean():.2e} max {d.max():.2e}")
         assert 0 < d.mean() < 0.05
     c = _flow_config(sd, 5, raft_type=rt, padding_mode="RAFT", small=small, precision="fp32")
-    assert c.of_class(c).engine.corr == "volume"
+    assert c.of_class(c).engine.corr == "otf"
 
 
 @torch.no_grad()
@@ -422,7 +423,7 @@ def test_degenerate_inputs_vs_reference(golden_dir, name, precision, epe_mean, e
 
 
 @torch.no_grad()
-@pytest.mark.parametrize("precision,corr,epe_mean,epe_max,wtol", [("bf16x3", "otf", 1e-3, 1e-2, 1e-4), ("fp32", "volume", 1e-3, 1e-2, 1e-4),
+@pytest.mark.parametrize("precision,corr,epe_mean,epe_max,wtol", [("bf16x3", "otf", 1e-3, 1e-2, 1e-4), ("fp32", "otf", 1e-3, 1e-2, 1e-4),
                                                                     ("bf16", "otf", 5e-2, 0.5, 5e-3), ("fp16", "otf", 1e-2, 0.1, 1e-3)])
 def test_real_frames_720p_vs_reference(golden_dir, precision, corr, epe_mean, epe_max, wtol):
     """BASELINE config 2 at its REAL size on REAL frames: a 720 x 1280 pair of the reference's demo sequence (decoded

@@ -846,14 +846,15 @@ def test_bf16_storage_volume(ops, h, w, precision):
 
 
 @pytest.mark.parametrize("h,w,precision,spread", [(17, 25, "bf16x3", 2.0), (24, 40, "bf16x3", 30.0), (16, 20, "bf16", 3.0),
-                                                  (9, 11, "bf16x3", 200.0)])
+                                                  (9, 11, "bf16x3", 200.0), (17, 25, "fp32", 2.0), (24, 40, "fp32", 30.0),
+                                                  (9, 11, "fp32", 200.0)])
 def test_lookup_on_the_fly(ops, h, w, precision, spread):
     """Volume-free lookup (woft_corr_lookup_otf) == lookup in the volume built by the correlation GEMM in the same
     arithmetic, bit for bit (identical correlation values, identical interpolation), for smooth, scattered and
     far-out-of-map coordinates."""
     c = 256
     f1, f2 = _rand(1, c, h, w, seed=51), _rand(1, c, h, w, seed=52)
-    vols, dims = _build_pyramid_gpu(ops, f1, f2, precision, presplit=True)
+    vols, dims = _build_pyramid_gpu(ops, f1, f2, precision, presplit=precision != "fp32")     # (fp32: the fp32-MFMA GEMM)
     coords = raft_ref.coords_grid(1, h, w) + _rand(1, 2, h, w, seed=53, scale=spread)
     coords[0, :, 0, 0] = torch.tensor([-7.3, 2.2])
     coords[0, :, h - 1, w - 1] = torch.tensor([w + 9.5, h + 3.0])
@@ -865,6 +866,8 @@ def test_lookup_on_the_fly(ops, h, w, precision, spread):
     a1, a2 = ops.act_from_nchw(f1), ops.act_from_nchw(f2)
 
     def split(t):
+        if precision == "fp32":             # terms = 0: the fp32 feature rows themselves
+            return t
         o = torch.zeros(t.shape[0], c * (2 if x3 else 1), dtype=torch.bfloat16, device="cuda")
         ops.split_bf16_lines(t, o) if x3 else ops.split_bf16(t, o, None)
         return o
@@ -876,7 +879,8 @@ def test_lookup_on_the_fly(ops, h, w, precision, spread):
             ops.avgpool2(cur, nxt)
             cur = nxt
     out = torch.full((h * w, 352), 7.0, device="cuda")
-    ops.run_lookup_otf(ops.make_lookup_otf_params(split(a1.t.contiguous()), f2s, dims, h, w, c, cg, out, 4, 3 if x3 else 1))
+    terms = 3 if x3 else (0 if precision == "fp32" else 1)
+    ops.run_lookup_otf(ops.make_lookup_otf_params(split(a1.t.contiguous()), f2s, dims, h, w, c, cg, out, 4, terms))
     torch.cuda.synchronize()
     assert torch.equal(out[:, :324], ref[:, :324]), "on-the-fly lookup differs from the lookup in the volume"
     assert float((out[:, 324:] - 7.0).abs().max()) == 0.0

@@ -43,9 +43,13 @@ __global__ __launch_bounds__(TW * 32, 2) void corr_lookup_otf_kernel(const woft_
     constexpr int NWV = NT / 64;                        // waves: NPX / 32 row groups x 2 column halves
     constexpr int TSH = (TW == 16) ? 4 : 3;             // log2(TW)
     constexpr int NW = 2 * R + 1, N2 = NW * NW;
-    constexpr int LD = (TERMS == 3) ? 2 * K : K;        // elements per operand row
+    // TERMS = 0 (exact fp32, round 3): the operand rows are the fp32 feature rows themselves -- a 128-byte line holds 32 k,
+    // a sub-step is 8 x v_mfma_f32_32x32x2_f32 on the k pairs (16 hh + 8 s2 + s, hh = 0 / 1), lines and sub-steps in
+    // conv_mfma_f32_kernel's order: every correlation value is bit-identical to the fp32 volume's.  Same ring, same boxes.
+    constexpr int NPL = (TERMS == 1) ? 1 : 2;           // 16-byte fragments per lane, line and sub-step (hi, lo | two fp32 quads)
+    constexpr int LD = (TERMS == 1) ? K : 2 * K;        // bf16-sized elements per operand row (fp32: K floats = 2 K of them)
     constexpr int NK = LD / 64;                         // K steps (one 128-byte line each)
-    constexpr int NSUB = (TERMS == 3) ? 2 : 4;          // MFMA k sub-steps per line
+    constexpr int NSUB = (TERMS == 1) ? 4 : 2;          // MFMA k sub-steps per line
     // LDS ring of B rows: NST stages of one K step each, consumed GS steps per workgroup barrier, DEPTH groups in flight
     // beyond the one being computed.  Where the time goes (round-2 ablation, tools/bench_lookup_otf.py OTF_ABL bits +
     // s_memtime stamps, 1080p, 89 us): without the target-row stream -6 us, without MFMAs -21 us, without both
@@ -136,7 +140,7 @@ __global__ __launch_bounds__(TW * 32, 2) void corr_lookup_otf_kernel(const woft_
     // The block's source features stay in REGISTERS for the whole kernel, as the MFMA A fragments of this wave's
     // 32 rows (lane (r32, hh): row r32, k = 8 (2 s + hh) .. + 7 of every line; hi and lo halves of the line) -- the
     // first version re-fetched the A tile with every 64-column chunk and was bound by that L2 -> LDS traffic.
-    bf16x8 afr[NK][NSUB][TERMS == 3 ? 2 : 1];
+    bf16x8 afr[NK][NSUB][NPL];
     {
         const int m = wm * 32 + r32;
         int y = py0 + (m >> TSH), x = px0 + (m & (TW - 1));
@@ -147,8 +151,13 @@ __global__ __launch_bounds__(TW * 32, 2) void corr_lookup_otf_kernel(const woft_
         for (int ks = 0; ks < NK; ++ks)
 #pragma unroll
             for (int s2 = 0; s2 < NSUB; ++s2) {
-                afr[ks][s2][0] = *(const bf16x8*)(row + ks * 128 + (s2 * 2 + hh) * 16);
-                if (TERMS == 3) afr[ks][s2][TERMS == 3 ? 1 : 0] = *(const bf16x8*)(row + ks * 128 + 64 + (s2 * 2 + hh) * 16);
+                if (TERMS == 0) {
+                    afr[ks][s2][0] = *(const bf16x8*)(row + ks * 128 + hh * 64 + s2 * 32);
+                    afr[ks][s2][NPL - 1] = *(const bf16x8*)(row + ks * 128 + hh * 64 + s2 * 32 + 16);
+                } else {
+                    afr[ks][s2][0] = *(const bf16x8*)(row + ks * 128 + (s2 * 2 + hh) * 16);
+                    if (TERMS == 3) afr[ks][s2][NPL - 1] = *(const bf16x8*)(row + ks * 128 + 64 + (s2 * 2 + hh) * 16);
+                }
             }
     }
     // B stream: the 8 DMA pieces of a step (piece q = rows 8 q .. 8 q + 7 of the 64 box positions) are issued by
@@ -293,13 +302,18 @@ __global__ __launch_bounds__(TW * 32, 2) void corr_lookup_otf_kernel(const woft_
                 // before the MFMAs of sub-step u (two register sets) -- left alone the compiler reads, waits out the LDS
                 // latency and only then issues the three MFMAs, every sub-step
                 constexpr int NU = GS * NSUB;
-                bf16x8 bq[2][TERMS == 3 ? 2 : 1];
+                bf16x8 bq[2][NPL];
                 auto load_b = [&](auto u_tag) {
                     constexpr int u = decltype(u_tag)::value;
                     constexpr int e = u / NSUB, s2 = u % NSUB;
                     const __bf16* br = b_rows + ((s0 + kg * GS + e) % NST) * 4096;
-                    bq[u & 1][0] = *(const bf16x8*)(br + ((s2 * 2 + hh) ^ sw) * 8);
-                    if (TERMS == 3) bq[u & 1][TERMS == 3 ? 1 : 0] = *(const bf16x8*)(br + ((4 + s2 * 2 + hh) ^ sw) * 8);
+                    if (TERMS == 0) {
+                        bq[u & 1][0] = *(const bf16x8*)(br + ((hh * 4 + s2 * 2) ^ sw) * 8);
+                        bq[u & 1][NPL - 1] = *(const bf16x8*)(br + ((hh * 4 + s2 * 2 + 1) ^ sw) * 8);
+                    } else {
+                        bq[u & 1][0] = *(const bf16x8*)(br + ((s2 * 2 + hh) ^ sw) * 8);
+                        if (TERMS == 3) bq[u & 1][NPL - 1] = *(const bf16x8*)(br + ((4 + s2 * 2 + hh) ^ sw) * 8);
+                    }
                 };
                 if (!(p.ablate & 2)) {
                     load_b(std::integral_constant<int, 0>{});
@@ -315,9 +329,16 @@ __global__ __launch_bounds__(TW * 32, 2) void corr_lookup_otf_kernel(const woft_
                                 if (OTF_IL && feed) issue_piece((g + DEPTH) * GS + pc / QPW, pc % QPW);
                             }
                             const bf16x8 bh = bq[u & 1][0];
-                            if (TERMS == 3) {
-                                const bf16x8 bl = bq[u & 1][TERMS == 3 ? 1 : 0];
-                                const bf16x8 ah = afr[ks][s2][0], al = afr[ks][s2][TERMS == 3 ? 1 : 0];
+                            if (TERMS == 0) {
+                                const f32x4 a0 = __builtin_bit_cast(f32x4, afr[ks][s2][0]), a1 = __builtin_bit_cast(f32x4, afr[ks][s2][NPL - 1]);
+                                const f32x4 b0 = __builtin_bit_cast(f32x4, bh), b1 = __builtin_bit_cast(f32x4, bq[u & 1][NPL - 1]);
+#pragma unroll
+                                for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b0[s], acc, 0, 0, 0);
+#pragma unroll
+                                for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b1[s], acc, 0, 0, 0);
+                            } else if (TERMS == 3) {
+                                const bf16x8 bl = bq[u & 1][NPL - 1];
+                                const bf16x8 ah = afr[ks][s2][0], al = afr[ks][s2][NPL - 1];
                                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);   // (order of corr_gemm_bf16_kernel)
                                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
                                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
@@ -384,9 +405,9 @@ extern "C" int woft_corr_lookup_otf(const woft_lookup_otf_params* pp, void* stre
     if (!pp) return WOFT_EINVAL;
     const woft_lookup_otf_params& p = *pp;
     if (p.levels < 1 || p.levels > 4 || !p.f1 || !p.coords || !p.out || p.hf <= 0 || p.wf <= 0) return WOFT_EINVAL;
-    if (p.terms != 1 && p.terms != 3) return WOFT_EINVAL;
-    if (p.k <= 0 || p.k % (p.terms == 3 ? 32 : 64) != 0) return WOFT_EINVAL;
-    const int64_t row_bytes = (int64_t)p.k * (p.terms == 3 ? 4 : 2);
+    if (p.terms != 0 && p.terms != 1 && p.terms != 3) return WOFT_EINVAL;
+    if (p.k <= 0 || p.k % (p.terms == 1 ? 64 : 32) != 0) return WOFT_EINVAL;
+    const int64_t row_bytes = (int64_t)p.k * (p.terms == 1 ? 2 : 4);
     if ((int64_t)p.hf * p.wf * row_bytes >= (1ll << 32)) return WOFT_EINVAL;        // 32-bit lane offsets
     for (int l = 0; l < p.levels; ++l)
         if (!p.f2[l] || p.h[l] <= 0 || p.w[l] <= 0 || (int64_t)p.h[l] * p.w[l] * row_bytes >= (1ll << 32)) return WOFT_EINVAL;
@@ -401,8 +422,11 @@ extern "C" int woft_corr_lookup_otf(const woft_lookup_otf_params* pp, void* stre
     // per barrier -- the per-workgroup chain of K steps binds.)
     dim3 grid((unsigned)(((p.wf + 7) / 8) * ((p.hf + 7) / 8)));
 #define OTF(T, RR, KK) woft_launch(0, corr_lookup_otf_kernel<T, RR, KK, 8>, grid, dim3(256), 0, s, p)
-    if (p.k == 256 && p.radius == 4) { if (p.terms == 3) OTF(3, 4, 256); else OTF(1, 4, 256); }       /* full model  */
-    else if (p.k == 128 && p.radius == 3) { if (p.terms == 3) OTF(3, 3, 128); else OTF(1, 3, 128); }  /* small model */
+    if (p.k == 256 && p.radius == 4) {                                                                /* full model  */
+        if (p.terms == 3) OTF(3, 4, 256); else if (p.terms == 0) OTF(0, 4, 256); else OTF(1, 4, 256);
+    } else if (p.k == 128 && p.radius == 3) {                                                         /* small model */
+        if (p.terms == 3) OTF(3, 3, 128); else if (p.terms == 0) OTF(0, 3, 128); else OTF(1, 3, 128);
+    }
     else return WOFT_EINVAL;
 #undef OTF
     return woft_launch_status();

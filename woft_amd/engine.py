@@ -118,8 +118,6 @@ class RaftEngine:
             raise ValueError(f"precision must be one of {sorted(ops.PRECISION)}")
         if corr not in ("volume", "otf"):
             raise ValueError("corr must be 'volume' or 'otf'")
-        if corr == "otf" and precision == "fp32":
-            raise ValueError("corr='otf' runs on the split-bf16 matrix-core path: precision 'bf16x3' or 'bf16'")
         self.precision = precision
         # arithmetic of the correlation (volume GEMM / volume-free lookup) and of the weight head's convolutions
         self.prec_corr = self.prec_wh = "bf16x3" if precision == "fp16" else precision
@@ -240,6 +238,8 @@ class _Plan:
         bf = lambda rows: (torch.zeros(rows.shape[0], rows.shape[1] * (2 if x3 else 1), dtype=torch.bfloat16, device=dev)
                            if self.prec != "fp32" else None)       # GEMM operand: [hi|lo] lines / bf16 plane
         self.f1s = bf(self.f1rows)
+        if eng.corr == "otf" and self.prec == "fp32":
+            self.f1s = self.f1rows      # exact fp32 (terms = 0): the volume-free lookup reads the fp32 feature rows themselves
         # target feature pyramid: linear NHWC maps (f2act) and their rows in 4x4-tile order (f2rows, the B
         # operand of the correlation GEMM, zero padded to the N tile) -> volumes in the tiled layout
         # (corr = "otf": no volume; the lookup reads the row-major split maps f2s directly)
@@ -251,7 +251,7 @@ class _Plan:
             self.dims.append((h, w))
             self.f2act.append(new_act(1, h, w, sp.fdim, zero=True))
             if self.otf:
-                self.f2s.append(bf(self.f2act[-1].t))
+                self.f2s.append(bf(self.f2act[-1].t) if self.prec != "fp32" else self.f2act[-1].t)
             else:
                 n = ops.tiled_dims(h, w)[2]
                 rows = z(_ru(n, 128), sp.fdim)
@@ -300,7 +300,7 @@ class _Plan:
         self.delta = new_act(1, hf, wf, 2, cs=4, zero=True)
         if self.otf:
             self.lookup = ops.make_lookup_otf_params(self.f1s, self.f2s, self.dims, hf, wf, sp.fdim, self.coords,
-                                                     self.corr.t, sp.radius, 3 if x3 else 1)
+                                                     self.corr.t, sp.radius, 3 if x3 else (0 if self.prec == "fp32" else 1))
         else:
             self.lookup = ops.make_lookup_params(self.vol, self.dims, self.coords, self.corr.t, sp.radius)
         self.prog_iter_first = self._iter_program(first=True)
@@ -493,14 +493,15 @@ class _Plan:
         prog = []
         alpha = 1.0 / math.sqrt(float(sp.fdim))
         x3 = self.prec_corr == "bf16x3"
-        if self.otf and PYRAMID_ONE_LAUNCH and sp.fdim % 32 == 0 and self.f2act[0].cs == sp.fdim and sp.levels <= 4:
+        if self.otf and self.prec != "fp32" and PYRAMID_ONE_LAUNCH and sp.fdim % 32 == 0 and self.f2act[0].cs == sp.fdim and sp.levels <= 4:
             # pooled maps and split operands of all levels in one launch (was 2 * levels - 1 launches)
             return [("pyramid", ops.PyramidArgs(self.f2act[:sp.levels], self.f2s[:sp.levels], 3 if x3 else 1))]
         for l in range(sp.levels):
             if l > 0:
                 prog.append(("pool", (self.f2act[l - 1], self.f2act[l])))
-            if self.otf:        # only the operands: pooled maps, split once
-                prog.append(("split", (self.f2act[l].t, self.f2s[l])))
+            if self.otf:        # only the operands: pooled maps, split once (exact fp32: the maps themselves)
+                if self.prec != "fp32":
+                    prog.append(("split", (self.f2act[l].t, self.f2s[l])))
                 continue
             prog.append(("tile", (self.f2act[l], self.f2rows[l])))
             if self.prec == "fp32":

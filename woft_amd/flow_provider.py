@@ -70,13 +70,9 @@ class RAFTWrapper:
         self.precision = os.environ.get("WOFT_PRECISION") or self.C.precision or \
             ("fp16" if cp.mixed_precision else "fp32")
         # correlation: "volume" (all-pairs volume + pyramid in HBM, corr.py:13-69) or "otf" (volume-free lookup, what
-        # the reference's `alternate_corr` switch selects, corr.py:72-100).  Bit-identical results in the split-bf16
-        # precisions, where "otf" is faster and needs no P x P buffer: it is the default there.
-        self.corr = os.environ.get("WOFT_CORR") or getattr(self.C, "corr", None) or \
-            ("otf" if cp.alternate_corr or self.precision != "fp32" else "volume")
-        if self.corr == "otf" and self.precision == "fp32":
-            raise ValueError("alternate_corr / corr='otf' runs on the split-bf16 matrix-core path: set precision "
-                             "'bf16x3' (fp32-emulating) or 'bf16'")
+        # the reference's `alternate_corr` switch selects, corr.py:72-100).  Bit-identical results in every precision
+        # (exact fp32 included: the lookup's fp32-MFMA instantiation), "otf" is faster and needs no P x P buffer: the default.
+        self.corr = os.environ.get("WOFT_CORR") or getattr(self.C, "corr", None) or "otf"
         # flow config key `volume_storage` ("fp32" | "bf16"): element type of the correlation volume (corr = "volume")
         self.engine = RaftEngine(state_dict, small=small, weighted=weighted, precision=self.precision, corr=self.corr,
                                  volume_storage=getattr(self.C, "volume_storage", None))
