@@ -27,6 +27,10 @@
 #ifndef OTF_IL
 #define OTF_IL 0                 // 1: DMA pieces issued one per k sub-step instead of four in a row after the barrier
 #endif
+#ifndef OTF_PIPE
+#define OTF_PIPE 0               // 1: the window drop of chunk c - 1 is spread over the MFMA sub-steps of chunk c (see the chunk loop):
+#endif                           //    bit-identical (tested), 81.3 vs 81.9 us alone and +-0 in a frame (A/B in one call) -- the drop was not
+                                 //    the chunk's exposed cost (round-2 ablation: 51 of 89 us remain without MFMAs, stream and drops); off
 #ifndef OTF_SAMPLE_UNROLL
 #define OTF_SAMPLE_UNROLL 3      // unroll factor of the sampling loop (21: fully unrolled)
 #endif
@@ -65,6 +69,7 @@ __global__ __launch_bounds__(TW * 32, 2) void corr_lookup_otf_kernel(const woft_
     __shared__ int2 s_w0[NPX];                          // window origin (x, y) of every source pixel at the current level
     __shared__ float s_fx[NPX], s_fy[NPX];
     __shared__ float2 s_cc[NPX];                         // lookup centre of every source pixel (level 0 units)
+    __shared__ float s_dump[NT];                         // where a lane's accumulator element goes when no window wants it (OTF_PIPE)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -281,10 +286,37 @@ __global__ __launch_bounds__(TW * 32, 2) void corr_lookup_otf_kernel(const woft_
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         int c0 = 0;
+        // OTF_PIPE (build-time experiment, measured neutral): hypothesis -- the two workgroups of a CU run in phase, so a chunk
+        // costs its MFMAs (both waves of a SIMD serialised on the matrix pipe) PLUS its window drop, nothing overlapping.
+        // The drop of chunk c - 1 (accumulator copy `accp`) is therefore issued one accumulator
+        // element per MFMA sub-step of chunk c -- a wave's vector and LDS instructions issue while its own MFMA runs, the
+        // next (dependent) MFMA waits for the pipe anyway.  Same cells, same values: bit-identical.
+        constexpr int NSTEPS = (NK / GS) * (GS * NSUB);   // MFMA sub-steps per chunk (16; 8 for the small model's split rows)
+        constexpr int RPS = 16 / NSTEPS;                  // accumulator elements dropped per sub-step
+        static_assert(RPS >= 1 && RPS * NSTEPS == 16, "drop schedule: 16 accumulator rows over the sub-steps of a chunk");
+        f32x16 accp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accp[r] = 0.f;
+        int txp = 0, typ = 0;
+        bool okp = false;                                // (first chunk of a level: nothing to drop yet)
+        auto row_of = [&](int r) { return wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh; };
+        int2 w0n = s_w0[row_of(0)];                      // window origin of the next element to drop, one element ahead
+        auto drop_elem = [&](auto r_tag) {
+            constexpr int r = decltype(r_tag)::value;
+            const int2 w0c = w0n;
+            w0n = s_w0[row_of((r + 1) & 15)];            // (read BEFORE this element's write: LDS reads are not moved above LDS writes)
+            const int cx = txp - w0c.x, cy = typ - w0c.y;
+            // (an UNCONDITIONAL store through a selected address -- the window cell, or this lane's own dump word: a
+            //  conditional store is control flow, which ends the scheduling region and the whole drop sinks behind the MFMAs)
+            const bool hit = okp && (unsigned)cx < (unsigned)WS && (unsigned)cy < (unsigned)WS;
+            float* dst = hit ? Wn + (row_of(r) * WLD + cy * WS + cx) : s_dump + tid;
+            *dst = accp[r] * p.alpha;
+        };
         stamp();
         for (int s0 = 0; s0 < S; s0 += NK) {             // one 64-column chunk per iteration, K steps unrolled
-#pragma unroll
-            for (int kg = 0; kg < NK / GS; ++kg) {
+            [&]<int... KGS>(std::integer_sequence<int, KGS...>) {
+            ([&] {
+                constexpr int KG = KGS, kg = KGS;        // (compile time: the drop schedule below names accumulator elements)
                 const int g = s0 / GS + kg;
                 // this group's pieces have landed; those of the following (up to DEPTH - 1) groups may still fly
                 const int rem = G - 1 - g;
@@ -345,14 +377,38 @@ __global__ __launch_bounds__(TW * 32, 2) void corr_lookup_otf_kernel(const woft_
                             } else {
                                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks][s2][0], bh, acc, 0, 0, 0);
                             }
+                            if (OTF_PIPE) {              // element(s) kg * NU + u of the PREVIOUS chunk's drop, under these MFMAs
+                                [&]<int... E>(std::integer_sequence<int, E...>) {
+                                    (drop_elem(std::integral_constant<int, (KG * NU + u) * RPS + E>{}), ...);
+                                }(std::make_integer_sequence<int, RPS>{});
+                                if (TERMS == 3) {        // one MFMA, then a third of the drop's vector work, three times
+                                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                                    __builtin_amdgcn_sched_group_barrier(0x102, 4 * RPS, 0);
+                                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                                    __builtin_amdgcn_sched_group_barrier(0x002, 4 * RPS, 0);
+                                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                                }
+                            }
                             __builtin_amdgcn_sched_barrier(0);
                         }(), ...);
                     }(std::make_integer_sequence<int, NU>{});
                 }
-            }
+            }(), ...);
+            }(std::make_integer_sequence<int, NK / GS>{});
             // ---- chunk complete: every lane drops its 16 correlations (one box position, 16 source pixels) into
             //      the windows that contain that position (zero outside the map = never written) ----
-            {
+            if (OTF_PIPE) {                              // ... during the NEXT chunk's MFMAs (after the loop for the last one)
+                const int pos = c0 + wn * 32 + r32;
+                const int by = pos / bw, bx = pos - by * bw;
+                txp = bx0 + bx;
+                typ = by0 + by;
+                okp = pos < N && !(p.ablate & 4);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    accp[r] = acc[r];
+                    acc[r] = 0.f;
+                }
+            } else {
                 const int pos = c0 + wn * 32 + r32;
                 const int by = pos / bw, bx = pos - by * bw;
                 const int tx = bx0 + bx, ty = by0 + by;  // target pixel of this column
@@ -372,6 +428,16 @@ __global__ __launch_bounds__(TW * 32, 2) void corr_lookup_otf_kernel(const woft_
                 }
             }
             c0 += 64;
+        }
+        if (OTF_PIPE && okp) {                           // the last chunk's drop (the all-reads-first form of the un-pipelined path)
+            int2 w0[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) w0[r] = s_w0[row_of(r)];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cx = txp - w0[r].x, cy = typ - w0[r].y;
+                if (cx >= 0 && cx < WS && cy >= 0 && cy < WS) Wn[row_of(r) * WLD + cy * WS + cx] = accp[r] * p.alpha;
+            }
         }
         stamp();
         __syncthreads();
