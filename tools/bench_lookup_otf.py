@@ -47,6 +47,16 @@ def main():
         for l in range(4):
             print(f"  level {l}: " + ", ".join(f"{n} {int(np.median(d[:, 5 * l + k]))}" for k, n in enumerate(names)))
         print(f"  workgroup total (median cycles): {int(np.median((rows[:, 20] - rows[:, 0]) & 0xffffffff))}")
+    if lp.ablate & 32:      # one chunk (level 0, second chunk), per K-step group: [start, stream landed, barrier, issued, MFMAs done] ... drop
+        import numpy as np
+        torch.cuda.synchronize()
+        rows = out.view(hf, wf, 352)[::8, ::8, 324:348].contiguous().view(torch.int32).cpu().numpy().astype(np.int64).reshape(-1, 24)
+        rows = rows[rows[:, 20] != 0]
+        d = np.diff(rows[:, :22], axis=1) & 0xffffffff
+        names = ["wait stream", "barrier", "issue", "reads+MFMAs", "to next group"]
+        for g in range(4):
+            print(f"  group {g}: " + ", ".join(f"{n} {int(np.median(d[:, 5 * g + k]))}" for k, n in enumerate(names) if 5 * g + k < d.shape[1]))
+        print(f"  chunk total (median cycles): {int(np.median((rows[:, 20] - rows[:, 0]) & 0xffffffff))}  ({len(rows)} workgroups)")
 
 
 if __name__ == "__main__":

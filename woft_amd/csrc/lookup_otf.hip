@@ -31,6 +31,9 @@
 #define OTF_PIPE 0               // 1: the window drop of chunk c - 1 is spread over the MFMA sub-steps of chunk c (see the chunk loop):
 #endif                           //    bit-identical (tested), 81.3 vs 81.9 us alone and +-0 in a frame (A/B in one call) -- the drop was not
                                  //    the chunk's exposed cost (round-2 ablation: 51 of 89 us remain without MFMAs, stream and drops); off
+#ifndef OTF_PROBE
+#define OTF_PROBE 0              // 1: compile the per-K-step-group phase probe in (ablate & 32, tools/bench_lookup_otf.py OTF_ABL=32)
+#endif
 #ifndef OTF_SAMPLE_UNROLL
 #define OTF_SAMPLE_UNROLL 3      // unroll factor of the sampling loop (21: fully unrolled)
 #endif
@@ -181,6 +184,15 @@ __global__ __launch_bounds__(TW * 32, 2) void corr_lookup_otf_kernel(const woft_
     int n_stamp = 0;
     auto stamp = [&]() { if (stamps && n_stamp < 24) stamps[n_stamp++] = (uint32_t)__builtin_amdgcn_s_memtime(); };
     stamp();
+    // second probe (ablate & 32): the phases of every K-step group of ONE chunk (level 0, second chunk) -- kept in LDS (a global
+    // store would count in vmcnt and disturb the DMA waits it is timing), written out after the last level
+    __shared__ uint32_t s_probe[24];
+    // (round-3 reading, `-DOTF_PROBE=1`, cycles incl. ~100-180 per stamp: per group wait 184, barrier 132-150, DMA issue 444-760,
+    //  fragment reads + MFMAs 620-776; after the fourth group the window drop 2 100 -- 9.2 k per probed chunk)
+    const bool probe = OTF_PROBE && (p.ablate & 32) && tid == 0 && p.ldo >= 4 * N2 + 24;
+    int n_probe = 0;
+    bool probe_on = false;
+    auto gstamp = [&]() { if (OTF_PROBE && probe_on && n_probe < 24) s_probe[n_probe++] = (uint32_t)__builtin_amdgcn_s_memtime(); };
     const int mypix = tid >> 2, part = tid & 3;         // sampling: 4 threads per source pixel
     const int gy = py0 + (mypix >> TSH), gx = px0 + (mypix & (TW - 1));
     const bool pvalid = gy < p.hf && gx < p.wf;
@@ -318,11 +330,15 @@ __global__ __launch_bounds__(TW * 32, 2) void corr_lookup_otf_kernel(const woft_
             ([&] {
                 constexpr int KG = KGS, kg = KGS;        // (compile time: the drop schedule below names accumulator elements)
                 const int g = s0 / GS + kg;
+                if (OTF_PROBE && kg == 0) probe_on = probe && l == 0 && s0 == NK;
+                gstamp();
                 // this group's pieces have landed; those of the following (up to DEPTH - 1) groups may still fly
                 const int rem = G - 1 - g;
                 if (rem >= DEPTH - 1) dma_wait<(DEPTH - 1) * GS * QPW>();
                 else dma_wait<0>();
+                gstamp();
                 __syncthreads();                         // ... for every wave; and group g - 1 is fully consumed
+                gstamp();
                 // the GS * QPW pieces of group g + DEPTH go into the stages of group g - 1, all of them right after the barrier
                 // (OTF_IL = 1, one per k sub-step between the fragment reads and the MFMAs, measured 6 us slower: see above)
                 const bool feed = g + DEPTH < G;
@@ -333,6 +349,7 @@ __global__ __launch_bounds__(TW * 32, 2) void corr_lookup_otf_kernel(const woft_
                 // the GS steps of the group as one list of k sub-steps; the B fragments of sub-step u + 1 are requested
                 // before the MFMAs of sub-step u (two register sets) -- left alone the compiler reads, waits out the LDS
                 // latency and only then issues the three MFMAs, every sub-step
+                gstamp();
                 constexpr int NU = GS * NSUB;
                 bf16x8 bq[2][NPL];
                 auto load_b = [&](auto u_tag) {
@@ -393,6 +410,7 @@ __global__ __launch_bounds__(TW * 32, 2) void corr_lookup_otf_kernel(const woft_
                         }(), ...);
                     }(std::make_integer_sequence<int, NU>{});
                 }
+                gstamp();
             }(), ...);
             }(std::make_integer_sequence<int, NK / GS>{});
             // ---- chunk complete: every lane drops its 16 correlations (one box position, 16 source pixels) into
@@ -428,6 +446,8 @@ __global__ __launch_bounds__(TW * 32, 2) void corr_lookup_otf_kernel(const woft_
                 }
             }
             c0 += 64;
+            gstamp();
+            probe_on = false;
         }
         if (OTF_PIPE && okp) {                           // the last chunk's drop (the all-reads-first form of the un-pipelined path)
             int2 w0[16];
@@ -462,6 +482,10 @@ __global__ __launch_bounds__(TW * 32, 2) void corr_lookup_otf_kernel(const woft_
         }
         stamp();
         __syncthreads();
+    }
+    if (probe) {
+        uint32_t* o = (uint32_t*)(p.out + ((int64_t)py0 * p.wf + px0) * p.ldo + 4 * N2);
+        for (int i = 0; i < 24; ++i) o[i] = i < n_probe ? s_probe[i] : 0u;
     }
 }
 
