@@ -89,6 +89,36 @@ def test_conv_halo_norm_on_load(ops, mode):
     _close(o1.nchw(), ref, 2e-4, what="norm-on-load conv")
 
 
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16", "fp16"])
+@pytest.mark.parametrize("c,h,w", [(64, 40, 56), (96, 21, 37), (128, 17, 33)])
+def test_conv_regb_instance_norm_plumbing(ops, c, h, w, precision):
+    """The fnet encoder's 3x3 layers on the register-streamed-weights kernel (conv_regb.hip, NORM instance): partial
+    InstanceNorm statistics out, the producer's InstanceNorm + ReLU applied while the halo is converted -- against the
+    LDS-halo kernel it replaces there: every output bit-identical, statistics equal up to their fp32 grouping
+    (extractor.py:28-56,168-192)."""
+    x = _rand(1, c, h, w, seed=96, scale=2.0) + 0.3
+    wt = _rand(c, c, 3, 3, seed=97, scale=1 / math.sqrt(c * 9))
+    b = _rand(c, seed=98, scale=0.1)
+    mean, rstd = _rand(c, seed=94, scale=0.5).cuda(), (_rand(c, seed=95).abs() + 0.5).cuda()
+    pc = ops.pack_conv(wt, b)
+    xa = ops.act_from_nchw(x)
+    res = {}
+    for halo in (None, 1):
+        out = ops.new_act(1, h, w, c, zero=True)
+        stats = (torch.zeros(256 * pc.cout_pad, device="cuda"), torch.zeros(256 * pc.cout_pad, device="cuda"))
+        p = ops.conv_params(xa, pc, out, precision=precision, in_norm=2, in_stats=(mean, rstd), stats=stats, halo=halo or 8,
+                            tiles=None if halo else (128, 64))
+        assert p.halo == (8 if halo is None else 1) and p.in_norm == 2 and (halo or p.tile_n == 64)
+        ops.run_conv(p)
+        mu, rs = torch.zeros(c, device="cuda"), torch.zeros(c, device="cuda")
+        ops.inorm_finalize(stats, 2 * p._m_tiles, pc.cout_pad, c, h * w, mu, rs)
+        res[halo] = (out.t.clone(), mu.clone(), rs.clone())
+    torch.cuda.synchronize()
+    assert torch.equal(res[None][0], res[1][0]), f"max diff {float((res[None][0] - res[1][0]).abs().max()):.3e}"
+    _close(res[None][1], res[1][1], 2e-6, what="mean")
+    _close(res[None][2], res[1][2], 0.0, rtol=1e-5, what="rstd")
+
+
 @pytest.mark.parametrize("precision,tol", [("bf16x3", 2e-5), ("bf16", 2e-2)])
 def test_wh_mean_epilogue(ops, precision, tol):
     """Last weight-head layer with ReLU + 1x1 conv + patch mean fused into the whole-patch kernel's epilogue

@@ -27,7 +27,10 @@ namespace {
 
 using woft::BK;
 
-template <int TY, int TX, int KY, int KX, int WM, int TERMS, int NBUF, int DIST, int AD, int CU = 1, int HD = 1, bool IL = true>
+// NORM (compile time; encoder layers, round 3): p.in_norm != 0 -- the producer's InstanceNorm (+ ReLU) applied while the halo is
+// converted, with conv_halo_bf16_kernel's expression (bit-identical); the per-channel statistics of the chunk travel with its halo rows.
+template <int TY, int TX, int KY, int KX, int WM, int TERMS, int NBUF, int DIST, int AD, int CU = 1, int HD = 1, bool IL = true,
+          bool NORM = false>
 __global__ __launch_bounds__(256, 2) void conv_regb_kernel(const woft_conv_params pa, const woft_conv_params pb, const int split) {
     // (two independent layers that run on the same instance of this kernel may share ONE launch -- woft_conv2d_pair: the
     //  workgroups [0, split) belong to the first layer, the rest to the second; split = gridDim.x for a single layer)
@@ -85,6 +88,7 @@ __global__ __launch_bounds__(256, 2) void conv_regb_kernel(const woft_conv_param
         hpix[j] = hok[j] ? (img0 * p.h + iy) * p.w + ix : 0;
     }
     f32x4 rh[HD][RH];                                    // ring: the input tile of chunk c waits in rh[c % HD]
+    f32x4 nmu[HD], nrs[HD];                              // NORM: mean / rstd of the chunk's channels 4 v .. 4 v + 3
     auto load_halo = [&](int chunk, auto slot_tag) {
         constexpr int hs = decltype(slot_tag)::value;
         const int c0 = chunk * BK;
@@ -93,13 +97,26 @@ __global__ __launch_bounds__(256, 2) void conv_regb_kernel(const woft_conv_param
         const int cs = second ? p.cs1 : p.cs0;
 #pragma unroll
         for (int j = 0; j < RH; ++j) rh[hs][j] = *(const f32x4*)(src + (uint32_t)(hpix[j] * cs));
+        if constexpr (NORM) {
+            nmu[hs] = *(const f32x4*)(p.in_mean + c0 + 4 * v);
+            nrs[hs] = *(const f32x4*)(p.in_rstd + c0 + 4 * v);
+        }
     };
     auto store_halo_row = [&](__bf16* As, auto slot_tag, auto j_tag) {      // one of this thread's RH halo rows -> LDS
         constexpr int hs = decltype(slot_tag)::value, j = decltype(j_tag)::value;
         const int ht = r0 + 32 * j;
         if (RH * 32 > HROWS && ht >= HROWS) return;
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-        const f32x4 val = hok[j] ? rh[hs][j] : zero;
+        f32x4 x = rh[hs][j];
+        if constexpr (NORM) {                            // (zero padding applies to the NORMALISED map: select afterwards)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float y = (x[e] - nmu[hs][e]) * nrs[hs][e];
+                if (p.in_norm == 2) y = fmaxf(y, 0.f);
+                x[e] = y;
+            }
+        }
+        const f32x4 val = hok[j] ? x : zero;
         const bf16x4 hi = cvt16<TERMS>(val);
         *(bf16x4*)(As + ht * LDB + 4 * v) = hi;
         if (NP == 2) {
@@ -350,7 +367,13 @@ int launch_regb(const woft_conv_params& p, const woft_conv_params* second, hipSt
 #define REGB(KY, KX, T, NB, D) \
     woft_launch(0, conv_regb_kernel<TY, TX, KY, KX, WM, T, NB, D, 2>, grid, dim3(256), (size_t)g_regb_dyn_lds, s, p, pb, split)
 #define REGB_TAPS(T)                                                     \
-    if (p.taps_y == 3 && p.taps_x == 3) REGB(3, 3, T, 3, 2);             \
+    if (p.in_norm != 0) {                 /* encoder residual blocks: 3x3, 8x16 x 64 tiles, single layer */ \
+        if constexpr (WM == 2 && TY == 8) {                                                                 \
+            if (p.taps_y == 3 && p.taps_x == 3 && second == nullptr)                                        \
+                woft_launch(0, conv_regb_kernel<TY, TX, 3, 3, WM, T, 3, 2, 2, 1, 1, true, true>, grid, dim3(256), (size_t)g_regb_dyn_lds, s, p, pb, split); \
+            else return WOFT_EINVAL;                                                                        \
+        } else return WOFT_EINVAL;                                                                          \
+    } else if (p.taps_y == 3 && p.taps_x == 3) REGB(3, 3, T, 3, 2);      \
     else if (p.taps_y == 1 && p.taps_x == 5) REGB(1, 5, T, 5, 3);        \
     else if (p.taps_y == 5 && p.taps_x == 1) REGB(5, 1, T, 5, 3);        \
     else if (p.taps_y == 1 && p.taps_x == 1) {    /* 1x1: three chunks per unrolled group, input tile three chunks ahead; \
@@ -384,7 +407,13 @@ int woft_conv_regb_launch(const woft_conv_params& p, const woft_conv_params* sec
             p.epi == WOFT_EPI_WH_MEAN || p.epi == WOFT_EPI_FLOWHEAD || p.tile_n != 128 || p.cout_pad % 128 != 0 || p.taps_y * p.taps_x == 1) return WOFT_EINVAL;
         return launch_regb<1, 4>(p, second, (hipStream_t)stream);
     }
-    if (p.wgt_frag == nullptr || p.in_norm != 0 || (p.in_mean != nullptr && p.in_mean != (const float*)1) || p.wh0_lookup != nullptr || p.epi == WOFT_EPI_WH_MEAN) return WOFT_EINVAL;
+    if (p.wgt_frag == nullptr || p.wh0_lookup != nullptr || p.epi == WOFT_EPI_WH_MEAN) return WOFT_EINVAL;
+    if (p.in_norm != 0) {               // InstanceNorm applied on load: the 3x3 / 64-column instance only
+        if (p.in_mean == nullptr || p.in_mean == (const float*)1 || p.in_rstd == nullptr || p.in1 != nullptr || p.tile_n != 64 ||
+            p.taps_y != 3 || p.taps_x != 3 || second != nullptr || p.epi == WOFT_EPI_FLOWHEAD)
+            return WOFT_EINVAL;
+    } else if (p.in_mean != nullptr && p.in_mean != (const float*)1) return WOFT_EINVAL;
+    if (p.stat_sum != nullptr && p.tile_n != 64) return WOFT_EINVAL;    // (statistics rows: two row halves per tile = the 2 x 2 wave layout)
     if (p.epi == WOFT_EPI_FLOWHEAD && (p.e0 == nullptr || p.ldo < 20 || p.ldo % 4 != 0 || p.co_off != 0 || p.cout % 32 != 0)) return WOFT_EINVAL;
     if (p.tile_n == 128 && p.cout_pad % 128 == 0) return launch_regb<1>(p, second, (hipStream_t)stream);
     if (p.tile_n == 64 && p.cout_pad % 64 == 0) return launch_regb<2>(p, second, (hipStream_t)stream);

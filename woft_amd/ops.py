@@ -173,6 +173,9 @@ USE_HALO = os.environ.get("WOFT_HALO", "1") != "0"
 USE_REGB = os.environ.get("WOFT_REGB", "1") != "0"
 USE_REGB1 = os.environ.get("WOFT_REGB1", "0") != "0"      # (measured: 45 vs 37 us on convc1 -- the 64 x 64 gather tiles win)
 REGB_TY4 = os.environ.get("WOFT_REGB_TY4", "1") != "0"
+# InstanceNorm layers (statistics out / normalise on load) on conv_regb.hip instead of the LDS-halo kernel: bit-identical (tested),
+# measured +-0 in a frame (138-143 vs 135-142 us per half-resolution layer): opt-in
+REGB_NORM = os.environ.get("WOFT_REGB_NORM", "0") != "0"
 USE_STEM = os.environ.get("WOFT_STEM", "1") != "0"        # 7x7 / stride-2 first layer on conv_stem.hip (0: gather kernel)
 HALO_TILES = {1: (8, 16, 1), 2: (9, 9, 1), 4: (4, 16, 1), 6: (6, 16, 1), 7: (8, 16, 1), 8: (8, 16, 1), 12: (4, 16, 1)}     # (TY, TX, images per workgroup)
 HALO_MIN_BLOCKS = int(os.environ.get("WOFT_HALO_MIN_BLOCKS", "400"))
@@ -284,6 +287,12 @@ def conv_params(x, pc, out, co_off=0, epi=_lib.EPI_LINEAR, x2=None, c_split=0, e
     if USE_REGB and auto_halo and halo in (1, 4) and tiles is None and stats is None and not in_norm and p.precision != 0:
         p.tile_n = tn = (p.tile_n if halo == 1 else 64)
         halo = 8
+    # ... and (round 3) the fnet encoder's 3x3 layers: partial statistics by the shared epilogue, the producer's InstanceNorm
+    # (+ ReLU) applied while the halo is converted (NORM instance: 8x16 pixels x 64 columns) -- bit-identical to the LDS-halo kernel
+    if USE_REGB and REGB_NORM and auto_halo and halo in (1, 4) and tiles is None and (stats is not None or in_norm) \
+            and p.precision != 0 and (pc.taps_y, pc.taps_x) == (3, 3) and x2 is None and pc.cout_pad % 64 == 0:
+        p.tile_n = tn = 64
+        halo = 8
     # 1x1 stride-1 layers (motion encoder convc1, mask head, encoder outputs) CAN run on the same kernel with the "taps"
     # dimension collapsed -- three chunks per unrolled group, 64-column tiles (halo=8 explicitly, or WOFT_REGB1=1); bit-identical
     # but 10-20 % slower than the gather kernel's 64 x 64 tiles on these short-K layers, so it is not the default
@@ -303,7 +312,7 @@ def conv_params(x, pc, out, co_off=0, epi=_lib.EPI_LINEAR, x2=None, c_split=0, e
     p.halo = halo
     p.wgt_frag = None
     if halo in (8, 12):                 # weights streamed to registers in MFMA-fragment order (conv_regb.hip)
-        assert p.precision != 0 and not pc.flat and pc.stride == 1 and not in_norm
+        assert p.precision != 0 and not pc.flat and pc.stride == 1 and (not in_norm or (pc.taps_y, pc.taps_x) == (3, 3))
         assert (pc.taps_y, pc.taps_x) in ((3, 3), (1, 5), (5, 1), (1, 1)) and (ho, wo) == (x.h, x.w)
         frag = pc.frag(2 if p.precision == 1 else 1, f16=p.precision == 3)
         p.wgt_frag = ptr(frag)
@@ -319,7 +328,7 @@ def conv_params(x, pc, out, co_off=0, epi=_lib.EPI_LINEAR, x2=None, c_split=0, e
         p.cout_pad = pc.cout_pad if stats is not None else _round_up(p.cout, p.tile_n)
     p.bias_map, p.ld_bias_map = (ptr(bias_map.t), bias_map.cs) if bias_map is not None else (None, 0)
     p.in_norm, p.in_mean, p.in_rstd = 0, None, None
-    if in_norm and halo in (1, 4) and (pc.taps_y, pc.taps_x) == (3, 3):      # (instantiated for the 3x3 pixel tiles)
+    if in_norm and halo in (1, 4, 8) and (pc.taps_y, pc.taps_x) == (3, 3):   # (instantiated for the 3x3 pixel tiles)
         p.in_norm, p.in_mean, p.in_rstd = int(in_norm), ptr(in_stats[0]), ptr(in_stats[1])
     p._m_tiles = math.ceil(m / tm)
     if halo in HALO_TILES:
