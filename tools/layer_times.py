@@ -15,10 +15,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--precision", default="bf16x3")
     ap.add_argument("--hw", default="1080,1920")
-    ap.add_argument("--corr", default=None, help="volume | otf (default: otf in the split-bf16 precisions)")
+    ap.add_argument("--corr", default=None, help="volume | otf (default: otf)")
     a = ap.parse_args()
     h, w = (int(v) for v in a.hw.split(","))
-    corr = a.corr or ("volume" if a.precision == "fp32" else "otf")
+    corr = a.corr or "otf"
     eng = RaftEngine(synth.make_state_dict(seed=7), small=False, weighted=True, precision=a.precision, corr=corr)
     plan = eng.plan(h, w) if hasattr(eng, "plan") else None
     if plan is None:
