@@ -153,6 +153,35 @@ def test_volume_free_lookup_equals_volume_lookup_4k(ops, volume4k):
         assert float(ref[P - 1].abs().max()) > 0 or name == "borders"
 
 
+def test_exact_fp32_volume_free_lookup_4k(ops, volume4k):
+    """The fp32-MFMA instantiation of the volume-free lookup (terms = 0: the fp32 feature rows themselves) at 4K feature size,
+    where the exact-fp32 volume would be another 90 GB: centre taps at integer coordinates against fp64 dot products (fp32
+    accumulation error only), the whole output within the split-bf16 lookup's 2^-16 class, shift identity."""
+    f1, maps, sa, f2s, vols, dims = volume4k
+    idx = torch.arange(P, device="cuda")
+    grid = torch.stack([idx % WF, idx // WF], 1).float()
+    coords = (grid + torch.tensor([3.0, -2.0], device="cuda")).contiguous()
+    rows = [m.t.contiguous() for m in maps]
+    out = torch.zeros(P, 352, device="cuda")
+    ops.run_lookup_otf(ops.make_lookup_otf_params(f1, rows, dims, HF, WF, C, coords, out, 4, 0))
+    ref3 = torch.zeros(P, 352, device="cuda")
+    ops.run_lookup_otf(ops.make_lookup_otf_params(sa, f2s, dims, HF, WF, C, coords, ref3, 4, 3))
+    torch.cuda.synchronize()
+    sample = torch.from_numpy(np.array(list(range(0, P, 257)))).cuda()
+    x, y = (sample % WF) + 3, (sample // WF) - 2
+    ok = (x >= 0) & (x < WF) & (y >= 0) & (y < HF)
+    q = (y.clamp(0, HF - 1) * WF + x.clamp(0, WF - 1))
+    dot = (f1[sample].double() * rows[0][q].double()).sum(1) / math.sqrt(C)
+    ref = torch.where(ok, dot, torch.zeros((), dtype=torch.float64, device="cuda"))
+    assert float((out[sample, 40].double() - ref).abs().max()) < 2e-6
+    assert float((out[:, :324] - ref3[:, :324]).abs().max()) < 2e-4          # (values of order 1: 2^-16 per product, 256 products)
+    out2 = torch.zeros(P, 352, device="cuda")
+    ops.run_lookup_otf(ops.make_lookup_otf_params(f1, rows, dims, HF, WF, C, (coords + torch.tensor([1.0, 0.0], device="cuda")).contiguous(),
+                                                  out2, 4, 0))
+    torch.cuda.synchronize()
+    assert torch.equal(out[:, :81].reshape(P, 9, 9)[:, 1:, :], out2[:, :81].reshape(P, 9, 9)[:, :-1, :])
+
+
 def test_whole_4k_flow_both_correlation_modes(ops, volume4k):
     """One full 4K compute_flow per correlation mode through the operator: finite, weights in [0, 1], exact int64
     grid, run-to-run bit-identical, and the two modes bit-identical to each other (104 GB volume vs none).
