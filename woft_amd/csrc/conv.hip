@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void conv_mfma_bf16_kernel(const woft_conv_par
             const bf16x4 hi = cvt16<TERMS>(val);
             *(bf16x4*)(As + (r0 + 32 * j) * LDB + 4 * v) = hi;
             if (NP == 2) {
-                const f32x4 rem = val - __builtin_convertvector(hi, f32x4);
+                const f32x4 rem = val - widen_bf16x4(hi);
                 *(bf16x4*)(As + A_PLANE + (r0 + 32 * j) * LDB + 4 * v) = __builtin_convertvector(rem, bf16x4);
             }
         }
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(256, (STAGES == 1 ? 4 : (TY == 9 ? 3 : 1))) void co
                 const bf16x4 hi = __builtin_convertvector(val, bf16x4);
                 *(bf16x4*)(As + hrow * LDB + ch) = hi;
                 if (NP == 2) {
-                    const f32x4 rem = val - __builtin_convertvector(hi, f32x4);
+                    const f32x4 rem = val - widen_bf16x4(hi);
                     *(bf16x4*)(As + A_PLANE + hrow * LDB + ch) = __builtin_convertvector(rem, bf16x4);
                 }
             }
@@ -519,7 +519,7 @@ __global__ __launch_bounds__(256, (STAGES == 1 ? 4 : (TY == 9 ? 3 : 1))) void co
             const bf16x4 hi = cvt16<TERMS>(val);
             *(bf16x4*)(As + ht * LDB + 4 * v) = hi;
             if (NP == 2) {
-                const f32x4 rem = val - __builtin_convertvector(hi, f32x4);
+                const f32x4 rem = val - widen_bf16x4(hi);
                 *(bf16x4*)(As + A_PLANE + ht * LDB + 4 * v) = __builtin_convertvector(rem, bf16x4);
             }
         }

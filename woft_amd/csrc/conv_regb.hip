@@ -93,10 +93,12 @@ __global__ __launch_bounds__(256, 2) void conv_regb_kernel(const woft_conv_param
         constexpr int hs = decltype(slot_tag)::value;
         const int c0 = chunk * BK;
         const bool second = (p.in1 != nullptr) && (c0 >= p.c_split);
-        const float* src = (second ? p.in1 + (c0 - p.c_split) : p.in0 + c0) + 4 * v;
+        // (wave-uniform base + 32-bit lane offset: the scalar-base addressing form -- with the lane's 4 v folded into the base the
+        //  six addresses of a chunk cost ~34 vector instructions of 64-bit arithmetic, and those add to the MFMAs' SIMD time)
+        const float* src = second ? p.in1 + (c0 - p.c_split) : p.in0 + c0;
         const int cs = second ? p.cs1 : p.cs0;
 #pragma unroll
-        for (int j = 0; j < RH; ++j) rh[hs][j] = *(const f32x4*)(src + (uint32_t)(hpix[j] * cs));
+        for (int j = 0; j < RH; ++j) rh[hs][j] = *(const f32x4*)(src + (uint32_t)(hpix[j] * cs + 4 * v));
         if constexpr (NORM) {
             nmu[hs] = *(const f32x4*)(p.in_mean + c0 + 4 * v);
             nrs[hs] = *(const f32x4*)(p.in_rstd + c0 + 4 * v);
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(256, 2) void conv_regb_kernel(const woft_conv_param
         const bf16x4 hi = cvt16<TERMS>(val);
         *(bf16x4*)(As + ht * LDB + 4 * v) = hi;
         if (NP == 2) {
-            const f32x4 rem = val - __builtin_convertvector(hi, f32x4);
+            const f32x4 rem = val - widen_bf16x4(hi);
             *(bf16x4*)(As + A_PLANE + ht * LDB + 4 * v) = __builtin_convertvector(rem, bf16x4);
         }
     };
@@ -307,7 +309,7 @@ __global__ __launch_bounds__(256, 2) void conv_regb_kernel(const woft_conv_param
                     for (int e = 0; e < 4; ++e) yv[e] = fmaxf(p.alpha * yv[e] + b4[e], 0.f);
                     const bf16x4 hi = cvt16<TERMS>(yv);
                     bf16x4 lo = hi;
-                    if constexpr (NP == 2) lo = __builtin_convertvector(yv - __builtin_convertvector(hi, f32x4), bf16x4);
+                    if constexpr (NP == 2) lo = __builtin_convertvector(yv - widen_bf16x4(hi), bf16x4);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { ah[s2][4 * q + e] = hi[e]; al[s2][4 * q + e] = lo[e]; }
                 }

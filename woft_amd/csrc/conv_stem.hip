@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(const woft_conv_param
                 const bf16x4 hi = cvt16<TERMS>(rp[j]);
                 *(bf16x4*)(As + pr * PITCH + pc * 4) = hi;
                 if (NP == 2) {
-                    const f32x4 rem = rp[j] - __builtin_convertvector(hi, f32x4);
+                    const f32x4 rem = rp[j] - widen_bf16x4(hi);
                     *(bf16x4*)(As + A_PLANE + pr * PITCH + pc * 4) = __builtin_convertvector(rem, bf16x4);
                 }
             }

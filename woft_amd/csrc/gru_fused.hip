@@ -123,7 +123,7 @@ __global__ __launch_bounds__(512, 2) void gru_halfstep_kernel(const woft_conv_pa
         const f32x4 val = ok ? rh[j] : zero;
         const bf16x4 hi = cvt16<TERMS>(val);
         *(bf16x4*)(As + ht * LDB + 4 * v) = hi;
-        if (NP == 2) *(bf16x4*)(As + plane + ht * LDB + 4 * v) = __builtin_convertvector(val - __builtin_convertvector(hi, f32x4), bf16x4);
+        if (NP == 2) *(bf16x4*)(As + plane + ht * LDB + 4 * v) = __builtin_convertvector(val - widen_bf16x4(hi), bf16x4);
     };
     auto store_rows = [&](__bf16* As, int plane, auto n_tag, auto phase_tag) {
         [&]<int... J>(std::integer_sequence<int, J...>) {
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(512, 2) void gru_halfstep_kernel(const woft_conv_pa
                 __bf16* dst = rhbuf + wave * R_CHUNK + ((oy + PY) * QX + (ox + PX)) * LDB + c4;
                 const bf16x4 hi = cvt16<TERMS>(y);
                 *(bf16x4*)dst = hi;
-                if (NP == 2) *(bf16x4*)(dst + R_PLANE) = __builtin_convertvector(y - __builtin_convertvector(hi, f32x4), bf16x4);
+                if (NP == 2) *(bf16x4*)(dst + R_PLANE) = __builtin_convertvector(y - widen_bf16x4(hi), bf16x4);
             }
             __builtin_amdgcn_wave_barrier();
         }(), ...);

@@ -23,6 +23,19 @@ __device__ __forceinline__ bf16x4 cvt16(const f32x4 v) {
     if constexpr (TERMS == 16) return __builtin_bit_cast(bf16x4, __builtin_convertvector(v, f16x4));
     else return __builtin_convertvector(v, bf16x4);
 }
+// bf16x4 -> f32x4, exact, from the two packed words (a shift / a mask per element).  `__builtin_convertvector(hi, f32x4)` is lowered
+// element by element through a second v_cvt_pk_bf16_f32 of the fp32 source plus a shift: 8 instead of 4 vector instructions per
+// float4 of every halo conversion -- and vector instructions ADD to the MFMAs' SIMD time.
+__device__ __forceinline__ f32x4 widen_bf16x4(const bf16x4 h) {
+    typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+    const u32x2_t w = __builtin_bit_cast(u32x2_t, h);
+    f32x4 r;
+    r[0] = __builtin_bit_cast(float, w[0] << 16);
+    r[1] = __builtin_bit_cast(float, w[0] & 0xffff0000u);
+    r[2] = __builtin_bit_cast(float, w[1] << 16);
+    r[3] = __builtin_bit_cast(float, w[1] & 0xffff0000u);
+    return r;
+}
 template <int TERMS>
 __device__ __forceinline__ f32x16 mma16(const bf16x8 a, const bf16x8 b, const f32x16 c) {
     if constexpr (TERMS == 16)
