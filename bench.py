@@ -282,9 +282,18 @@ def main():
         kern = {8: "conv_regb_kernel<8,16,3,3> (weights streamed global -> registers)", 1: "conv_halo_bf16_kernel<8,16,3,3>",
                 4: "conv_halo_bf16_kernel<4,16,3,3>", 0: "conv_mfma_f32_kernel"}.get(p0.halo, f"halo {p0.halo}")
         t = tot_ms * 1e-3
+        # HBM bytes per launch of this symbol from the committed PMC passes (tools/conv_pmc.sh; 1080p, default precision only)
+        traffic, tsrc = None, None
+        if p0.halo == 8 and p0._m == 135 * 240 and args.precision == "bf16x3":
+            for name in ("r03_conv_pmc.json",):
+                pth = ROOT / "profiles" / name
+                if pth.exists():
+                    traffic = json.loads(pth.read_text())["traffic_bytes_per_launch"]
+                    tsrc = f"profiles/{name} (tools/conv_pmc.sh: separate rocprofv3 --pmc passes, mean over the symbol's dispatches)"
+                    break
         return {"bound": "mfma", "kernel": f"{kern}, tile_n {p0.tile_n}: motion-encoder 3x3 convs on {p0._m} pixels",
                 "achieved": tot_fl / t / 1e12, "peak": mfma_peak, "unit": "TFLOP/s", "frac": tot_fl / t / 1e12 / mfma_peak,
-                "traffic": None, "matrix_core_issue_frac": tot_issued / t / 1e12 / mfma_peak,
+                "traffic": traffic, "traffic_source": tsrc, "matrix_core_issue_frac": tot_issued / t / 1e12 / mfma_peak,
                 "algorithmic_flops_per_launch": tot_fl / max(n_l, 1), "mfma_terms_per_product": terms,
                 "avg_launch_ms": tot_ms / max(n_l, 1), "launches_timed": n_l, "layers": per,
                 "note": "frac prices the launches' own 2*M*K*N products against the dense peak of the MFMA type used; the "
