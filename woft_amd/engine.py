@@ -110,7 +110,8 @@ class RaftEngine:
         only): those convolutions on fp16 operands with fp32 accumulation, the correlation, the weight head and both
         upsamplings in fp32-class arithmetic (bf16x3 here).
         corr: "volume" (all-pairs volume + pyramid in HBM, corr.py:13-69) or "otf" (volume-free lookup from the
-        feature maps, the reference's alternate_corr idea, corr.py:72-100; split-bf16 precisions only).
+        feature maps, the reference's alternate_corr idea, corr.py:72-100; every precision, exact fp32 included: bit-identical
+        to the volume path of the same precision).
         volume_storage: element type of the volume in HBM, "fp32" or "bf16" (fp32 accumulators rounded once at the GEMM's
         store; lookup interpolation and output stay fp32).  Default: "bf16" in the plain-bf16 precision -- its operating
         point, half the store stream and the lookup's reads, SURVEY 8d -- else "fp32"."""
