@@ -37,6 +37,11 @@ HBM_PEAK_GBS = 8000.0                                             # MI355X_MICRO
 
 CLIP = 48      # frames per clip of the synthetic sequence
 
+# flow EPE of the GPU path against the oracle, (mean, max) px at 12 iterations.  fp32 and the fp32-emulating
+# bf16x3 share the GPU-fp32 budget; bf16: 0.05 px mean (max: the bf16 tests' 0.25 px); fp16 (mixed_precision scoping):
+# the tested budgets of tests/test_flow_gpu.py
+EPE_BUDGET = {"fp32": (1e-3, 1e-2), "bf16x3": (1e-3, 1e-2), "bf16": (0.05, 0.25), "fp16": (0.01, 0.05)}
+
 
 def restart_clip(tracker):
     """Pose state of a freshly initialised tracker (TRK:43-47); template-side tensors stay as they are."""
@@ -105,8 +110,10 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--iters", type=int, default=12)
-    ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16x3", "bf16", "fp16"],
-                    help="conv / correlation-GEMM arithmetic: exact fp32 MFMA, split-bf16 (fp32-emulating, default), bf16")
+    ap.add_argument("--precision", default=None, choices=["fp32", "bf16x3", "bf16", "fp16"],
+                    help="conv / correlation-GEMM arithmetic: exact fp32 MFMA, split-bf16 (fp32-emulating), bf16, fp16 scoping. "
+                         "Default: whatever the SHIPPED flow config selects (pytracking/optical_flow/configs/"
+                         "v2_SNOB_large_g05_RAFT.py: the configuration a drop-in user runs) -- reported as config.precision_source")
     ap.add_argument("--corr", default="otf", choices=["volume", "otf"],
                     help="correlation: volume-free on-the-fly lookup (default in the split-bf16 precisions) or the "
                          "all-pairs volume in HBM whose lookup is the HBM-roofline kernel (bit-identical results; "
@@ -154,6 +161,7 @@ def main():
     from woft_amd import dist as wdist, ops, synth
     from pytracking.utils.config import load_config
     rank, world, local = wdist.init_distributed()
+    affinity0 = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
     binding = wdist.bind_to_gpu_node(wdist.device_index(), local, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch {args.gpus} ranks "
@@ -170,8 +178,10 @@ def main():
         conf.mask_weight_head = (not args.full_weight_head) if mask_wh is None else mask_wh
         conf.flow_config.model = sd
         conf.flow_config.iters = args.iters
-        conf.flow_config.precision = precision
+        if precision is not None:                 # (None: the shipped flow config's own `precision` key decides)
+            conf.flow_config.precision = precision
         conf.flow_config.graph = graph
+        precision = precision or conf.flow_config.precision or "fp32"
         # (exact fp32: volume-free since round 3 -- bit-identical to the volume path, no P x P buffer; WOFT_FP32_CORR=volume: A/B)
         conf.flow_config.corr = (corr or args.corr) if precision != "fp32" else (corr or os.environ.get("WOFT_FP32_CORR", "otf"))
         trk = conf.tracker_class(conf)
@@ -181,6 +191,9 @@ def main():
         return trk
 
     tracker = make_tracker(args.precision)
+    precision_source = ("bench.py --precision" if args.precision else
+                        f"{tracker.flower.precision_source} of the shipped pytracking/optical_flow/configs/v2_SNOB_large_g05_RAFT.py")
+    args.precision = tracker.flower.precision            # (from here on: the precision the timed tracker really runs)
     plan = tracker.flower.engine.plan(H, W)
     corr_mode = tracker.flower.engine.corr
 
@@ -341,7 +354,7 @@ def main():
                    "resolution": [H, W], "iters": args.iters, "sequences": world, "correlation": corr_mode,
                    "weight_head": wh_desc,
                    "template_cache": not args.no_template_cache, "weights": "synthetic seed 7 (reference key set)",
-                   "frames_resident_in_hbm": True},
+                   "frames_resident_in_hbm": True, "precision": args.precision, "precision_source": precision_source},
         "lost_frames": n_lost, "hbm_allocated_peak_gb": peak_gb, "tracks_gathered": [int(tracks.shape[0]), int(tracks.shape[1])],
         # one entry per rank (a straggler shows here; `value` uses the slowest rank): ms per step inside the same barriers,
         # the NUMA node of the rank's GPU and the host cores its launch thread is pinned to (woft_amd.dist.bind_to_gpu_node)
@@ -477,6 +490,31 @@ def main():
         del trk, pl
         drop()
     if world == 1 and not args.no_ladder:
+        # ---- host frames: what a real caller hands track() (WOFT_demo.py:61-78, TRK:113-120) -- one numpy frame per call,
+        # crossing PCIe inside the timed region (pinned double-buffered staging + async H2D in woft_amd.tracker._FrameUploader);
+        # same sequence, same tracks as the resident-frame headline
+        frames_np = [f.cpu().numpy() for f in frames]
+        trk = make_tracker(args.precision)
+        for i in range(Wm):
+            trk.track(frames_np[i % CLIP])
+        torch.cuda.synchronize()
+        n_hf = max(K2, 20)
+        t1 = time.perf_counter()
+        res_hf = []
+        for i in range(Wm, Wm + n_hf):
+            if i > 0 and i % CLIP == 0:
+                restart_clip(trk)
+            res_hf.append(trk.track(frames_np[i % CLIP]))
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        out["host_frames"] = {"frames_per_s": n_hf / dt, "ms_per_step": 1000.0 * dt / n_hf, "steps": n_hf,
+                              "pcie_bytes_per_frame": int(frames_np[0].nbytes),
+                              "tracks_identical_to_timed_run": bool(all(np.array_equal(a[0], b_[0]) for a, b_ in
+                                                                        zip(res_hf, results[Wm:Wm + n_hf]))),
+                              "note": "numpy frame per track() call: host memcpy into pinned staging + async H2D on the compute "
+                                      "stream, inside the timed region; `value` is the resident-frame figure"}
+        del trk, frames_np
+        drop()
         # ---- like-for-like ladder: the flow operator doing the reference's FULL work (weight head on every pixel, as
         # WeightedRAFT.forward evaluates it) in the fp32-emulating arithmetic of the headline and in the reference's own
         # arithmetic class (exact fp32 MFMA products); same sequence, same step count each
@@ -549,6 +587,10 @@ def main():
             del trk
             drop()
     if world == 1 and not args.no_cpu_baseline:
+        if affinity0 is not None:
+            # the launch thread was pinned to the GPU's NUMA node for the timed region (woft_amd.dist.bind_to_gpu_node);
+            # the CPU baseline gets the cores the process started with
+            os.sched_setaffinity(0, affinity0)
         torch.set_num_threads(usable_cores())
         n_cpu = 3
         times, tc = cpu_baseline(sd, template, mask, [frames[i].cpu().numpy() for i in range(n_cpu)], args.iters)
@@ -559,12 +601,40 @@ def main():
             e = torch.sqrt(((dst - tc[1]).reshape(2, -1) ** 2).sum(0))
             epes[prec] = {"mean_px": float(e.mean()), "max_px": float(e.max())}
         out["cpu_baseline"] = {"value": 1.0 / med, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-                               "os_cpu_count": os.cpu_count(), "seconds_per_frame": [round(t, 2) for t in times],
+                               "os_cpu_count": os.cpu_count(), "affinity_cores": usable_cores(), "seconds_per_frame": [round(t, 2) for t in times],
                                "sample": f"{n_cpu} tracked frames at {H}x{W}, {args.iters} iters (oracle/tracker_ref.py, torch-CPU "
                                          f"fp32 restatement of the reference path), median {med:.1f} s per frame"}
         out["flow_epe_vs_cpu_oracle"] = epes[args.precision]
         out["flow_epe_vs_cpu_oracle_by_precision"] = epes
+        # parity gate (SURVEY 8d budgets, flow EPE in px against the CPU oracle: (mean, max)): a run outside the budget of
+        # its precision is a FAILED run, whatever its frames/s
+        scale = 1.0 if args.iters <= 12 else 3.0          # (8d: bf16 0.05 px @ 12 it, 0.15 px @ 32 it)
+        bad = {}
+        for prec, e in epes.items():
+            b_mean, b_max = EPE_BUDGET[prec]
+            e["budget_px"] = {"mean": b_mean * scale, "max": b_max * scale}
+            e["within_budget"] = bool(e["mean_px"] <= b_mean * scale and e["max_px"] <= b_max * scale)   # (NaN -> False)
+            if not e["within_budget"]:
+                bad[prec] = e
+        out["epe_gate"] = {"passed": not bad, "failed_precisions": sorted(bad)}
+        gate_failed = bool(bad)
+    else:
+        out["epe_gate"] = {"passed": None, "note": "skipped: no CPU-oracle pass in this run (--no-cpu-baseline or N > 1)"}
+        gate_failed = False
+    # the figures a reader of the driver's `parsed` record needs beside `value` (it keeps `config`, not the extra keys)
+    cfgd = out["config"]
+    g = lambda d, *ks: (g(d.get(ks[0], {}), *ks[1:]) if len(ks) > 1 else d.get(ks[0])) if isinstance(d, dict) else None
+    r1 = lambda v: None if v is None else round(float(v), 2)
+    cfgd["fps_strict_fp32_full_head"] = r1(g(out, "reference_work", "fp32_full_weight_head", "frames_per_s"))
+    cfgd["fps_bf16x3_full_head"] = r1(g(out, "reference_work", "bf16x3_full_weight_head", "frames_per_s"))
+    cfgd["fps_strict_fp32"] = r1(g(out, "strict_fp32", "frames_per_s"))
+    cfgd["fps_host_frames"] = r1(g(out, "host_frames", "frames_per_s"))
+    cfgd["epe_mean_px"] = g(out, "flow_epe_vs_cpu_oracle", "mean_px")
+    cfgd["epe_gate_passed"] = out["epe_gate"]["passed"]
     print(json.dumps(out), flush=True)
+    if gate_failed:
+        print(f"bench.py: flow EPE outside the SURVEY 8d budget: {json.dumps(bad)}", file=sys.stderr)
+        sys.exit(1)
 
 
 if __name__ == "__main__":

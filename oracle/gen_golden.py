@@ -441,6 +441,57 @@ def gen_degenerate():
     np.savez_compressed(GOLD / "degenerate_128x160_it4.npz", **out)
 
 
+def metric_pair(H=1080, W=1920, seq_id=0, t=3):
+    """The bench's own kind of input at the metric's resolution: the SURVEY 8d template of sequence `seq_id` and its frame
+    t (numpy warp, woft_amd/synth.py).  Regenerated from the seeds by the tests (12 MB of noise texture is not a fixture);
+    the fixture stores CRC32s of both images so that a drift of the generator is caught before anything is compared."""
+    template = synth.make_template(H, W, seq_id=seq_id)
+    return template, synth.make_frame(template, t)
+
+
+def lattice_summary(prefix, flow_up, w_up, stride):
+    """Full-resolution outputs as a stride-`stride` lattice + per-row means in full (a checksum of what the lattice skips)."""
+    d = {f"{prefix}flow_up_s": flow_up[..., ::stride, ::stride].contiguous().numpy(),
+         f"{prefix}flow_up_rowmean": flow_up.double().mean(-1).numpy()}
+    if w_up is not None:
+        d[f"{prefix}w_up_s"] = w_up[..., ::stride, ::stride].contiguous().numpy()
+        d[f"{prefix}w_up_rowmean"] = w_up.double().mean(-1).numpy()
+    return d
+
+
+@torch.no_grad()
+def gen_metric():
+    """(1) The metric's own configuration (BASELINE.json metric / configs[1]): WeightedRAFT-full, 12 iterations, on a
+    1080 x 1920 pair of the synthetic sequence (weighted_raft.py:186-290; ~20 s and ~12 GB on the CPU here).  Stored: the
+    1/8-resolution flow and weight logits in full, the full-resolution outputs on a stride-8 lattice + row means.
+    (2) BASELINE configs[0]: plain RAFT-small, 4 iterations, 480 x 640 (raft.py:169-262 -> raft_core/raft.py,
+    extractor.py:244-267); flow_low in full, flow_up on a stride-4 lattice + row means."""
+    import zlib
+    from raft_core.weighted_raft import WeightedRAFT
+    from raft_core.raft import RAFT
+    crc = lambda a: np.int64(zlib.crc32(np.ascontiguousarray(a).tobytes()))
+    sd = synth.make_state_dict(seed=7, small=False, weighted=True)
+    net = WeightedRAFT(ref_args(False)).eval()
+    net.load_state_dict(sd, strict=True)
+    a, b = metric_pair()
+    flow_low, flow_up, _, w_low, w_up = net(to_t(a), to_t(b), iters=12, test_mode=True)
+    out = dict(seed=7, iters=12, H=1080, W=1920, seq_id=0, t=3, stride=8, crc_img1=crc(a), crc_img2=crc(b),
+               flow_low=flow_low.numpy(), w_low=w_low.numpy(), **lattice_summary("", flow_up, w_up, 8))
+    np.savez_compressed(GOLD / "metric_1080p_it12.npz", **out)
+    print("1080p: mean |flow|", float(flow_up.abs().mean()), "w logits", float(w_up.min()), float(w_up.max()))
+    del net
+
+    sds = synth.make_state_dict(seed=8, small=True, weighted=False)
+    nets = RAFT(ref_args(True)).eval()
+    nets.load_state_dict(sds, strict=True)
+    a, b = pair(480, 640, seed=14, shift=(5, -3))
+    fl, fu = nets(to_t(a), to_t(b), iters=4, test_mode=True)
+    out = dict(seed=8, iters=4, H=480, W=640, pair_seed=14, shift=np.asarray((5, -3)), stride=4, crc_img1=crc(a), crc_img2=crc(b),
+               flow_low=fl.numpy(), **lattice_summary("", fu, None, 4))
+    np.savez_compressed(GOLD / "cfg0_small_480x640_it4.npz", **out)
+    print("480x640 small: mean |flow|", float(fu.abs().mean()))
+
+
 def main():
     GOLD.mkdir(parents=True, exist_ok=True)
     install_stubs()
@@ -458,6 +509,8 @@ def main():
         gen_degenerate()
     if only in (None, "real"):
         gen_real()
+    if only in (None, "metric"):
+        gen_metric()
     for p in sorted(GOLD.iterdir()):
         print(f"{p.name:40s} {p.stat().st_size/1024:9.1f} KB")
 

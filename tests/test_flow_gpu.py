@@ -478,3 +478,66 @@ def test_launch_merging_switches_are_bit_identical(monkeypatch, small):
         # launches per refinement iteration: everything merged (GRU half steps in one launch each) / one per layer / merged
         # without the GRU fusion
         assert outs[0][2] == 7 and outs[3][2] == 12 and outs[4][2] == 9
+
+
+def _crc(a):
+    import zlib
+    return zlib.crc32(np.ascontiguousarray(a).tobytes())
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("precision,epe_mean,epe_max,wtol", [("bf16x3", 1e-3, 1e-2, 1e-4), ("fp32", 1e-3, 1e-2, 1e-4),
+                                                             ("bf16", 5e-2, 0.5, 5e-3), ("fp16", 1e-2, 0.1, 1e-3)])
+def test_metric_resolution_1080p_vs_reference(golden_dir, precision, epe_mean, epe_max, wtol):
+    """The metric's own configuration (BASELINE.json: 1080 x 1920, WeightedRAFT-full, 12 iterations) against the REFERENCE's
+    outputs on the same pair (tests/golden/metric_1080p_it12.npz, oracle/gen_golden.py: gen_metric -- weighted_raft.py:186-290
+    run on the CPU of the build container): 1/8-resolution flow in full, full-resolution flow and weight logits on the stored
+    stride-8 lattice and through the per-row means.  The pair is regenerated from its seeds; the stored CRC32s pin it."""
+    g = np.load(golden_dir / "metric_1080p_it12.npz")
+    H, W = int(g["H"]), int(g["W"])
+    a = synth.make_template(H, W, seq_id=int(g["seq_id"]))
+    b = synth.make_frame(a, int(g["t"]))
+    assert _crc(a) == int(g["crc_img1"]) and _crc(b) == int(g["crc_img2"]), "synthetic pair drifted from the fixture's"
+    sd = synth.make_state_dict(seed=int(g["seed"]))
+    fc = _flow_config(sd, int(g["iters"]), precision=precision)
+    flower = fc.of_class(fc)
+    assert flower.engine.corr == "otf"
+    flow, w = flower.compute_flow(a, b, mode="flow", do_sigmoid=False)
+    torch.cuda.synchronize()
+    s = int(g["stride"])
+    assert tuple(flow.shape) == (2, H, W)
+    m, mx = _epe(flow[:, ::s, ::s], torch.from_numpy(g["flow_up_s"])[0])
+    rm = float((flow.double().mean(-1).cpu() - torch.from_numpy(g["flow_up_rowmean"])[0]).abs().max())
+    dws = float((torch.sigmoid(w[:, ::s, ::s].cpu()) - torch.sigmoid(torch.from_numpy(g["w_up_s"])[0])).abs().max())
+    wrm = float((w.double().mean(-1).cpu() - torch.from_numpy(g["w_up_rowmean"])[0]).abs().max())
+    print(f"1080p metric pair, {precision}: EPE mean {m:.2e} max {mx:.2e}; row means {rm:.2e}; sigmoid(w) {dws:.2e}; "
+          f"w row means {wrm:.2e} (mean |flow| {float(np.sqrt((g['flow_up_s'] ** 2).sum(1)).mean()):.2f} px)")
+    assert m < epe_mean and mx < epe_max, (m, mx)
+    assert rm < epe_max and dws < wtol and wrm < 50 * wtol
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("precision,epe_mean,epe_max", [("bf16x3", 1e-3, 1e-2), ("fp32", 1e-3, 1e-2), ("bf16", 5e-2, 0.5),
+                                                        ("fp16", 1e-2, 0.1)])
+def test_config1_small_480x640_vs_reference(golden_dir, precision, epe_mean, epe_max):
+    """BASELINE configs[0]: plain RAFT-small, 4 iterations, 480 x 640 (raft.py:169-262 -> raft_core/raft.py:95-167,
+    extractor.py:244-267, update.py:71-77,23-31,106-112; `upflow8` bilinear x8) against the reference's outputs on the same
+    pair (tests/golden/cfg0_small_480x640_it4.npz): flow_low in full, flow_up on the stride-4 lattice + row means."""
+    from oracle.gen_golden import pair                      # (the fixture's input generator; checker side only)
+    g = np.load(golden_dir / "cfg0_small_480x640_it4.npz")
+    H, W = int(g["H"]), int(g["W"])
+    a, b = pair(H, W, seed=int(g["pair_seed"]), shift=tuple(int(v) for v in g["shift"]))
+    assert _crc(a) == int(g["crc_img1"]) and _crc(b) == int(g["crc_img2"]), "synthetic pair drifted from the fixture's"
+    sd = synth.make_state_dict(seed=int(g["seed"]), small=True, weighted=False)
+    fc = _flow_config(sd, int(g["iters"]), raft_type="orig", small=True, precision=precision)
+    flower = fc.of_class(fc)
+    flow, w = flower.compute_flow(a, b, mode="flow")
+    torch.cuda.synchronize()
+    assert w is None and tuple(flow.shape) == (2, H, W)
+    s = int(g["stride"])
+    m, mx = _epe(flow[:, ::s, ::s], torch.from_numpy(g["flow_up_s"])[0])
+    rm = float((flow.double().mean(-1).cpu() - torch.from_numpy(g["flow_up_rowmean"])[0]).abs().max())
+    print(f"480x640 RAFT-small 4 it, {precision}: EPE mean {m:.2e} max {mx:.2e}; row means {rm:.2e} "
+          f"(mean |flow| {float(np.sqrt((g['flow_up_s'] ** 2).sum(1)).mean()):.2f} px)")
+    assert m < epe_mean and mx < epe_max, (m, mx)
+    assert rm < epe_max

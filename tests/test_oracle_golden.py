@@ -221,3 +221,46 @@ def test_real_frames_720p(golden_dir):
     assert np.abs(out["flow_up"].double().mean(-1).numpy() - g["flow_up_rowmean"]).max() < 1e-4
     assert np.abs(out["weights_up"][..., ::s, ::s].numpy() - g["w_up_s4"]).max() < 3e-4
     assert np.abs(out["weights_up"].double().mean(-1).numpy() - g["w_up_rowmean"]).max() < 1e-4
+
+
+def _crc(a):
+    import zlib
+    return zlib.crc32(np.ascontiguousarray(a).tobytes())
+
+
+@torch.no_grad()
+def test_config1_small_480x640(golden_dir):
+    """BASELINE configs[0] (plain RAFT-small, 4 iterations, 480 x 640): oracle vs the reference's outputs."""
+    from oracle.gen_golden import pair
+    g = np.load(golden_dir / "cfg0_small_480x640_it4.npz")
+    a, b = pair(int(g["H"]), int(g["W"]), seed=int(g["pair_seed"]), shift=tuple(int(v) for v in g["shift"]))
+    assert _crc(a) == int(g["crc_img1"]) and _crc(b) == int(g["crc_img2"])
+    sd = synth.make_state_dict(seed=int(g["seed"]), small=True, weighted=False)
+    out = raft_ref.raft_forward(sd, _t(a), _t(b), int(g["iters"]), small=True, weighted=False)
+    s = int(g["stride"])
+    m, mx = _epe(out["flow_low"], g["flow_low"])
+    assert m < 1e-4 and mx < 1e-3, (m, mx)
+    m, mx = _epe(out["flow_up"][..., ::s, ::s], g["flow_up_s"])
+    assert m < 1e-4 and mx < 1e-3, (m, mx)
+    assert np.abs(out["flow_up"].double().mean(-1).numpy() - g["flow_up_rowmean"]).max() < 1e-4
+
+
+@torch.no_grad()
+def test_metric_resolution_1080p(golden_dir):
+    """The metric's own configuration (1080 x 1920, WeightedRAFT-full, 12 iterations): oracle vs the reference's outputs on
+    the regenerated synthetic pair (CRC-pinned).  ~30-60 s on 8 cores: the one slow test of the CPU suite."""
+    g = np.load(golden_dir / "metric_1080p_it12.npz")
+    H, W = int(g["H"]), int(g["W"])
+    a = synth.make_template(H, W, seq_id=int(g["seq_id"]))
+    b = synth.make_frame(a, int(g["t"]))
+    assert _crc(a) == int(g["crc_img1"]) and _crc(b) == int(g["crc_img2"])
+    sd = synth.make_state_dict(seed=int(g["seed"]), small=False, weighted=True)
+    out = raft_ref.raft_forward(sd, _t(a), _t(b), int(g["iters"]))
+    s = int(g["stride"])
+    m, mx = _epe(out["flow_low"], g["flow_low"])
+    assert m < 1e-4 and mx < 2e-3, (m, mx)
+    m, mx = _epe(out["flow_up"][..., ::s, ::s], g["flow_up_s"])
+    assert m < 1e-4 and mx < 2e-3, (m, mx)
+    assert np.abs(out["flow_up"].double().mean(-1).numpy() - g["flow_up_rowmean"]).max() < 1e-4
+    assert np.abs(out["weights_up"][..., ::s, ::s].numpy() - g["w_up_s"]).max() < 3e-4
+    assert np.abs(out["weights_up"].double().mean(-1).numpy() - g["w_up_rowmean"]).max() < 1e-4

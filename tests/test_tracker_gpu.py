@@ -22,10 +22,10 @@ def _corners_err(Ha, Hb, H, W):
 
 
 @pytest.mark.parametrize("cfg,estimator,precision", [("WOFT.py", "qr", None), ("WOFT_IRLS.py", "irls_huber2", None),
-                                                     ("WOFT.py", "qr", "bf16x3")])
+                                                     ("WOFT.py", "qr", "fp32")])
 def test_tracker_matches_oracle(cfg, estimator, precision):
-    """precision None: the config's default (exact fp32 MFMA, all-pairs volume); "bf16x3": the bench's default path
-    (split-bf16 MFMA emulating fp32, volume-free correlation lookup)."""
+    """precision None: what the SHIPPED flow config selects (bf16x3: split-bf16 MFMA emulating fp32 -- the path a drop-in
+    user and the bench run); "fp32": exact fp32 MFMA products.  Volume-free correlation lookup in both."""
     from pytracking.utils.config import load_config
     H, W, iters, nframes = 128, 160, 4, 4
     sd = synth.make_state_dict(seed=7)
@@ -40,6 +40,7 @@ def test_tracker_matches_oracle(cfg, estimator, precision):
         conf.flow_config.precision = precision
     tracker = conf.tracker_class(conf)
     assert tracker.flower.engine.corr == "otf"         # (every precision, exact fp32 included)
+    assert tracker.flower.precision == (precision or "bf16x3")
     tracker.init(template, mask)
     ref = tracker_ref.TrackerRef(sd, iters=iters, estimator=estimator)
     ref.init(template, mask)
@@ -498,3 +499,44 @@ def test_tracker_on_real_720p_frames_vs_reference_tracker(golden_dir, monkeypatc
         err = _corners_err(Hg, g["track_H"][i], H, W)
         print(f"real 720p frame {i}: corners within {err:.3f} px of the reference tracker")
         assert err < 1.0, (i, err)
+
+
+def test_host_frames_through_pinned_staging_equal_device_frames():
+    """track() on numpy frames (what WOFT_demo.py:61-78 hands it: the pinned double-buffered upload of
+    woft_amd.tracker._FrameUploader, incl. a non-contiguous view) == track() on frames already on the device, bit for bit --
+    also across forced-lost frames, whose local stage reads the PREVIOUS frame's device buffer (TRK:181-184)."""
+    from pytracking.utils.config import load_config
+    H, W, iters = 128, 160, 3
+    sd = synth.make_state_dict(seed=7)
+    template = synth.make_template(H, W, seq_id=2)
+    frames = [synth.make_frame(template, t) for t in range(1, 7)]
+    mask = synth.make_init_mask(H, W)
+
+    def run(as_host):
+        conf = load_config(ROOT / "pytracking" / "configs" / "WOFT.py")
+        conf.flow_config.model, conf.flow_config.iters = sd, iters
+        trk = conf.tracker_class(conf)
+        inner, seen = trk._global_stage, {"i": 0}
+
+        def overruled(frame, prewarp_H):
+            fit = inner(frame, prewarp_H)
+            seen["i"] += 1
+            if seen["i"] in (3, 4):
+                fit.success = False
+            return fit
+        trk._global_stage = overruled
+        trk.init(template, mask)
+        out = []
+        for k, f in enumerate(frames):
+            if as_host:
+                x = np.ascontiguousarray(f[:, ::-1])[:, ::-1] if k == 1 else f      # (k == 1: a negative-stride view)
+            else:
+                x = torch.from_numpy(f).cuda()
+            Hc, m = trk.track(x)
+            out.append((Hc.copy(), bool(m.lost)))
+        return out
+
+    a, b = run(True), run(False)
+    assert [l for _, l in a] == [l for _, l in b] and any(l for _, l in a)
+    for (Ha, _), (Hb, _) in zip(a, b):
+        assert np.array_equal(Ha, Hb)

@@ -5,7 +5,6 @@
 """
 import logging
 import os
-import zipfile
 from pathlib import Path
 from timeit import default_timer as timer
 
@@ -67,8 +66,15 @@ class RAFTWrapper:
         # precision class), "bf16x3" (split-bf16 operands, fp32 accumulation: fp32-emulating), "bf16", or "fp16".
         # `mixed_precision=True` selects "fp16" with the reference's scoping (autocast = fp16 around fnet, cnet and the
         # update block only, weighted_raft.py:204-219,233-234; correlation, weight head and upsampling stay fp32-class).
-        self.precision = os.environ.get("WOFT_PRECISION") or self.C.precision or \
-            ("fp16" if cp.mixed_precision else "fp32")
+        # The shipped flow config (pytracking/optical_flow/configs/v2_SNOB_large_g05_RAFT.py) sets precision = 'bf16x3' with
+        # its error budget beside it; a reference config file without the key gets the reference's own arithmetic class.
+        for src, val in (("env WOFT_PRECISION", os.environ.get("WOFT_PRECISION")),
+                         ("flow config key 'precision'", self.C.precision),
+                         ("class_params.mixed_precision", "fp16" if cp.mixed_precision else None),
+                         ("built-in default (no key in the flow config: the reference's fp32)", "fp32")):
+            if val:
+                self.precision, self.precision_source = str(val), src
+                break
         # correlation: "volume" (all-pairs volume + pyramid in HBM, corr.py:13-69) or "otf" (volume-free lookup, what
         # the reference's `alternate_corr` switch selects, corr.py:72-100).  Bit-identical results in every precision
         # (exact fp32 included: the lookup's fp32-MFMA instantiation), "otf" is faster and needs no P x P buffer: the default.
@@ -218,7 +224,9 @@ class RAFTWrapper:
         self.last_flow_shape = {"batch": 1, "delta": 2, "H": oh, "W": ow}
         if numpy_out:
             return host(o["src"]), host(o["dst"]), (host(weights) if weights is not None else None)
-        return own(o["src"]), own(o["dst"]), (own(weights) if weights is not None else None)
+        # (the int64 source grid is a constant of the resolution -- 33 MB at 1080p: handed out SHARED, never cloned;
+        #  a caller that wants to write into it must copy it first)
+        return o["src"], own(o["dst"]), (own(weights) if weights is not None else None)
 
     def compute_flow(self, src_img, dst_img, mode="TC", vis=False, src_img_identifier=None,
                      numpy_out=False, do_sigmoid=False, borrow=False, defer_weights=False, weight_region=False):
@@ -238,8 +246,8 @@ class RAFTWrapper:
         if src_img_identifier is not None:                 # pre-computed flow (raft.py:92-109)
             try:
                 return self._cached_flow(src_img, src_img_identifier, mode, numpy_out, do_sigmoid, borrow)
-            except (OSError, KeyError, ValueError, EOFError, zipfile.BadZipFile) as ex:   # no such file / array, object
-                # placeholders, truncated archives (the reference falls back on any exception, raft.py:108-109): compute the flow
+            except Exception as ex:   # no such file / array, object placeholders, truncated archives, wrong shapes / dtypes:
+                # the reference falls back on ANY exception (raft.py:108-109): compute the flow
                 key = (type(ex), str(ex))                  # (the reference logs each distinct error once)
                 if key not in self._cache_errors:
                     self._cache_errors.add(key)

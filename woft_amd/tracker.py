@@ -72,6 +72,34 @@ def _device_u8(img, copy=False):
     return t.clone() if copy and t is img else t
 
 
+class _FrameUploader:
+    """Host frames (numpy, as WOFT_demo.py:61-78 / TRK:113-120 hand them to track()) -> device, without the pageable-copy
+    path of `tensor.cuda()`: the frame is copied into one of two PINNED staging buffers and sent with an asynchronous
+    H2D copy on the stream the frame's kernels are enqueued on; the two device buffers alternate, so the frame that becomes
+    `prev_img` stays valid while the next one arrives (the local stage reads frame t-1, TRK:181-184).  6.2 MB per 1080p
+    frame: ~0.25 ms of host memcpy + ~0.15 ms of PCIe time, against 2-3 ms for the pageable copy (bench `host_frames`)."""
+
+    def __init__(self):
+        self.key, self.stage, self.dev, self.done, self.i = None, None, None, None, 0
+
+    def __call__(self, a):
+        a = np.asarray(a)
+        if a.dtype != np.uint8:
+            raise TypeError(f"frames and masks must be uint8, got {a.dtype}")
+        key = a.shape
+        if key != self.key:
+            self.stage = [torch.empty(key, dtype=torch.uint8).pin_memory() for _ in range(2)]
+            self.dev = [torch.empty(key, dtype=torch.uint8, device="cuda") for _ in range(2)]
+            self.done = [torch.cuda.Event(), torch.cuda.Event()]
+            self.key, self.i = key, 0
+        i = self.i = self.i ^ 1
+        self.done[i].synchronize()                   # (the copy that last read this staging buffer: two frames ago)
+        np.copyto(self.stage[i].numpy(), a)          # handles non-contiguous views (e.g. a BGR<->RGB flipped array)
+        self.dev[i].copy_(self.stage[i], non_blocking=True)
+        self.done[i].record()
+        return self.dev[i]
+
+
 class _Fit(SimpleNamespace):
     """Result of one solve: H (3x3 float64, cur -> src) and, for the global stage, the re-detection verdict."""
 
@@ -86,6 +114,7 @@ class YAOFTrackerSingleControl:
         self._fused = self._fused_specs()
         self._sparse_weights = False
         self._replay = None
+        self._upload = _FrameUploader()
 
     # ---- which solver back end ------------------------------------------------------------------
     def _fused_specs(self):
@@ -194,7 +223,8 @@ class YAOFTrackerSingleControl:
         if self.C.no_prewarp_after_N and self.N_lost > self.C.no_prewarp_after_N:
             self.last_good_H2init = _EYE.copy()                      # TRK:78-79
         meta.last_good_H2init = self.last_good_H2init.copy()
-        frame = _device_u8(input_img, copy=True)                     # (becomes prev_img: the reference keeps a copy)
+        # (becomes prev_img: the reference keeps a copy.  Host frames go through the pinned double buffer)
+        frame = _device_u8(input_img, copy=True) if isinstance(input_img, torch.Tensor) else self._upload(input_img)
 
         prewarp_H = self.last_good_H2init
         fit = self._global_stage(frame, prewarp_H)
