@@ -226,14 +226,17 @@ def main():
     wh_events, conv_events = [], {t: [] for t in ROOF_TAGS}
     wdist.barrier()
     torch.cuda.synchronize()
+    wait0 = tracker.host_wait_s
     t0 = time.perf_counter()
     results += track_all(tracker, Wm, K, timed=(plan, wh_events, conv_events))
+    t_track = time.perf_counter() - t0
+    host_busy = t_track - (tracker.host_wait_s - wait0)   # the rank's Python launch loop: wall time not spent blocked on the GPU
     tracks = wdist.gather_tracks(results[Wm:])
     torch.cuda.synchronize()
     wdist.barrier()
     elapsed = time.perf_counter() - t0
     per_rank = wdist.gather_floats([elapsed, binding.get("numa_node") if binding.get("numa_node") is not None else -1,
-                                    binding.get("cores") or 0, float(bool(binding.get("bound")))])
+                                    binding.get("cores") or 0, float(bool(binding.get("bound"))), host_busy])
     elapsed = wdist.max_over_ranks(elapsed)
     events = plan.lookup_events
     plan.lookup_events = plan.wh_events = plan.conv_events = None
@@ -257,7 +260,7 @@ def main():
         # bf16-storage volume of the plain-bf16 operating point
         algo_bytes = (LOOKUP_ALGO_BYTES_PER_PIXEL if storage == "fp32" else 4 * (10 * 10 * 2 + 9 * 9 * 4)) * P
         traffic, src = None, None
-        for name in (("r03_lookup_pmc.json", "r02_lookup_pmc.json", "r01_lookup_pmc.json") if storage == "fp32" else ()):   # (PMC passes: fp32 volume;
+        for name in (("r04_lookup_pmc.json", "r03_lookup_pmc.json", "r02_lookup_pmc.json", "r01_lookup_pmc.json") if storage == "fp32" else ()):   # (PMC passes: fp32 volume;
                                                         # FETCH_SIZE is uncalibrated for the bf16 volume's 8-B-per-lane loads)
             try:
                 pmc = json.loads((ROOT / "profiles" / name).read_text())
@@ -298,7 +301,7 @@ def main():
         # HBM bytes per launch of this symbol from the committed PMC passes (tools/conv_pmc.sh; 1080p, default precision only)
         traffic, tsrc = None, None
         if p0.halo == 8 and p0._m == 135 * 240 and args.precision == "bf16x3":
-            for name in ("r03_conv_pmc.json",):
+            for name in ("r04_conv_pmc.json", "r03_conv_pmc.json"):
                 pth = ROOT / "profiles" / name
                 if pth.exists():
                     traffic = json.loads(pth.read_text())["traffic_bytes_per_launch"]
@@ -359,8 +362,12 @@ def main():
         # one entry per rank (a straggler shows here; `value` uses the slowest rank): ms per step inside the same barriers,
         # the NUMA node of the rank's GPU and the host cores its launch thread is pinned to (woft_amd.dist.bind_to_gpu_node)
         "per_rank": [{"rank": r, "ms_per_step": 1000.0 * float(v[0]) / K, "gpu_numa_node": (int(v[1]) if v[1] >= 0 else None),
-                      "host_cores": int(v[2]), "bound": bool(v[3])} for r, v in enumerate(per_rank.tolist())],
+                      "host_cores": int(v[2]), "bound": bool(v[3]),
+                      # host time of the rank's launch loop per frame (track() wall time minus the time blocked on the per-flow
+                      # result read): what must stay well below the GPU's frame time for N loops on two sockets not to limit N GPUs
+                      "host_busy_ms_per_step": 1000.0 * float(v[4]) / K} for r, v in enumerate(per_rank.tolist())],
     }
+    out["host_busy_ms_per_step"] = max(r["host_busy_ms_per_step"] for r in out["per_rank"])
     layers = {e[2]: (list(e[1]) if e[0] == "conv2" else [e[1]]) for e in plan.prog_iter if len(e) > 2 and e[2] in ROOF_TAGS}
     same = {(p_.halo, p_.tile_n, p_.taps_y, p_.taps_x) for ps_ in layers.values() for p_ in ps_}
     if len(same) > 1:                    # (another resolution / precision picked different kernels: keep the largest layer)

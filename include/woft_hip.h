@@ -139,9 +139,34 @@ typedef struct woft_conv_params {
        32-column band and all 128 rows; tile_n 64: 2 x 2 waves.  halo == 12: the same kernel on 4x16-pixel tiles x 128
        columns (tile_n 128, cout_pad % 128 == 0, multi-tap layers): one wave per band and all 64 rows.            */
     const void* wgt_frag;
+    /* Split-packed activations (round 4; split-bf16 / fp16 precisions).  A tensor in this format has the geometry of the
+       fp32 NHWC tensor it replaces (same pixel stride, same channel offsets, 4 bytes per channel), but the 16 bytes of every
+       aligned group of four channels hold the MFMA operand form of the four values instead of the values:
+           bytes 0-7 : hi[0..3] = bf16(x) (precision 1, 2) / fp16(x) (precision 3)
+           bytes 8-15: lo[0..3] = bf16(x - hi) (precision 1); zero otherwise
+       -- exactly what every consumer tile computed from the fp32 value while filling its LDS tile (those
+       conversions were ~a quarter of the vector instructions of the update block's conv launches, and every consumer tile
+       repeated them: 3 column tiles x 1.4 halo overlap for convc2).  The PRODUCER's epilogue converts once, consumers copy.
+       in_fmt : bit 0: in0 is split-packed, bit 1: in1 is (both or neither for halo 8 / 12; never with `flat` or in_norm).
+                halo 8 / 12: each split-packed source must be FOLLOWED BY ONE PIXEL ROW OF ZEROS (pixel index n_img * h * w of its
+                buffer, the channels this layer reads): the halo loader points the taps outside the image there instead of
+                selecting zeros per element.  (The per-tap kernel, halo 0, has no such requirement.)
+       out_fmt: bit 0: `out` is written split-packed (element-wise kinds, WOFT_EPI_GRU_Q's state); a ragged last group
+                (cout % 4 != 0) is completed from e0 (WOFT_EPI_RELU only: out[m][cout .. group end) = the first values of
+                e0[m * lde0 ...], or zero when e0 is NULL -- the motion encoder's `cat([out, flow])`, update.py:96-97);
+                bit 1: `out1` is split-packed: the r*h output of WOFT_EPI_GRU_ZR; with WOFT_EPI_GRU_Q, out1 != NULL receives
+                a split-packed COPY of the new state (out keeps the fp32 state the next gates read).
+       Results are bit-identical to the fp32-activation path (same hi / lo values reach the matrix cores). */
+    int32_t in_fmt, out_fmt;
 } woft_conv_params;
 
 int woft_conv2d(const woft_conv_params* p, void* stream);
+/* fp32 activation rows -> the split-packed form consumed through in_fmt (see woft_conv_params): x [rows][ldx] fp32, the first
+ * `channels` (% 4 == 0) of every row -> out [rows][ldo] (same geometry; in place allowed: out == x, ldo == ldx), in the operand form
+ * of `precision` (1 bf16x3: hi | lo, 2 bf16, 3 fp16: hi | zero).  For activations that no conv epilogue produces in that form (the
+ * GRU's initial state: the context encoder's tanh output, weighted_raft.py:217-218). */
+int woft_pack_split(const float* x, int64_t rows, int32_t channels, int32_t ldx, int32_t precision, float* out, int32_t ldo,
+                    void* stream);
 /* Two INDEPENDENT layers in one launch: both must select the same kernel instance -- same precision (split-bf16 only),
  * halo mode (0 = per-tap kernel, any tap shapes; 8 / 12 = register-streamed kernel, equal tap shape), tile_m / tile_n;
  * no InstanceNorm statistics.  The first layer's workgroups are dispatched first.  Results are those of two woft_conv2d

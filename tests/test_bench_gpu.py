@@ -56,3 +56,19 @@ def test_bench_line_carries_ladder_and_lost_frames():
     assert lf["lost_frame_ms"] > lf["normal_frame_ms"] > 0 and lf["frame_after_lost_ms"] > 0
     assert d["steady_state"]["steps"] == 200 and d["steady_state"]["frames_per_s"] > 0
     assert len(d["per_rank"]) == 1
+
+
+def test_eight_ranks_1080p_host_launch_loops():
+    """8-GPU readiness without the node: eight ranks at the METRIC's size (1080 x 1920, 12 iterations), NUMA
+    binding on, sharing the one device -- so the GPU side is 8x slower than on eight GPUs, but each rank's HOST side (the
+    Python launch loop: ~180 enqueues + one result read per frame) is what it will be there.  Its time per frame must stay
+    below a quarter of a single GPU's frame time, or eight loops on two sockets become the limiter of the 8-GPU run."""
+    one = _run(["--steps", "6", "--warmup", "3"])
+    gpu_ms = one["ms_per_step"]
+    assert one["per_rank"][0]["host_busy_ms_per_step"] <= 0.25 * gpu_ms, one["per_rank"]
+    assert os.environ.get("WOFT_BIND", "1") != "0"              # (the launch threads are pinned as on the 8-GPU node)
+    d = _run(["--gpus", "8", "--steps", "4", "--warmup", "2"], timeout=1800)
+    assert d["n_gpus"] == 8 and d["tracks_gathered"] == [8, 4] and d["config"]["resolution"] == [1080, 1920]
+    busy = [r["host_busy_ms_per_step"] for r in d["per_rank"]]
+    print(f"single-rank GPU frame {gpu_ms:.2f} ms; host launch loop per frame, 8 ranks: {[round(b, 2) for b in busy]} ms")
+    assert max(busy) <= 0.25 * gpu_ms, (busy, gpu_ms)

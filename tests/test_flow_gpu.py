@@ -541,3 +541,27 @@ def test_config1_small_480x640_vs_reference(golden_dir, precision, epe_mean, epe
           f"(mean |flow| {float(np.sqrt((g['flow_up_s'] ** 2).sum(1)).mean()):.2f} px)")
     assert m < epe_mean and mx < epe_max, (m, mx)
     assert rm < epe_max
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16", "fp16"])
+@pytest.mark.parametrize("h,w", [(136, 200), (64, 72)])
+def test_split_packed_update_block_is_bit_identical(monkeypatch, precision, h, w):
+    """The update block on split-packed activations (engine.PACKED_ACTS: producers' epilogues write the MFMA operand form,
+    consumers copy) gives bit-identical flows and weights to fp32 activations -- the same hi / lo values reach the matrix
+    cores.  64 x 72: an 8 x 9 feature map, where the 3x3 layers run on the per-tap kernel (its packed-input path)."""
+    from woft_amd import engine
+    sd = synth.make_state_dict(seed=21)
+    a = synth.make_template(h, w, seq_id=6)
+    b = synth.make_frame(a, 2)
+    outs = []
+    for on in (True, False):
+        monkeypatch.setattr(engine, "PACKED_ACTS", on)
+        c = _flow_config(sd, 5, precision=precision)
+        prov = c.of_class(c)
+        flow, wts = prov.compute_flow(a, b, mode="flow")
+        assert prov.engine.plan(h, w).packed == on
+        outs.append((flow.clone(), wts.clone()))
+        flow2, _ = prov.compute_flow(a, b, mode="flow")          # (second call: buffers hold the previous flow's packed data)
+        assert torch.equal(flow2, flow)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])

@@ -1195,3 +1195,115 @@ def test_conv_1x1_register_streamed(ops, precision, cin, cout, h, w, epi):
         _close(out.nchw(), ref, 1e-4 if precision == "bf16x3" else 3e-2, what=f"1x1 halo {p.halo}")
         assert float(out.t[:, cout:].abs().max()) == 0.0
     assert float((outs[8].t - outs[0].t).abs().max()) < 2e-5
+
+
+# ------------------------------------------------------------------------------------------
+# split-packed activations (woft_conv_params.in_fmt / out_fmt, round 4)
+# ------------------------------------------------------------------------------------------
+def _packed_ref(t, precision):
+    """Host restatement of the split-packed form of fp32 rows [rows][c] (c % 4 == 0): per 4-channel group the 16 bytes
+    [hi[0..3] | lo[0..3]], hi = bf16(x) / fp16(x), lo = bf16(x - hi) (bf16x3) or zero -- as int16 words."""
+    x = t.detach().cpu().float()
+    rows, c = x.shape
+    if precision == "fp16":
+        hi = x.to(torch.float16)
+        lo = torch.zeros_like(hi)
+    else:
+        hi = x.to(torch.bfloat16)
+        lo = (x - hi.float()).to(torch.bfloat16) if precision == "bf16x3" else torch.zeros_like(hi)
+    g = torch.stack([hi.view(torch.int16).reshape(rows, c // 4, 4), lo.view(torch.int16).reshape(rows, c // 4, 4)], 2)
+    return g.reshape(rows, 2 * c)
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16", "fp16"])
+def test_pack_split_kernel(ops, precision):
+    x = _rand(301, 136, seed=3, scale=3.0).cuda()
+    x[5, :8] = torch.tensor([0.0, -0.0, 1e-30, -1e-30, 65000.0, -3.0e4, 1.0, -1.0])
+    out = torch.zeros_like(x)
+    ops.pack_split(x[:, :128], out, precision, channels=128)
+    torch.cuda.synchronize()
+    assert torch.equal(out[:, :128].contiguous().view(torch.int16).cpu(), _packed_ref(x[:, :128], precision))
+    assert float(out[:, 128:].abs().max()) == 0.0
+    y = x.clone()
+    ops.pack_split(y, y, precision)                          # in place
+    torch.cuda.synchronize()
+    assert torch.equal(y.view(torch.int16).cpu(), _packed_ref(x, precision))
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16", "fp16"])
+@pytest.mark.parametrize("kh,kw,cin,cout,h,w,tiles", [(3, 3, 256, 192, 24, 40, None), (3, 3, 128, 64, 17, 37, None),
+                                                      (1, 5, 128, 128, 24, 40, None), (5, 1, 128, 128, 9, 16, None),
+                                                      (3, 3, 256, 126, 24, 40, None), (1, 1, 256, 96, 17, 25, None),
+                                                      (3, 3, 128, 256, 24, 40, (128, 128)), (3, 3, 64, 64, 5, 9, None)])
+def test_conv_split_packed_activations(ops, precision, kh, kw, cin, cout, h, w, tiles):
+    """A conv reading split-packed input (in_fmt) / writing split-packed output (out_fmt) -- on the register-streamed kernel
+    (8x16 / 4x16 tiles, both column widths) and the per-tap kernel (1x1, tiny maps) -- computes exactly what the fp32-activation
+    path computes: the output of the packed-input launch is bit-identical, the packed output is the packed form of the fp32
+    output.  Ragged last group (cout 126): completed from e0's row (the motion encoder's cat([out, flow]), update.py:96-97)."""
+    E = ops._lib
+    x = _rand(1, cin, h, w, seed=11, scale=2.0)
+    wt = _rand(cout, cin, kh, kw, seed=12, scale=1.0 / math.sqrt(cin * kh * kw))
+    b = _rand(cout, seed=13, scale=0.1)
+    pc = ops.pack_conv(wt, b, padding=(kh // 2, kw // 2))
+    xa = ops.act_from_nchw(x)
+    xp = ops.new_act(1, h, w, cin, cs=xa.cs, zero=True)       # (new_act: followed by the zero pixel row the halo loader reads)
+    ops.pack_split(xa.t, xp.t, precision)
+    cs_out = ops._round_up(cout, 4)
+    o_ref, o_in, o_out = (ops.new_act(1, h, w, cout, cs=cs_out, zero=True) for _ in range(3))
+    kw_ = dict(epi=E.EPI_RELU, precision=precision, tiles=tiles, halo=8 if tiles else None)    # (explicit tiles: 8x16 x 128 columns)
+    p_ref = ops.conv_params(xa, pc, o_ref, **kw_)
+    p_in = ops.conv_params(xp, pc, o_in, in_fmt=1, **kw_)
+    assert p_in.halo == p_ref.halo and p_in.halo in (0, 8, 12)
+    tail = _rand(h * w, 4, seed=14).cuda()
+    p_out = ops.conv_params(xp, pc, o_out, in_fmt=1, out_fmt=1, e0=ops.Act(tail, 1, h, w, 4) if cout % 4 else None, **kw_)
+    for p in (p_ref, p_in, p_out):
+        ops.run_conv(p)
+    torch.cuda.synchronize()
+    assert torch.equal(o_in.t, o_ref.t)
+    want = o_ref.t.clone()
+    if cout % 4:
+        want[:, cout:cs_out] = tail[:, :cs_out - cout]
+    assert torch.equal(o_out.t.view(torch.int16).cpu(), _packed_ref(want, precision))
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "fp16"])
+@pytest.mark.parametrize("kh,kw", [(1, 5), (5, 1)])
+def test_gru_half_step_split_packed(ops, kh, kw, precision):
+    """SepConvGRU half step on split-packed [h | motion] / [r*h | motion]: z, the fp32 state and (unpacked) r*h bit-identical to
+    the fp32-activation launches; the state's packed copy (GRU_Q's out1) = the packed form of the fp32 state."""
+    E = ops._lib
+    n, h, w = 1, 24, 40
+    hprev = torch.tanh(_rand(n, 128, h, w, seed=4))
+    xin = _rand(n, 128, h, w, seed=5)
+    mk = lambda s: _rand(128, 256, kh, kw, seed=s, scale=1 / math.sqrt(256 * kh * kw))
+    pad = (kh // 2, kw // 2)
+    pzr = ops.pack_conv(torch.cat([mk(6), mk(7)], 0), None, padding=pad)
+    pq = ops.pack_conv(mk(8), None, padding=pad)
+    gz, gq = ops.act_from_nchw(_rand(n, 256, h, w, seed=9, scale=0.3)), ops.act_from_nchw(_rand(n, 128, h, w, seed=10, scale=0.3))
+    ha, xa = ops.act_from_nchw(hprev), ops.act_from_nchw(xin)
+    hp, xp = ops.new_act(n, h, w, 128, zero=True), ops.new_act(n, h, w, 128, zero=True)
+    ops.pack_split(ha.t, hp.t, precision)
+    ops.pack_split(xa.t, xp.t, precision)
+    z0, rh0, h0 = (ops.new_act(n, h, w, 128, zero=True) for _ in range(3))
+    z1, rh1, h1, h1p = (ops.new_act(n, h, w, 128, zero=True) for _ in range(4))
+    kw_zr = dict(c_split=128, epi=E.EPI_GRU_ZR, split=128, e0=ha, precision=precision)
+    kw_q = dict(c_split=128, epi=E.EPI_GRU_Q, e0=ha, precision=precision)
+    ops.run_conv(ops.conv_params(ha, pzr, z0, x2=xa, out1=rh0, bias_map=gz, **kw_zr))
+    ops.run_conv(ops.conv_params(rh0, pq, h0, x2=xa, e1=z0, bias_map=gq, **kw_q))
+    a = ops.conv_params(hp, pzr, z1, x2=xp, out1=rh1, bias_map=gz, in_fmt=3, out_fmt=2, **kw_zr)
+    b = ops.conv_params(rh1, pq, h1, x2=xp, e1=z1, bias_map=gq, in_fmt=3, out_fmt=2, out1=h1p, **kw_q)
+    assert a.halo in (8, 12) and b.halo in (8, 12)
+    ops.run_conv(a)
+    ops.run_conv(b)
+    torch.cuda.synchronize()
+    assert torch.equal(z1.t, z0.t) and torch.equal(h1.t, h0.t)
+    assert torch.equal(rh1.t.view(torch.int16).cpu(), _packed_ref(rh0.t, precision))
+    assert torch.equal(h1p.t.view(torch.int16).cpu(), _packed_ref(h0.t, precision))
+    # what the ABI refuses: packed input on a kernel without the path, mixed sources on the register-streamed kernel
+    with pytest.raises(ValueError):
+        ops.conv_params(hp, pzr, z1, x2=xp, out1=rh1, in_fmt=3, halo=1, **kw_zr)
+    bad = ops.conv_params(hp, pzr, z1, x2=xp, out1=rh1, in_fmt=3, **kw_zr)
+    bad.in_fmt = 1
+    assert ops._lib.load().woft_conv2d(bad, ops.stream_ptr()) != 0
+    with pytest.raises(ValueError):            # (a tensor without the zero pixel row behind it)
+        ops.conv_params(ops.Act(torch.zeros_like(hp.t), n, h, w, 128), pzr, z1, x2=xp, out1=rh1, in_fmt=3, **kw_zr)

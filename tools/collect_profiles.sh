@@ -1,7 +1,7 @@
 #!/bin/bash
 # One pass over everything profiles/<round>_* is made of (run on the GPU box through gpurun; results -> gpurun_out/<tag>_*):
 #   tools/collect_profiles.sh r02
-tag=${1:-r03}
+tag=${1:-r04}
 root=${GRAFT_REPO_ROOT:-/root/repo}
 out=$root/gpurun_out
 mkdir -p $out

@@ -4,7 +4,7 @@
 # separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over the default bench, corrected as MI355X_MICROARCH.md's HBM section
 # prescribes and as tools/lookup_pmc.sh does (FETCH_SIZE doubled on gfx950 for 16-B-per-lane coalesced reads).  On the GPU box:
 #   tools/conv_pmc.sh r03   ->  gpurun_out/r03_conv_pmc.json  (copy to profiles/ and commit)
-tag=${1:-r03}
+tag=${1:-r04}
 root=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p $root/gpurun_out
 cd /tmp && export TMPDIR=/tmp

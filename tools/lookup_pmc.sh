@@ -4,7 +4,7 @@
 # as MI355X_MICROARCH.md's HBM section prescribes (FETCH_SIZE doubled on gfx950 for 16-B-per-lane coalesced reads;
 # WRITE_SIZE calibrated in the same run on a kernel of known output size).  Run on the GPU box:
 #   tools/lookup_pmc.sh r02      ->  gpurun_out/r02_lookup_pmc.json  (copy to profiles/ and commit)
-tag=${1:-r03}
+tag=${1:-r04}
 root=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p $root/gpurun_out
 cd /tmp && export TMPDIR=/tmp

@@ -31,7 +31,7 @@ class ConvParams(C.Structure):
         ("in_norm", i32), ("in_mean", vp), ("in_rstd", vp), ("bias_map", vp), ("ld_bias_map", i32),
         ("out_index", vp),
         ("wh0_lookup", vp), ("wh0_ld", i32), ("wh0_mean", vp), ("wh0_w", vp), ("wh0_bias", vp), ("wh0_index", vp),
-        ("wgt_frag", vp),
+        ("wgt_frag", vp), ("in_fmt", i32), ("out_fmt", i32),
     ]
 
 
@@ -60,6 +60,7 @@ _SIGS = {
     "woft_conv2d": (i32, [C.POINTER(ConvParams), vp]),
     "woft_conv2d_pair": (i32, [C.POINTER(ConvParams), C.POINTER(ConvParams), vp]),
     "woft_gru_halfstep": (i32, [C.POINTER(ConvParams), C.POINTER(ConvParams), vp]),
+    "woft_pack_split": (i32, [vp, i64, i32, i32, i32, vp, i32, vp]),
     "woft_split_bf16": (i32, [vp, i64, vp, vp, vp]),
     "woft_split_bf16_lines": (i32, [vp, i64, vp, vp]),
     "woft_flow_to_tc": (i32, [vp, vp, i32, i32, vp, vp, i32, vp]),

@@ -3,6 +3,7 @@ import hashlib
 import os
 import subprocess
 import sys
+import time
 from pathlib import Path
 
 HERE = Path(__file__).resolve().parent
@@ -15,8 +16,26 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math"
          "-Wno-c++20-extensions"]
 
 
+# Translation units.  The two template-heavy sources are compiled once per arithmetic mode (-DWOFT_ONLY_PREC = the precision code
+# of woft_conv_params: 1 bf16x3, 2 bf16 (+ the exact-fp32 kernels), 3 fp16; conv_regb.hip additionally per input format,
+# -DWOFT_ONLY_PK = 0 fp32 / 1 split-packed activations): hipcc compiles a unit on ONE core (conv.hip as a single unit: 9+ minutes),
+# the parts run side by side.  Every part exports its own dispatcher symbol (woft_conv_dispatch_p<k>, woft_conv_regb_launch_p<k>_<pk>);
+# the C ABI entry points live in part 1 of conv.hip.
+PARTS = {"conv.hip": [("p1", ["-DWOFT_ONLY_PREC=1"]), ("p2", ["-DWOFT_ONLY_PREC=2"]), ("p3", ["-DWOFT_ONLY_PREC=3"])],
+         "conv_regb.hip": [(f"p{k}_{pk}", [f"-DWOFT_ONLY_PREC={k}", f"-DWOFT_ONLY_PK={pk}"]) for k in (1, 2, 3) for pk in (0, 1)]}
+
+
 def _sources():
     return sorted(CSRC.glob("*.hip"))
+
+
+def _units():
+    """-> [(source, object, extra flags)]"""
+    out = []
+    for src in _sources():
+        for tag, flags in PARTS.get(src.name, [("", [])]):
+            out.append((src, LIBDIR / (src.stem + ("." + tag if tag else "") + ".o"), flags))
+    return out
 
 
 def _digest():
@@ -25,6 +44,7 @@ def _digest():
         h.update(p.name.encode())
         h.update(p.read_bytes())
     h.update(" ".join(FLAGS).encode())
+    h.update(repr(sorted(PARTS.items())).encode())
     return h.hexdigest()
 
 
@@ -34,17 +54,31 @@ def build(force=False, verbose=True):
     if not force and LIB.exists() and STAMP.exists() and STAMP.read_text().strip() == dig:
         return LIB
     objs = []
-    procs = []
-    for src in _sources():
-        obj = LIBDIR / (src.stem + ".o")
-        objs.append(obj)
-        cmd = [HIPCC, *FLAGS, "-c", str(src), "-o", str(obj)]
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        procs.append((src, subprocess.Popen(cmd)))
-    for src, p in procs:
-        if p.wait() != 0:
-            raise RuntimeError(f"hipcc failed on {src}")
+    for old in LIBDIR.glob("*.o"):            # (objects of an earlier unit list must not be linked)
+        old.unlink()
+    units = _units()
+    # heaviest units first; at most `jobs` compilers at a time
+    jobs = int(os.environ.get("WOFT_BUILD_JOBS", os.cpu_count() or 4))
+    units.sort(key=lambda u: -(u[0].stat().st_size * (4 if u[0].name in PARTS else 1)))
+    pending, running = list(units), []
+    while pending or running:
+        while pending and len(running) < jobs:
+            src, obj, extra = pending.pop(0)
+            objs.append(obj)
+            cmd = [HIPCC, *FLAGS, *extra, "-c", str(src), "-o", str(obj)]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            running.append((src, subprocess.Popen(cmd)))
+        time.sleep(0.2)
+        for ent in list(running):
+            rc = ent[1].poll()
+            if rc is None:
+                continue
+            running.remove(ent)
+            if rc != 0:
+                for _, other in running:
+                    other.kill()
+                raise RuntimeError(f"hipcc failed on {ent[0]}")
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB), *map(str, objs)]
     if verbose:
         print(" ".join(cmd), flush=True)

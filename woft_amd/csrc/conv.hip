@@ -31,17 +31,40 @@
 #include "dma.h"
 #include "halo_map.h"
 
+// Build parts (woft_amd/build.py): this file is compiled once per precision code of woft_conv_params -- -DWOFT_ONLY_PREC=1 (bf16x3:
+// the TERMS = 3 instances + the C ABI entry points), 2 (bf16: TERMS = 1 + the exact-fp32 kernel), 3 (fp16: TERMS = 16 + the
+// correlation GEMM) -- a single unit took 9+ minutes on one core.  Part k exports woft_conv_dispatch_p<k>.
+#if !defined(WOFT_ONLY_PREC)
+#error "conv.hip is compiled in parts: -DWOFT_ONLY_PREC=1|2|3 (woft_amd/build.py)"
+#endif
+#define WOFT_CAT2_(a, b) a##b
+#define WOFT_CAT2(a, b) WOFT_CAT2_(a, b)
+#define WOFT_CAT4_(a, b, c, d) a##b##c##d
+#define WOFT_CAT4(a, b, c, d) WOFT_CAT4_(a, b, c, d)
+#if WOFT_ONLY_PREC == 1
+constexpr int PART_TERMS = 3;
+#elif WOFT_ONLY_PREC == 3
+constexpr int PART_TERMS = 16;
+#else
+constexpr int PART_TERMS = 1;
+#endif
+
+// developer knob (woft_set_tuning; never set on the hot path): [2] = ablation bits of corr_gemm_bf16_kernel for
+// tools/bench_cgemm.py (1 no stores, 2 no epilogue, 4 no operand DMA after the first step, 8 no MFMAs, 16 non-temporal stores)
+#if WOFT_ONLY_PREC == 1
+int g_tuning[4] = {0, 0, 0, 0};
+#else
+extern int g_tuning[4];
+#endif
+
 namespace {
 
 using woft::ARows;
 using woft::BK;
 
-// developer knob (woft_set_tuning; never set on the hot path): [2] = ablation bits of corr_gemm_bf16_kernel for
-// tools/bench_cgemm.py (1 no stores, 2 no epilogue, 4 no operand DMA after the first step, 8 no MFMAs, 16 non-temporal stores)
-int g_tuning[4] = {0, 0, 0, 0};
-
 constexpr int LDS_LD = 36;   // fp32 tiles: floats per row (144 B: 16-B aligned, conflict-free b128 reads)
 
+#if WOFT_ONLY_PREC == 2
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void conv_mfma_f32_kernel(const woft_conv_params p) {
     constexpr int TM = BM / 64, TN = BN / 64;
@@ -135,6 +158,8 @@ __global__ __launch_bounds__(256) void conv_mfma_f32_kernel(const woft_conv_para
 
 // ---- split-bf16 kernel -------------------------------------------------------------------------
 
+#endif  // WOFT_ONLY_PREC == 2 (fp32 kernel)
+
 // Per-tap ("gather") implicit GEMM on split-bf16 operands: any stride / tap shape / flat packing, 1x1 included.
 // A rows (fp32, NHWC) are fetched one K step ahead into registers, split into bf16 hi / lo and written to the idle
 // one of two LDS stages; the weight tile goes global -> LDS by LDS-DMA into the idle one of two stages (unpadded
@@ -213,9 +238,11 @@ __global__ __launch_bounds__(256) void conv_mfma_bf16_kernel(const woft_conv_par
     // HBM latency of its activation rows in every step
     f32x4 ra0[RA], ra1[RA];
     bool rok0[RA], rok1[RA];
-    auto load_a = [&](f32x4 (&ra)[RA], bool (&rok)[RA]) {   // the step at the prefetch position
+    bool rpk0 = false, rpk1 = false;                    // the set's rows are split-packed (woft_conv_params.in_fmt): copy, do not convert
+    auto load_a = [&](f32x4 (&ra)[RA], bool (&rok)[RA], bool& rpk) {   // the step at the prefetch position
         const int c0 = pf_chunk * BK;
         const bool second = (p.in1 != nullptr) && (c0 >= p.c_split);
+        rpk = (p.in_fmt & (second ? 2 : 1)) != 0;
         const float* src = (second ? p.in1 + (c0 - p.c_split) : p.in0 + (p.flat ? 0 : c0)) + 4 * v;
         const int cs = second ? p.cs1 : p.cs0;
 #pragma unroll
@@ -232,8 +259,18 @@ __global__ __launch_bounds__(256) void conv_mfma_bf16_kernel(const woft_conv_par
             tap_rows();
         }
     };
-    auto store_a = [&](int stage, f32x4 (&ra)[RA], bool (&rok)[RA]) {
+    auto store_a = [&](int stage, f32x4 (&ra)[RA], bool (&rok)[RA], const bool rpk) {
         __bf16* As = Asm + stage * A_STAGE;
+        if (rpk) {                                      // (wave-uniform)
+#pragma unroll
+            for (int j = 0; j < RA; ++j) {
+                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                const f32x4 val = rok[j] ? ra[j] : zero;
+                *(bf16x4*)(As + (r0 + 32 * j) * LDB + 4 * v) = packed_hi(val);
+                if (NP == 2) *(bf16x4*)(As + A_PLANE + (r0 + 32 * j) * LDB + 4 * v) = packed_lo(val);
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < RA; ++j) {
             const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -310,11 +347,11 @@ __global__ __launch_bounds__(256) void conv_mfma_bf16_kernel(const woft_conv_par
 
     tap_rows();
     dma_b(0, 0);
-    load_a(ra0, rok0);
-    store_a(0, ra0, rok0);
+    load_a(ra0, rok0, rpk0);
+    store_a(0, ra0, rok0, rpk0);
     if (nk > 1) {                                        // step 1 -> set 0 (stays in flight across the barrier)
         advance();
-        load_a(ra0, rok0);
+        load_a(ra0, rok0, rpk0);
         dma_wait<RA>();
     } else {
         dma_wait<0>();
@@ -322,23 +359,23 @@ __global__ __launch_bounds__(256) void conv_mfma_bf16_kernel(const woft_conv_par
     __syncthreads();
     int stage = 0;
     // one K step: `cur` holds the rows of step ks + 1 (requested a step ago), `nxt` receives those of step ks + 2
-    auto step = [&](int ks, f32x4 (&cur)[RA], bool (&cok)[RA], f32x4 (&nxt)[RA], bool (&nok)[RA]) {
+    auto step = [&](int ks, f32x4 (&cur)[RA], bool (&cok)[RA], const bool cpk, f32x4 (&nxt)[RA], bool (&nok)[RA], bool& npk) {
         dma_b(ks + 1, stage ^ 1);                       // lands in the idle stage while this step computes
         const bool ahead = ks + 2 < nk;
         if (ahead) {
             advance();
-            load_a(nxt, nok);
+            load_a(nxt, nok, npk);
         }
         compute(stage);
-        store_a(stage ^ 1, cur, cok);                   // idle A stage: last read in step ks-1, a barrier ago
+        store_a(stage ^ 1, cur, cok, cpk);                 // idle A stage: last read in step ks-1, a barrier ago
         if (ahead) dma_wait<RA>();                      // (the RA loads of `nxt` were issued after the DMA)
         else dma_wait<0>();
         __syncthreads();
         stage ^= 1;
     };
     for (int ks = 0; ks + 1 < nk; ks += 2) {
-        step(ks, ra0, rok0, ra1, rok1);
-        if (ks + 2 < nk) step(ks + 1, ra1, rok1, ra0, rok0);
+        step(ks, ra0, rok0, rpk0, ra1, rok1, rpk1);
+        if (ks + 2 < nk) step(ks + 1, ra1, rok1, rpk1, ra0, rok0, rpk0);
     }
     compute(stage);
     __syncthreads();
@@ -742,10 +779,13 @@ int launch_halo(const woft_conv_params& p, hipStream_t s) {
     else if (p.taps_y == 1 && p.taps_x == 5) HALO_LAUNCH(1, 5, T, false);                       \
     else if (p.taps_y == 5 && p.taps_x == 1) HALO_LAUNCH(5, 1, T, false);                       \
     else return WOFT_EINVAL
-    if (p.precision == 1) { HALO_TAPS(3); } else if (p.precision == 3) {
-        if constexpr (TY == 9) return WOFT_EINVAL;       /* (the weight head keeps the split-bf16 arithmetic) */
-        else { HALO_TAPS(16); }
-    } else { HALO_TAPS(1); }
+    if (p.precision != WOFT_ONLY_PREC || p.in_fmt != 0) return WOFT_EINVAL;      // (fp32-activation inputs only: see conv_regb.hip)
+#if WOFT_ONLY_PREC == 3
+    if constexpr (TY == 9) return WOFT_EINVAL;           /* (the weight head keeps the split-bf16 arithmetic) */
+    else { HALO_TAPS(16); }
+#else
+    HALO_TAPS(PART_TERMS);
+#endif
 #undef HALO_TAPS
 #undef HALO_LAUNCH
     return woft_launch_status();
@@ -764,6 +804,7 @@ int launch_halo(const woft_conv_params& p, hipStream_t s) {
 // service group holds 8 even and 8 odd rows whose (r >> 1) & 7 are all different).
 // One stage only (32 KiB): four workgroups per CU overlap each other's load, MFMA and store-drain phases,
 // which measured faster than two stages with two workgroups (tools/bench_cgemm.py).
+#if WOFT_ONLY_PREC == 3
 template <int TERMS, int WM, int WN, int STAGES, bool OUT16 = false>
 __global__ __launch_bounds__(WM * WN * 64, 4)
 void corr_gemm_bf16_kernel(const __bf16* __restrict__ a, const __bf16* __restrict__ b, int line_elems_per_row,
@@ -921,6 +962,9 @@ void corr_gemm_bf16_kernel(const __bf16* __restrict__ a, const __bf16* __restric
         }
 }
 
+#endif  // WOFT_ONLY_PREC == 3 (correlation GEMM kernel)
+
+#if WOFT_ONLY_PREC == 1
 // fp32 matrix -> hi / lo bf16 planes (used for the dynamic B operand of the correlation GEMM)
 __global__ void split_bf16_kernel(const float* __restrict__ x, int64_t n4, __bf16* __restrict__ hi,
                                   __bf16* __restrict__ lo) {
@@ -932,6 +976,8 @@ __global__ void split_bf16_kernel(const float* __restrict__ x, int64_t n4, __bf1
     if (lo != nullptr) *(bf16x4*)(lo + i * 4) = __builtin_convertvector(vv - __builtin_convertvector(h, f32x4), bf16x4);
 }
 
+#endif
+
 template <int BM, int BN>
 int launch_conv(const woft_conv_params& p, const woft_conv_params* second, hipStream_t s) {
     auto blocks = [](const woft_conv_params& q) { return ceil_div64((int64_t)q.n_img * q.ho * q.wo, BM) * (q.cout_pad / BN); };
@@ -939,30 +985,36 @@ int launch_conv(const woft_conv_params& p, const woft_conv_params* second, hipSt
     const int split = (int)blocks(p);
     dim3 grid((unsigned)(blocks(p) + (second ? blocks(pb) : 0)));       // 1-D: see woft::tile_of_block
     if (p.precision == 0) {
-        if (second) return WOFT_EINVAL;
+#if WOFT_ONLY_PREC == 2
+        if (second || p.in_fmt != 0 || p.out_fmt != 0) return WOFT_EINVAL;
         woft_launch(0, conv_mfma_f32_kernel<BM, BN>, grid, dim3(256), 0, s, p);
         return woft_launch_status();
+#else
+        return WOFT_EINVAL;
+#endif
     }
+    if (p.precision != WOFT_ONLY_PREC) return WOFT_EINVAL;
     // split-bf16 kernels use 32-bit element offsets
     for (const woft_conv_params* q : {&p, &pb}) {
         const int64_t cs_max = (q->in1 != nullptr && q->cs1 > q->cs0) ? q->cs1 : q->cs0;
         if ((int64_t)q->n_img * q->h * q->w * cs_max >= (1ll << 31)) return WOFT_EINVAL;
         if ((int64_t)q->taps_y * q->taps_x * q->cin_pad >= (1 << 20)) return WOFT_EINVAL;
     }
-    if (p.precision == 1)
-        woft_launch(0, conv_mfma_bf16_kernel<BM, BN, 3>, grid, dim3(256), 0, s, p, pb, split);
-    else if (p.precision == 3)
-        woft_launch(0, conv_mfma_bf16_kernel<BM, BN, 16>, grid, dim3(256), 0, s, p, pb, split);
-    else
-        woft_launch(0, conv_mfma_bf16_kernel<BM, BN, 1>, grid, dim3(256), 0, s, p, pb, split);
+    woft_launch(0, conv_mfma_bf16_kernel<BM, BN, PART_TERMS>, grid, dim3(256), 0, s, p, pb, split);
     return woft_launch_status();
 }
 
 }  // namespace
 
-int woft_conv_regb_launch(const woft_conv_params& p, const woft_conv_params* second, void* stream);     // conv_regb.hip
+// conv_regb.hip, the parts of this precision: fp32 / split-packed input activations
+int WOFT_CAT4(woft_conv_regb_launch_p, WOFT_ONLY_PREC, _, 0)(const woft_conv_params& p, const woft_conv_params* second, void* stream);
+int WOFT_CAT4(woft_conv_regb_launch_p, WOFT_ONLY_PREC, _, 1)(const woft_conv_params& p, const woft_conv_params* second, void* stream);
 int woft_conv_stem_launch(const woft_conv_params& p, void* stream);                                     // conv_stem.hip
+int woft_conv_dispatch_p1(const woft_conv_params& p, const woft_conv_params* second, void* stream);
+int woft_conv_dispatch_p2(const woft_conv_params& p, const woft_conv_params* second, void* stream);
+int woft_conv_dispatch_p3(const woft_conv_params& p, const woft_conv_params* second, void* stream);
 
+#if WOFT_ONLY_PREC == 1
 static int conv_check(const woft_conv_params& p) {
     if (p.in0 == nullptr || p.out == nullptr) return WOFT_EINVAL;
     if (p.precision < 0 || p.precision > 3) return WOFT_EINVAL;
@@ -1011,18 +1063,33 @@ static int conv_check(const woft_conv_params& p) {
          p.in_norm != 0 || p.ho != 9 || p.wo != 9 || p.wh0_ld < 324 || p.wh0_ld % 4 != 0 || p.wh0_mean == nullptr ||
          p.wh0_w == nullptr || p.wh0_bias == nullptr))
         return WOFT_EINVAL;
+    // split-packed activations (in_fmt / out_fmt): split-bf16 / fp16 precisions; inputs of the per-tap kernel (halo 0, not flat)
+    // and of the register-streamed kernel (halo 8 / 12: both sources or neither); outputs of the shared epilogue's kinds
+    if ((p.in_fmt & ~3) != 0 || (p.out_fmt & ~3) != 0) return WOFT_EINVAL;
+    if (p.in_fmt != 0) {
+        if (p.precision == 0 || p.flat || p.in_norm != 0 || (p.halo != 0 && p.halo != 8 && p.halo != 12)) return WOFT_EINVAL;
+        if ((p.in_fmt & 2) != 0 && p.in1 == nullptr) return WOFT_EINVAL;
+        if (p.halo != 0 && p.in_fmt != (p.in1 != nullptr ? 3 : 1)) return WOFT_EINVAL;
+    }
+    if (p.out_fmt != 0) {
+        if (p.precision == 0 || p.epi == WOFT_EPI_WH_MEAN || p.epi == WOFT_EPI_FLOWHEAD || p.epi == WOFT_EPI_CTX) return WOFT_EINVAL;
+        if ((p.out_fmt & 1) != 0 && p.epi == WOFT_EPI_GRU_ZR) return WOFT_EINVAL;             // (z stays fp32: only the blend reads it)
+        if ((p.out_fmt & 2) != 0 && ((p.epi != WOFT_EPI_GRU_ZR && p.epi != WOFT_EPI_GRU_Q) || p.out1 == nullptr)) return WOFT_EINVAL;
+        if ((p.out_fmt & 1) != 0 && p.cout % 4 != 0 && p.epi != WOFT_EPI_RELU) return WOFT_EINVAL;   // (ragged group completed from e0)
+    } else if (p.epi == WOFT_EPI_GRU_Q && p.out1 != nullptr) return WOFT_EINVAL;
     return WOFT_OK;
 }
+#endif  // WOFT_ONLY_PREC == 1 (argument checks)
 
 // second != NULL: one launch for two layers that run on the same kernel instance (woft_conv2d_pair)
-static int conv_dispatch(const woft_conv_params& p, const woft_conv_params* second, void* stream) {
+int WOFT_CAT2(woft_conv_dispatch_p, WOFT_ONLY_PREC)(const woft_conv_params& p, const woft_conv_params* second, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (second != nullptr && (second->precision != p.precision || second->halo != p.halo ||
                               (p.halo == 0 && second->tile_m != p.tile_m) ||
                               second->tile_n != p.tile_n || p.precision == 0 || (p.halo != 0 && p.halo != 8 && p.halo != 12)))
         return WOFT_EINVAL;
     if (p.halo == 7)                      // the encoders' 7x7 / stride-2 first layer on its own kernel (conv_stem.hip)
-        return second != nullptr ? WOFT_EINVAL : woft_conv_stem_launch(p, stream);
+        return (second != nullptr || p.in_fmt != 0) ? WOFT_EINVAL : woft_conv_stem_launch(p, stream);
     for (const woft_conv_params* q : {&p, second}) {
         if (q == nullptr || q->halo == 0) continue;
         // LDS-halo kernels: split-bf16 precisions, stride 1, 3x3 / 1x5 / 5x1 taps, non-flat, same-size output
@@ -1033,7 +1100,9 @@ static int conv_dispatch(const woft_conv_params& p, const woft_conv_params* seco
         if ((int64_t)q->taps_y * q->taps_x * q->cin_pad >= (1 << 20)) return WOFT_EINVAL;
     }
     if (p.halo != 0) {
-        if (p.halo == 8 || p.halo == 12) return woft_conv_regb_launch(p, second, stream);
+        if (p.halo == 8 || p.halo == 12)
+            return p.in_fmt != 0 ? WOFT_CAT4(woft_conv_regb_launch_p, WOFT_ONLY_PREC, _, 1)(p, second, stream)
+                                 : WOFT_CAT4(woft_conv_regb_launch_p, WOFT_ONLY_PREC, _, 0)(p, second, stream);
         if (p.halo == 1 && p.tile_n == 128) return launch_halo<8, 16, 128, 2, 2>(p, s);
         if (p.halo == 1 && p.tile_n == 64) return launch_halo<8, 16, 64, 2, 2>(p, s);
         if (p.halo == 2 && p.tile_n == 128 && p.ho == 9 && p.wo == 9) return launch_halo<9, 9, 128, 1, 2>(p, s);
@@ -1047,6 +1116,15 @@ static int conv_dispatch(const woft_conv_params& p, const woft_conv_params* seco
     if (p.tile_m == 128 && p.tile_n == 64) return launch_conv<128, 64>(p, second, s);
     if (p.tile_m == 64 && p.tile_n == 128) return launch_conv<64, 128>(p, second, s);
     return launch_conv<64, 64>(p, second, s);
+}
+
+#if WOFT_ONLY_PREC == 1
+static int conv_dispatch(const woft_conv_params& p, const woft_conv_params* second, void* stream) {
+    switch (p.precision) {               // (the exact-fp32 kernel lives in the bf16 part)
+        case 1: return woft_conv_dispatch_p1(p, second, stream);
+        case 3: return woft_conv_dispatch_p3(p, second, stream);
+        default: return woft_conv_dispatch_p2(p, second, stream);
+    }
 }
 
 extern "C" int woft_conv2d(const woft_conv_params* pp, void* stream) {
@@ -1063,7 +1141,9 @@ extern "C" int woft_conv2d_pair(const woft_conv_params* a, const woft_conv_param
     if (a->stat_sum != nullptr || b->stat_sum != nullptr) return WOFT_EINVAL;     // (statistics rows are indexed by the launch's tiles)
     return conv_dispatch(*a, b, stream);
 }
+#endif  // WOFT_ONLY_PREC == 1 (woft_conv2d, woft_conv2d_pair)
 
+#if WOFT_ONLY_PREC == 3
 extern "C" int woft_corr_gemm_bf16(const void* a, const void* b, int64_t m, int64_t n, int64_t rows_a, int64_t rows_b,
                                    int32_t k, float alpha, void* out, int64_t ldo, int32_t terms, int32_t out_bf16,
                                    void* stream) {
@@ -1098,6 +1178,9 @@ extern "C" int woft_corr_gemm_bf16(const void* a, const void* b, int64_t m, int6
     return woft_launch_status();
 }
 
+#endif  // WOFT_ONLY_PREC == 3 (woft_corr_gemm_bf16)
+
+#if WOFT_ONLY_PREC == 1
 int g_regb_dyn_lds = 0;     // developer knob [3]: extra dynamic LDS bytes of conv_regb launches (occupancy experiments)
 
 extern "C" int woft_set_tuning(int key, int value) {
@@ -1130,3 +1213,4 @@ extern "C" int woft_split_bf16(const float* x, int64_t n, void* hi, void* lo, vo
                        n / 4, (__bf16*)hi, (__bf16*)lo);
     return woft_launch_status();
 }
+#endif  // WOFT_ONLY_PREC == 1

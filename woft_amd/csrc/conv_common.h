@@ -3,6 +3,7 @@
 // fused epilogue.  See conv.hip for the GEMM formulation.
 #pragma once
 #include "common.h"
+#include "halo_map.h"
 #include <utility>
 #include <type_traits>
 
@@ -143,6 +144,7 @@ struct EpiRegs {
     float alpha;
     bool no_store;
     bool fast;             // gate functions on the hardware exp2 / rcp (split-bf16 / fp16 precisions), see common.h
+    int pk, pk1;           // != 0: `out` / `out1` are written split-packed in this precision's operand form (woft_conv_params.out_fmt)
 };
 
 // One row group (8 rows x 32 columns of a transposed tile) in two steps, so that a caller can issue the operand loads of
@@ -157,7 +159,11 @@ __device__ __forceinline__ EpiOps epi_load(const EpiRegs& a, const int64_t m, co
     EpiOps o;
     o.b4 = bias4;
     o.o0 = o.o1 = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (!nok) return o;
+    if (!nok) {
+        // split-packed output, ragged last group (WOFT_EPI_RELU): the group is stored whole, its tail = the first values of e0's row
+        if (EPI == WOFT_EPI_RELU && a.pk != 0 && !a.e0.null()) o.o0 = a.e0.ld4(m * a.lde0);
+        return o;
+    }
     if (!a.bias_map.null()) o.b4 = a.bias_map.ld4(m * a.ld_bias_map + n);
     if (EPI == WOFT_EPI_RELU_RES_RELU || EPI == WOFT_EPI_GRU_Q) o.o0 = a.e0.ld4(m * a.lde0 + n);
     if (EPI == WOFT_EPI_GRU_ZR && n >= a.split) o.o0 = a.e0.ld4(m * a.lde0 + (n - a.split));
@@ -195,18 +201,27 @@ __device__ __forceinline__ f32x4 epi_finish(const EpiRegs& a, const f32x4 v, con
             if (n >= a.split) {                        // split % 4 == 0 (validated): whole vector is r
 #pragma unroll
                 for (int e = 0; e < 4; ++e) y[e] *= o.o0[e];
-                if (!a.no_store) a.out1.st4(m * a.ldo1 + (n - a.split), y);
+                if (!a.no_store) a.out1.st4(m * a.ldo1 + (n - a.split), a.pk1 != 0 ? pack_split_rt(y, a.pk1) : y);
                 stored = true;
             }
             break;
         case WOFT_EPI_GRU_Q:
 #pragma unroll
             for (int e = 0; e < 4; ++e) y[e] = (1.f - o.o1[e]) * o.o0[e] + o.o1[e] * tanh_t<FAST>(y[e]);
+            // (the state in both forms: fp32 for the next gates' element-wise reads, split-packed for the convs that read it)
+            if (a.pk1 != 0 && !a.no_store) a.out1.st4(m * a.ldo1 + n, pack_split_rt(y, a.pk1));
             break;
         default: break;
     }
     if (stored) return ypre;
-    if (nok) {
+    if (a.pk != 0) {
+        if (!nok) {                                    // ragged group: completed from e0 (epi_load) or with zeros
+#pragma unroll
+            for (int e = 1; e < 4; ++e)
+                if (e >= nrag) y[e] = o.o0[e - nrag];
+        }
+        a.out.st4(m * a.ldo + a.co_off + n, pack_split_rt(y, a.pk));
+    } else if (nok) {
         a.out.st4(m * a.ldo + a.co_off + n, y);
     } else {                                           // ragged group (element-wise kinds only)
 #pragma unroll
@@ -315,6 +330,8 @@ __device__ __forceinline__ void conv_epilogue_t(const woft_conv_params& p, f32x1
     a.split = keep_sgpr(p.split); a.epi = keep_sgpr(p.epi); a.alpha = keep_sgpr(p.alpha);
     a.no_store = p.out_w == -12345;                            // (micro-benchmark ablation, tools/bench_conv.py)
     a.fast = p.precision != 0 && p.out_w != -12346;            // (-12346: developer ablation, library gate functions)
+    a.pk = keep_sgpr((p.out_fmt & 1) ? p.precision : 0);
+    a.pk1 = keep_sgpr((p.out_fmt & 2) ? p.precision : 0);
     const GPtr stat_sum = keep_gptr(p.stat_sum), stat_sq = keep_gptr(p.stat_sq);
     const int cout_pad = keep_sgpr(p.cout_pad);
     const bool do_stats = !stat_sum.null();

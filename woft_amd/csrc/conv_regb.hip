@@ -23,14 +23,26 @@
 
 extern int g_regb_dyn_lds;          // conv.hip (woft_set_tuning key 3)
 
+// Build parts (woft_amd/build.py): this file is compiled once per (precision code, input format) -- WOFT_ONLY_PREC in {1, 2, 3},
+// WOFT_ONLY_PK in {0, 1} -- each part exporting woft_conv_regb_launch_p<prec>_<pk>; conv.hip's dispatcher of the same precision
+// picks the part by the layer's in_fmt.
+#if !defined(WOFT_ONLY_PREC) || !defined(WOFT_ONLY_PK)
+#error "conv_regb.hip is compiled in parts: -DWOFT_ONLY_PREC=1|2|3 -DWOFT_ONLY_PK=0|1 (woft_amd/build.py)"
+#endif
+#define WOFT_CAT4_(a, b, c, d) a##b##c##d
+#define WOFT_CAT4(a, b, c, d) WOFT_CAT4_(a, b, c, d)
+#define WOFT_REGB_ENTRY WOFT_CAT4(woft_conv_regb_launch_p, WOFT_ONLY_PREC, _, WOFT_ONLY_PK)
+
 namespace {
 
 using woft::BK;
 
 // NORM (compile time; encoder layers, round 3): p.in_norm != 0 -- the producer's InstanceNorm (+ ReLU) applied while the halo is
 // converted, with conv_halo_bf16_kernel's expression (bit-identical); the per-channel statistics of the chunk travel with its halo rows.
+// PK (compile time; round 4): both input sources are SPLIT-PACKED (woft_conv_params.in_fmt): a halo row's 16 bytes already
+// are [hi[0..3] | lo[0..3]] of its four channels -- the loader copies them into the two LDS planes, no conversion.
 template <int TY, int TX, int KY, int KX, int WM, int TERMS, int NBUF, int DIST, int AD, int CU = 1, int HD = 1, bool IL = true,
-          bool NORM = false>
+          bool NORM = false, bool PK = (WOFT_ONLY_PK != 0)>
 __global__ __launch_bounds__(256, 2) void conv_regb_kernel(const woft_conv_params pa, const woft_conv_params pb, const int split) {
     // (two independent layers that run on the same instance of this kernel may share ONE launch -- woft_conv2d_pair: the
     //  workgroups [0, split) belong to the first layer, the rest to the second; split = gridDim.x for a single layer)
@@ -85,7 +97,9 @@ __global__ __launch_bounds__(256, 2) void conv_regb_kernel(const woft_conv_param
         const int hy = ht / HX, hx = ht - hy * HX;
         const int iy = y0 + hy - p.pad_y, ix = x0 + hx - p.pad_x;
         hok[j] = ht < HROWS && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w;
-        hpix[j] = hok[j] ? (img0 * p.h + iy) * p.w + ix : 0;
+        // (PK: taps outside the image read the ZERO PIXEL ROW that follows a split-packed tensor -- pixel index n_img * h * w,
+        //  see woft_conv_params.in_fmt -- so the loader needs no per-element select)
+        hpix[j] = hok[j] ? (img0 * p.h + iy) * p.w + ix : (PK ? p.n_img * p.h * p.w : 0);
     }
     f32x4 rh[HD][RH];                                    // ring: the input tile of chunk c waits in rh[c % HD]
     f32x4 nmu[HD], nrs[HD];                              // NORM: mean / rstd of the chunk's channels 4 v .. 4 v + 3
@@ -117,6 +131,12 @@ __global__ __launch_bounds__(256, 2) void conv_regb_kernel(const woft_conv_param
                 if (p.in_norm == 2) y = fmaxf(y, 0.f);
                 x[e] = y;
             }
+        }
+        if constexpr (PK) {                              // (the zero row supplied the padding: a plain copy)
+            static_assert(!NORM, "split-packed inputs are final activations");
+            *(bf16x4*)(As + ht * LDB + 4 * v) = packed_hi(x);
+            if (NP == 2) *(bf16x4*)(As + A_PLANE + ht * LDB + 4 * v) = packed_lo(x);
+            return;
         }
         const f32x4 val = hok[j] ? x : zero;
         const bf16x4 hi = cvt16<TERMS>(val);
@@ -368,12 +388,18 @@ int launch_regb(const woft_conv_params& p, const woft_conv_params* second, hipSt
     dim3 grid((unsigned)(blocks(p) + (second ? blocks(pb) : 0)));
 #define REGB(KY, KX, T, NB, D) \
     woft_launch(0, conv_regb_kernel<TY, TX, KY, KX, WM, T, NB, D, 2>, grid, dim3(256), (size_t)g_regb_dyn_lds, s, p, pb, split)
+#if WOFT_ONLY_PK == 0
+#define REGB_NORM_INSTANCE(T) \
+            if (p.taps_y == 3 && p.taps_x == 3 && second == nullptr)                                        \
+                woft_launch(0, conv_regb_kernel<TY, TX, 3, 3, WM, T, 3, 2, 2, 1, 1, true, true>, grid, dim3(256), (size_t)g_regb_dyn_lds, s, p, pb, split); \
+            else return WOFT_EINVAL;
+#else
+#define REGB_NORM_INSTANCE(T) return WOFT_EINVAL;
+#endif
 #define REGB_TAPS(T)                                                     \
     if (p.in_norm != 0) {                 /* encoder residual blocks: 3x3, 8x16 x 64 tiles, single layer */ \
         if constexpr (WM == 2 && TY == 8) {                                                                 \
-            if (p.taps_y == 3 && p.taps_x == 3 && second == nullptr)                                        \
-                woft_launch(0, conv_regb_kernel<TY, TX, 3, 3, WM, T, 3, 2, 2, 1, 1, true, true>, grid, dim3(256), (size_t)g_regb_dyn_lds, s, p, pb, split); \
-            else return WOFT_EINVAL;                                                                        \
+            REGB_NORM_INSTANCE(T)                                                                           \
         } else return WOFT_EINVAL;                                                                          \
     } else if (p.taps_y == 3 && p.taps_x == 3) REGB(3, 3, T, 3, 2);      \
     else if (p.taps_y == 1 && p.taps_x == 5) REGB(1, 5, T, 5, 3);        \
@@ -384,7 +410,14 @@ int launch_regb(const woft_conv_params& p, const woft_conv_params* second, hipSt
             woft_launch(0, conv_regb_kernel<TY, TX, 1, 1, WM, T, 3, 2, 1, 3, 3, false>, grid, dim3(256), (size_t)g_regb_dyn_lds, s, p, pb, split); \
         else return WOFT_EINVAL;                                                                                                \
     } else return WOFT_EINVAL
-    if (p.precision == 1) { REGB_TAPS(3); } else if (p.precision == 3) { REGB_TAPS(16); } else { REGB_TAPS(1); }
+    if (p.precision != WOFT_ONLY_PREC) return WOFT_EINVAL;
+#if WOFT_ONLY_PREC == 1
+    REGB_TAPS(3);
+#elif WOFT_ONLY_PREC == 3
+    REGB_TAPS(16);
+#else
+    REGB_TAPS(1);
+#endif
 #undef REGB_TAPS
 #undef REGB
     return woft_launch_status();
@@ -395,7 +428,13 @@ int launch_regb(const woft_conv_params& p, const woft_conv_params* second, hipSt
 // Called by woft_conv2d for p.halo == 8 (8 x 16-pixel tiles) and 12 (4 x 16 pixels x 128 columns: four waves = four column
 // bands of 64 rows -- the per-wave work of the 8 x 16 x 64 layout with the weights fetched once per workgroup), after its
 // argument checks.
-int woft_conv_regb_launch(const woft_conv_params& p, const woft_conv_params* second, void* stream) {
+int WOFT_REGB_ENTRY(const woft_conv_params& p, const woft_conv_params* second, void* stream) {
+    // input format of this part: both sources split-packed (WOFT_ONLY_PK = 1) or both fp32
+    for (const woft_conv_params* q : {&p, second}) {
+        if (q == nullptr) continue;
+        const int want = WOFT_ONLY_PK ? ((q->in1 != nullptr) ? 3 : 1) : 0;
+        if ((q->in_fmt & 3) != want || (WOFT_ONLY_PK && q->in_norm != 0)) return WOFT_EINVAL;
+    }
     if (second != nullptr) {            // one launch for two layers: the same kernel instance, no probe
         const woft_conv_params& b = *second;
         if (b.halo != p.halo || b.tile_n != p.tile_n || b.taps_y != p.taps_y || b.taps_x != p.taps_x || b.precision != p.precision ||

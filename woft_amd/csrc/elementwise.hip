@@ -1,7 +1,19 @@
 // Streaming (HBM-bound) helpers: input normalisation, InstanceNorm finalize/apply, 2x2 pooling.
 #include "common.h"
+#include "halo_map.h"
 
 namespace {
+
+// ---- fp32 activation rows -> split-packed rows (woft_conv_params.in_fmt): group of 4 channels -> [hi[0..3] | lo[0..3]] ----
+template <int TERMS>
+__global__ void pack_split_kernel(const float* __restrict__ x, int64_t rows, int32_t c4, int32_t ldx, float* __restrict__ out,
+                                  int32_t ldo) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * c4) return;
+    const int64_t r = i / c4;
+    const int g = (int)(i - r * c4);
+    *(f32x4*)(out + r * ldo + 4 * g) = pack_split<TERMS>(*(const f32x4*)(x + r * ldx + 4 * g));
+}
 
 // ---- uint8 BGR HWC -> normalised RGB NHWC4 with replicate padding ------------------------------
 __global__ void preprocess_kernel(const uint8_t* __restrict__ img, int h, int w, float* __restrict__ out,
@@ -324,5 +336,19 @@ extern "C" int woft_feature_pyramid(const float* in, int32_t h, int32_t w, int32
     const dim3 grid((unsigned)(((h + 7) / 8) * ((w + 7) / 8)));
     if (terms == 3) hipLaunchKernelGGL(feature_pyramid_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(feature_pyramid_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    return woft_launch_status();
+}
+
+extern "C" int woft_pack_split(const float* x, int64_t rows, int32_t channels, int32_t ldx, int32_t precision, float* out,
+                               int32_t ldo, void* stream) {
+    if (!x || !out || rows <= 0 || channels <= 0 || channels % 4 != 0 || ldx % 4 != 0 || ldo % 4 != 0 || ldx < channels ||
+        ldo < channels || precision < 1 || precision > 3)
+        return WOFT_EINVAL;
+    const int64_t n = rows * (channels / 4);
+    const dim3 grid((unsigned)ceil_div64(n, 256));
+    hipStream_t s = (hipStream_t)stream;
+    if (precision == 1) hipLaunchKernelGGL(pack_split_kernel<3>, grid, dim3(256), 0, s, x, rows, channels / 4, ldx, out, ldo);
+    else if (precision == 3) hipLaunchKernelGGL(pack_split_kernel<16>, grid, dim3(256), 0, s, x, rows, channels / 4, ldx, out, ldo);
+    else hipLaunchKernelGGL(pack_split_kernel<1>, grid, dim3(256), 0, s, x, rows, channels / 4, ldx, out, ldo);
     return woft_launch_status();
 }

@@ -451,6 +451,17 @@ extern "C" int woft_gru_halfstep(const woft_conv_params* zr, const woft_conv_par
     if (a.e0 == nullptr || b.e0 != a.e0 || a.lde0 % 4 != 0 || b.lde0 != a.lde0 || a.e0 != a.in0 || b.out == nullptr || b.ldo % 4 != 0 ||
         b.co_off % 4 != 0 || a.flat || b.flat || a.in_norm || b.in_norm || a.stat_sum != nullptr || b.stat_sum != nullptr)
         return WOFT_EINVAL;
+    if (a.in_fmt != 0 || b.in_fmt != 0 || a.out_fmt != 0 || b.out_fmt != 0 || b.out1 != nullptr) return WOFT_EINVAL;   // (fp32 activations only)
+    // The new state must not overwrite the old one: other workgroups still read h on their tiles' 1x5 / 5x1 halos (and z|r's e0)
+    // while this one stores -- an in-place call would race silently
+    {
+        const int64_t px = (int64_t)a.h * a.w;
+        const char* h0 = (const char*)a.in0;
+        const char* h1 = h0 + (size_t)(px * a.cs0) * sizeof(float);
+        const char* o0 = (const char*)(b.out + b.co_off);
+        const char* o1 = o0 + (size_t)((px - 1) * b.ldo + b.cout) * sizeof(float);
+        if (o0 < h1 && h0 < o1) return WOFT_EINVAL;
+    }
     const int64_t cs_max = a.cs1 > a.cs0 ? a.cs1 : a.cs0;
     if ((int64_t)a.h * a.w * cs_max >= (1ll << 31)) return WOFT_EINVAL;                     // 32-bit element offsets
     dim3 grid((unsigned)(((a.h + 7) / 8) * ((a.w + 15) / 16)));

@@ -44,18 +44,32 @@ class Act:
         return self.t[:, :self.c].reshape(self.n, self.h, self.w, self.c).permute(0, 3, 1, 2).contiguous()
 
 
+def _rows_with_zero_row(n_pix, cs, zero):
+    """(n_pix, cs) fp32 view of a buffer with ONE more pixel row, which is zero and never written: the LDS-halo loader of the
+    register-streamed conv kernel points the out-of-image taps of a split-packed input there (woft_conv_params.in_fmt) instead
+    of selecting zeros per element."""
+    buf = (torch.zeros if zero else torch.empty)(n_pix + 1, cs, dtype=torch.float32, device=DEV)
+    if not zero:
+        buf[n_pix].zero_()
+    return buf[:n_pix]
+
+
+def has_zero_row(t):
+    """True when the tensor's storage extends one pixel row past its last row (what _rows_with_zero_row allocates)."""
+    return t.untyped_storage().nbytes() >= 4 * (t.storage_offset() + (t.shape[0] + 1) * t.stride(0))
+
+
 def act_from_nchw(x, cs=None):
     n, c, h, w = x.shape
     cs = cs or _round_up(c, 4)
-    t = torch.zeros(n * h * w, cs, dtype=torch.float32, device=DEV)
+    t = _rows_with_zero_row(n * h * w, cs, True)
     t[:, :c] = x.to(DEV).permute(0, 2, 3, 1).reshape(n * h * w, c)
     return Act(t, n, h, w, c)
 
 
 def new_act(n, h, w, c, cs=None, zero=False):
     cs = cs or _round_up(c, 4)
-    f = torch.zeros if zero else torch.empty
-    return Act(f(n * h * w, cs, dtype=torch.float32, device=DEV), n, h, w, c)
+    return Act(_rows_with_zero_row(n * h * w, cs, zero), n, h, w, c)
 
 
 # ------------------------------------------------------------------------------------------
@@ -199,12 +213,15 @@ def pick_tiles(m, cout_pad):
 # ------------------------------------------------------------------------------------------
 def conv_params(x, pc, out, co_off=0, epi=_lib.EPI_LINEAR, x2=None, c_split=0, e0=None, e1=None, out1=None,
                 split=0, alpha=1.0, stats=None, ho=None, wo=None, tiles=None, cout=None, precision=0, halo=None,
-                in_norm=0, in_stats=None, bias_map=None, x2_off=0, wh0=None):
+                in_norm=0, in_stats=None, bias_map=None, x2_off=0, wh0=None, in_fmt=0, out_fmt=0):
     """Build (and keep alive) a woft_conv_params for `out[:, co_off:co_off+cout] = epi(conv(x))`.
     in_norm = 1 / 2 with in_stats = (mean, rstd): x is a RAW conv output, InstanceNorm (2: + ReLU) applied while
     loading -- LDS-halo kernel only (check p.halo on the result; the caller falls back to woft_inorm_apply).
     wh0 = (lookup Act, mean, fragments (pack_wh0_frags), bias, index | None): the weight head's first conv is
-    evaluated inside this launch from the lookup windows and x is not read (whole-window kernel only: p.halo == 2)."""
+    evaluated inside this launch from the lookup windows and x is not read (whole-window kernel only: p.halo == 2).
+    in_fmt / out_fmt: split-packed activations (woft_conv_params.in_fmt / out_fmt: bit 0 = x / out, bit 1 = x2 / out1 hold the
+    MFMA operand form [hi | lo] of every 4-channel group instead of fp32 values).  Inputs: the per-tap kernel and the
+    register-streamed kernel only -- ValueError when this layer selects another one."""
     if ho is None or wo is None:
         ho, wo = pc.out_hw(x.h, x.w)
     p = ConvParams()
@@ -326,6 +343,14 @@ def conv_params(x, pc, out, co_off=0, epi=_lib.EPI_LINEAR, x2=None, c_split=0, e
         if p.tile_n == 128 and pc.cout_pad % 128 != 0:
             p.tile_n = 64
         p.cout_pad = pc.cout_pad if stats is not None else _round_up(p.cout, p.tile_n)
+    p.in_fmt, p.out_fmt = int(in_fmt), int(out_fmt)
+    if p.in_fmt and (p.precision == 0 or halo not in (0, 8, 12) or pc.flat or in_norm):
+        raise ValueError(f"split-packed input: not supported by the kernel this layer selects (halo {halo})")
+    if p.in_fmt and halo in (8, 12) and p.in_fmt != (3 if x2 is not None else 1):
+        raise ValueError("split-packed input: both sources or neither on the register-streamed kernel")
+    if p.in_fmt and halo in (8, 12) and not (has_zero_row(x.t) and (x2 is None or has_zero_row(x2.t))):
+        raise ValueError("split-packed input of the register-streamed kernel: the tensor must be followed by one zero pixel row "
+                         "(ops.new_act / act_from_nchw allocate it)")
     p.bias_map, p.ld_bias_map = (ptr(bias_map.t), bias_map.cs) if bias_map is not None else (None, 0)
     p.in_norm, p.in_mean, p.in_rstd = 0, None, None
     if in_norm and halo in (1, 4, 8) and (pc.taps_y, pc.taps_x) == (3, 3):   # (instantiated for the 3x3 pixel tiles)
@@ -408,6 +433,8 @@ def pair_ok(a, b):
         return False
     if a.halo == 0:
         return True
+    if bool(a.in_fmt) != bool(b.in_fmt):                     # (the input format is a compile-time property of the instance)
+        return False
     return a.halo in (8, 12) and (a.taps_y, a.taps_x) == (b.taps_y, b.taps_x) and a.taps_y * a.taps_x > 1
 
 
@@ -416,7 +443,15 @@ def gru_ok(zr, q):
     return (zr.precision in (1, 2, 3) and q.precision == zr.precision and (zr.taps_y, zr.taps_x) in ((1, 5), (5, 1))
             and (q.taps_y, q.taps_x) == (zr.taps_y, zr.taps_x) and zr.n_img == 1 and zr.cin_pad == 256 == q.cin_pad
             and zr.c_split == 128 == q.c_split and zr.cout == 256 and q.cout == 128 and bool(zr.wgt_frag) and bool(q.wgt_frag)
-            and bool(zr.bias_map) and bool(q.bias_map) and bool(zr.in1) and zr.in1 == q.in1 and zr.e0 == zr.in0 == q.e0)
+            and bool(zr.bias_map) and bool(q.bias_map) and bool(zr.in1) and zr.in1 == q.in1 and zr.e0 == zr.in0 == q.e0
+            and not (zr.in_fmt or zr.out_fmt or q.in_fmt or q.out_fmt))
+
+
+def pack_split(x, out, precision, channels=None):
+    """fp32 activation rows x (tensor [rows][ld]) -> split-packed rows (woft_pack_split); in place when out is x."""
+    c = channels or x.shape[1]
+    check(_lib.load().woft_pack_split(ptr(x), x.shape[0], c, x.stride(0), PRECISION.get(precision, precision), ptr(out),
+                                      out.stride(0), stream_ptr()), "woft_pack_split")
 
 
 def run_gru_halfstep(zr, q):

@@ -21,6 +21,7 @@ template's feature / context tensors are computed once (the flow provider pins t
 """
 import logging
 import os
+import time
 from inspect import signature
 from types import SimpleNamespace
 
@@ -115,6 +116,7 @@ class YAOFTrackerSingleControl:
         self._sparse_weights = False
         self._replay = None
         self._upload = _FrameUploader()
+        self.host_wait_s = 0.0       # seconds this tracker's thread spent blocked on the per-flow result read (device back end)
 
     # ---- which solver back end ------------------------------------------------------------------
     def _fused_specs(self):
@@ -354,7 +356,9 @@ class YAOFTrackerSingleControl:
         host = self._host_res
         host.copy_(res, non_blocking=True)
         self._host_ev.record()
+        t0 = time.perf_counter()
         self._host_ev.synchronize()
+        self.host_wait_s += time.perf_counter() - t0      # (bench: wall time minus this = the launch loop's host time per frame)
         ih = host.view(torch.int32)
         if int(ih[10]) == 1:
             raise AssertionError(torch.Size([1, int(ih[12]), 2]))    # least_squares_H.py:162 (fewer than 4 points)
