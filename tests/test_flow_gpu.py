@@ -545,11 +545,11 @@ def test_config1_small_480x640_vs_reference(golden_dir, precision, epe_mean, epe
 
 @torch.no_grad()
 @pytest.mark.parametrize("precision", ["bf16x3", "bf16", "fp16"])
-@pytest.mark.parametrize("h,w", [(136, 200), (64, 72)])
+@pytest.mark.parametrize("h,w", [(136, 200), (72, 136)])
 def test_split_packed_update_block_is_bit_identical(monkeypatch, precision, h, w):
     """The update block on split-packed activations (engine.PACKED_ACTS: producers' epilogues write the MFMA operand form,
     consumers copy) gives bit-identical flows and weights to fp32 activations -- the same hi / lo values reach the matrix
-    cores.  64 x 72: an 8 x 9 feature map, where the 3x3 layers run on the per-tap kernel (its packed-input path)."""
+    cores.  (Opt-in, WOFT_PACKED=1: measured neutral to -1.5 % frames/s)"""
     from woft_amd import engine
     sd = synth.make_state_dict(seed=21)
     a = synth.make_template(h, w, seq_id=6)

@@ -1,0 +1,174 @@
+// Probe for DESIGN section 7, item 0b: an fp32-emulating product in TWO matrix-pipe passes instead of three --
+//     a * w  ~=  fp16(a) * fp16(w)  +  mx8(la) * mx8(w)  +  mx8(a) * mx8(lw),     la = a - fp16(a), lw = w - fp16(w)
+// main term on v_mfma_f32_32x32x16_f16 (bf16's rate), the two small cross terms on the block-scaled MX-fp8 form
+// v_mfma_scale_f32_32x32x64_f8f6f4 (twice the rate; one E8M0 scale per lane = per row and 32-K block).
+//   part 1: numerics on the hardware -- C = A B^T (32 x 32, K = 64 n) by bf16x3 (the shipped scheme) and by the 2-pass scheme,
+//           both against fp64 on the host (this also pins the MX operand layout assumed here: lane l holds row l & 31,
+//           K = 32 (l >> 5) .. + 31, scale in byte 0 of the scale operand);
+//   part 2: matrix-pipe time of the two instruction mixes, 2 waves per SIMD on every CU.
+// Build: hipcc --offload-arch=gfx950 -O3 -o tools/micro/mx_split_probe.bin tools/micro/mx_split_probe.hip ; run on the GPU box.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float bf16_round(float x) { return (float)(__bf16)x; }
+
+// 32 fp32 values of one (row, 32-K block) -> 32 fp8 e4m3 bytes + the block's E8M0 scale (value = 2^(scale - 127))
+__device__ __forceinline__ void mx8_quantise(const float* v, i32x8& q, int& scale) {
+    float amax = 0.f;
+    for (int e = 0; e < 32; ++e) amax = fmaxf(amax, fabsf(v[e]));
+    int ex = 0;
+    if (amax > 0.f) { frexpf(amax, &ex); ex -= 1; }          // amax = m * 2^ex, m in [1, 2)
+    const int se = (amax > 0.f) ? ex - 7 : -127;            // scaled block maximum in [128, 256) <= 448 (e4m3's largest)
+    scale = se + 127;
+    const float inv = ldexpf(1.0f, -se);
+    for (int e = 0; e < 32; e += 4) {
+        int w = 0;
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(v[e] * inv, v[e + 1] * inv, w, false);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(v[e + 2] * inv, v[e + 3] * inv, w, true);
+        q[e / 4] = w;
+    }
+}
+
+__global__ void numerics_kernel(const float* __restrict__ A, const float* __restrict__ B, int K, float* __restrict__ c3,
+                                float* __restrict__ c2) {
+    const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
+    f32x16 acc3, acc2;
+    for (int i = 0; i < 16; ++i) acc3[i] = acc2[i] = 0.f;
+    for (int k0 = 0; k0 < K; k0 += 64) {
+        // ---- 16-K steps: bf16x3 and the fp16 main term
+        for (int s = 0; s < 4; ++s) {
+            bf16x8 ah, al, bh, bl;
+            f16x8 af, bf;
+            for (int e = 0; e < 8; ++e) {
+                const float a = A[r * K + k0 + 16 * s + 8 * hh + e], b = B[r * K + k0 + 16 * s + 8 * hh + e];
+                ah[e] = (__bf16)a; al[e] = (__bf16)(a - (float)ah[e]);
+                bh[e] = (__bf16)b; bl[e] = (__bf16)(b - (float)bh[e]);
+                af[e] = (_Float16)a; bf[e] = (_Float16)b;
+            }
+            acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc3, 0, 0, 0);
+            acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc3, 0, 0, 0);
+            acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc3, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc2, 0, 0, 0);
+        }
+        // ---- one 64-K step: the two cross terms, block-scaled fp8
+        float a[32], la[32], b[32], lb[32];
+        for (int e = 0; e < 32; ++e) {
+            a[e] = A[r * K + k0 + 32 * hh + e];
+            b[e] = B[r * K + k0 + 32 * hh + e];
+            la[e] = a[e] - (float)(_Float16)a[e];
+            lb[e] = b[e] - (float)(_Float16)b[e];
+        }
+        i32x8 qa, qla, qb, qlb;
+        int sa, sla, sb, slb;
+        mx8_quantise(a, qa, sa); mx8_quantise(la, qla, sla); mx8_quantise(b, qb, sb); mx8_quantise(lb, qlb, slb);
+        acc2 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(qla, qb, acc2, 0, 0, 0, sla, 0, sb);
+        acc2 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(qa, qlb, acc2, 0, 0, 0, sa, 0, slb);
+    }
+    for (int i = 0; i < 16; ++i) {
+        const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
+        c3[row * 32 + r] = acc3[i];
+        c2[row * 32 + r] = acc2[i];
+    }
+}
+
+// matrix-pipe time: per "K = 64 block of products" 12 bf16 MFMAs (bf16x3) vs 4 f16 + 2 MX-fp8 MFMAs, two accumulators
+template <int MODE>
+__global__ __launch_bounds__(512) void rate_kernel(int iters, float* out) {
+    f32x16 acc0, acc1;
+    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 1.f; }
+    bf16x8 a, b;
+    f16x8 af, bf;
+    i32x8 qa, qb;
+    for (int e = 0; e < 8; ++e) {
+        a[e] = (__bf16)(0.001f * (threadIdx.x + e)); b[e] = (__bf16)(0.002f * e);
+        af[e] = (_Float16)(0.001f * (threadIdx.x + e)); bf[e] = (_Float16)(0.002f * e);
+        qa[e] = 0x38383838 + threadIdx.x; qb[e] = 0x30303030 + e;
+    }
+    const int sc = 127;
+    for (int it = 0; it < iters; ++it) {
+        if (MODE == 0) {
+#pragma unroll
+            for (int s = 0; s < 6; ++s) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc1, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc1, 0, 0, 0);
+            }
+            acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(qa, qb, acc0, 0, 0, 0, sc, 0, sc);
+            acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(qa, qb, acc1, 0, 0, 0, sc, 0, sc);
+        }
+    }
+    float s = 0.f;
+    for (int i = 0; i < 16; ++i) s += acc0[i] + acc1[i];
+    if (s == 12345.678f) out[0] = s;                     // (keeps the loop)
+}
+
+int main() {
+    for (int K : {64, 576, 2304}) {
+        std::vector<float> A(32 * K), B(32 * K);
+        srand(1);
+        auto rnd = [] { return (float)rand() / RAND_MAX * 2.f - 1.f; };
+        for (int i = 0; i < 32; ++i) {
+            const float amp = 0.05f + 3.f * (float)rand() / RAND_MAX;
+            for (int k = 0; k < K; ++k) {
+                const float g = rnd() + rnd() + rnd();
+                A[i * K + k] = amp * fmaxf(g, 0.f);                       // ReLU-like activations, per-row amplitude
+                B[i * K + k] = (rnd() + rnd() + rnd()) / sqrtf((float)K);  // weights
+            }
+        }
+        float *dA, *dB, *d3, *d2;
+        hipMalloc(&dA, A.size() * 4); hipMalloc(&dB, B.size() * 4); hipMalloc(&d3, 4096); hipMalloc(&d2, 4096);
+        hipMemcpy(dA, A.data(), A.size() * 4, hipMemcpyHostToDevice);
+        hipMemcpy(dB, B.data(), B.size() * 4, hipMemcpyHostToDevice);
+        hipLaunchKernelGGL(numerics_kernel, dim3(1), dim3(64), 0, 0, dA, dB, K, d3, d2);
+        std::vector<float> c3(1024), c2(1024);
+        hipMemcpy(c3.data(), d3, 4096, hipMemcpyDeviceToHost);
+        hipMemcpy(c2.data(), d2, 4096, hipMemcpyDeviceToHost);
+        double e3 = 0, e2 = 0, m3 = 0, m2 = 0;
+        for (int i = 0; i < 32; ++i)
+            for (int j = 0; j < 32; ++j) {
+                double ex = 0, nm = 0;
+                for (int k = 0; k < K; ++k) { ex += (double)A[i * K + k] * B[j * K + k]; nm += fabs((double)A[i * K + k] * B[j * K + k]); }
+                const double r3 = (c3[i * 32 + j] - ex) / nm, r2 = (c2[i * 32 + j] - ex) / nm;
+                e3 += r3 * r3; e2 += r2 * r2; m3 = fmax(m3, fabs(r3)); m2 = fmax(m2, fabs(r2));
+            }
+        printf("K = %4d: error / sum|a||w|  bf16x3 (3 passes) rms %.2e max %.2e | fp16 + 2 x MX-fp8 (2 passes) rms %.2e max %.2e  (x%.1f)\n", K,
+               sqrt(e3 / 1024), m3, sqrt(e2 / 1024), m2, sqrt(e2 / e3));
+        hipFree(dA); hipFree(dB); hipFree(d3); hipFree(d2);
+    }
+    float* dout;
+    hipMalloc(&dout, 4);
+    hipEvent_t t0, t1;
+    hipEventCreate(&t0); hipEventCreate(&t1);
+    const int iters = 20000;
+    for (int mode = 0; mode < 2; ++mode) {
+        float best = 1e9f;
+        for (int rep = 0; rep < 3; ++rep) {
+            hipEventRecord(t0);
+            if (mode == 0) hipLaunchKernelGGL(rate_kernel<0>, dim3(256), dim3(512), 0, 0, iters, dout);
+            else hipLaunchKernelGGL(rate_kernel<1>, dim3(256), dim3(512), 0, 0, iters, dout);
+            hipEventRecord(t1);
+            hipEventSynchronize(t1);
+            float ms; hipEventElapsedTime(&ms, t0, t1);
+            best = fminf(best, ms);
+        }
+        // products per iteration and wave: 2 accumulators x 32 x 32 x 64 K
+        const double prod = 2.0 * 32 * 32 * 64 * iters * 256.0 * 8;
+        printf("%s: %.2f ms for %d x (2 x 32x32x64 products) on 256 x 8 waves -> %.0f T fp32-emulating FMA/s (= %.0f TFLOP/s of products)\n",
+               mode == 0 ? "bf16x3, 12 bf16 MFMAs        " : "fp16 x 4 + MX-fp8 x 2 MFMAs  ", best, iters, prod / best * 1e-9, 2 * prod / best * 1e-9);
+    }
+    return 0;
+}

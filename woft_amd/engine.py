@@ -45,8 +45,12 @@ GRU_FUSE = os.environ.get("WOFT_GRU_FUSE", "0")          # "1": always, "auto": 
 # Split-packed activations in the update block (round 4; full model, split-bf16 / fp16 precisions): every activation that only
 # convolutions read (motion-encoder layers, r*h, the motion features; the GRU state additionally as a packed copy) is written by
 # its producer's epilogue in MFMA operand form -- [hi | lo] per 4-channel group, woft_conv_params.out_fmt -- and the consumers'
-# loaders copy instead of converting (in_fmt).  Same hi / lo values reach the matrix cores: bit-identical flows (0: fp32 activations)
-PACKED_ACTS = os.environ.get("WOFT_PACKED", "1") != "0"
+# loaders copy instead of converting (in_fmt).  Same hi / lo values reach the matrix cores: bit-identical flows (tested).
+# OPT-IN (WOFT_PACKED=1): it removes 80 % of the vector instructions of the conv main loops (134 -> 26 per 108 MFMAs, ISA) and
+# changes NO launch time -- per-layer times equal within noise, frames/s 0 ... -1.5 % (the epilogues' conversions, the state's second
+# store) in three A/B runs: the main loops are bound by the matrix pipe that the two resident waves of a SIMD share, not by vector
+# issue.
+PACKED_ACTS = os.environ.get("WOFT_PACKED", "0") != "0"
 
 
 def _ru(x, m):
