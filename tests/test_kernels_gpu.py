@@ -1307,3 +1307,43 @@ def test_gru_half_step_split_packed(ops, kh, kw, precision):
     assert ops._lib.load().woft_conv2d(bad, ops.stream_ptr()) != 0
     with pytest.raises(ValueError):            # (a tensor without the zero pixel row behind it)
         ops.conv_params(ops.Act(torch.zeros_like(hp.t), n, h, w, 128), pzr, z1, x2=xp, out1=rh1, in_fmt=3, **kw_zr)
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("kh,kw,h,w", [(1, 5, 18, 22), (5, 1, 18, 22), (1, 5, 8, 9), (5, 1, 8, 9), (3, 3, 5, 7)])
+def test_gru_convs_on_the_per_tap_kernel(ops, kh, kw, h, w, precision):
+    """The GRU's two-source convs with their gate epilogues on the PER-TAP kernel (halo 0) -- the kernel they fall back to on
+    feature maps too small for the pixel-tile kernels -- against torch fp32, and against the pixel-tile kernel where that one
+    exists (18 x 22)."""
+    E = ops._lib
+    n = 1
+    hprev = torch.tanh(_rand(n, 128, h, w, seed=4))
+    xin = _rand(n, 128, h, w, seed=5)
+    mk = lambda s: (_rand(128, 256, kh, kw, seed=s, scale=1 / math.sqrt(256 * kh * kw)), _rand(128, seed=s + 50, scale=0.1))
+    (wz, bz), (wr, br), (wq, bq) = mk(6), mk(7), mk(8)
+    pad = (kh // 2, kw // 2)
+    hx = torch.cat([hprev, xin], 1)
+    z = torch.sigmoid(F.conv2d(hx, wz, bz, padding=pad))
+    r = torch.sigmoid(F.conv2d(hx, wr, br, padding=pad))
+    q = torch.tanh(F.conv2d(torch.cat([r * hprev, xin], 1), wq, bq, padding=pad))
+    ref = (1 - z) * hprev + z * q
+    pzr = ops.pack_conv(torch.cat([wz, wr], 0), torch.cat([bz, br], 0), padding=pad)
+    pq = ops.pack_conv(wq, bq, padding=pad)
+    ha, xa = ops.act_from_nchw(hprev), ops.act_from_nchw(xin)
+    outs = {}
+    for halo in (0, 8) if (h >= 8 and w >= 16) else (0,):
+        zb, rh, hn = (ops.new_act(n, h, w, 128, zero=True) for _ in range(3))
+        a = ops.conv_params(ha, pzr, zb, x2=xa, c_split=128, epi=E.EPI_GRU_ZR, split=128, e0=ha, out1=rh, precision=precision,
+                            halo=halo)
+        b = ops.conv_params(rh, pq, hn, x2=xa, c_split=128, epi=E.EPI_GRU_Q, e0=ha, e1=zb, precision=precision, halo=halo)
+        assert a.halo == halo and b.halo == halo
+        ops.run_conv(a)
+        ops.run_conv(b)
+        torch.cuda.synchronize()
+        outs[halo] = (zb.t.clone(), rh.t.clone(), hn.t.clone())
+    tol = 8e-5 if precision == "bf16x3" else 3e-2
+    _close(ops.Act(outs[0][0], n, h, w, 128).nchw(), z, tol, what="z")
+    _close(ops.Act(outs[0][2], n, h, w, 128).nchw(), ref, tol, what="h")
+    if 8 in outs:        # (different accumulation order -- tap-major vs chunk-major K steps: close, not bit-identical)
+        for u, v_ in zip(outs[0], outs[8]):
+            _close(u, v_, tol, what="per-tap vs pixel-tile kernel")

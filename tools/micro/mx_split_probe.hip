@@ -3,8 +3,7 @@
 // main term on v_mfma_f32_32x32x16_f16 (bf16's rate), the two small cross terms on the block-scaled MX-fp8 form
 // v_mfma_scale_f32_32x32x64_f8f6f4 (twice the rate; one E8M0 scale per lane = per row and 32-K block).
 //   part 1: numerics on the hardware -- C = A B^T (32 x 32, K = 64 n) by bf16x3 (the shipped scheme) and by the 2-pass scheme,
-//           both against fp64 on the host (this also pins the MX operand layout assumed here: lane l holds row l & 31,
-//           K = 32 (l >> 5) .. + 31, scale in byte 0 of the scale operand);
+//           both against fp64 on the host (MX operand convention: tools/micro/mx_layout_probe.hip);
 //   part 2: matrix-pipe time of the two instruction mixes, 2 waves per SIMD on every CU.
 // Build: hipcc --offload-arch=gfx950 -O3 -o tools/micro/mx_split_probe.bin tools/micro/mx_split_probe.hip ; run on the GPU box.
 #include <hip/hip_runtime.h>
@@ -59,17 +58,30 @@ __global__ void numerics_kernel(const float* __restrict__ A, const float* __rest
             acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc3, 0, 0, 0);
             acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc2, 0, 0, 0);
         }
-        // ---- one 64-K step: the two cross terms, block-scaled fp8
-        float a[32], la[32], b[32], lb[32];
-        for (int e = 0; e < 32; ++e) {
-            a[e] = A[r * K + k0 + 32 * hh + e];
-            b[e] = B[r * K + k0 + 32 * hh + e];
-            la[e] = a[e] - (float)(_Float16)a[e];
-            lb[e] = b[e] - (float)(_Float16)b[e];
-        }
+        // ---- one 64-K step: the two cross terms, block-scaled fp8.  Operand convention pinned by tools/micro/mx_layout_probe.hip:
+        // MX block b (32 K) = bytes 16 b .. 16 b + 15 of BOTH lane halves of a row (lane half hh holds K 16 hh .. 16 hh + 15 of the
+        // block), and the block's scale is the scale operand of lane half hh = b.
+        float a[64], b[64];
+        for (int e = 0; e < 64; ++e) { a[e] = A[r * K + k0 + e]; b[e] = B[r * K + k0 + e]; }
         i32x8 qa, qla, qb, qlb;
-        int sa, sla, sb, slb;
-        mx8_quantise(a, qa, sa); mx8_quantise(la, qla, sla); mx8_quantise(b, qb, sb); mx8_quantise(lb, qlb, slb);
+        int sa = 0, sla = 0, sb = 0, slb = 0;
+        for (int blk = 0; blk < 2; ++blk) {
+            float va[32], vla[32], vb[32], vlb[32];
+            for (int e = 0; e < 32; ++e) {
+                va[e] = a[32 * blk + e]; vb[e] = b[32 * blk + e];
+                vla[e] = va[e] - (float)(_Float16)va[e];
+                vlb[e] = vb[e] - (float)(_Float16)vb[e];
+            }
+            i32x8 ta, tla, tb, tlb;
+            int s0, s1, s2, s3;
+            mx8_quantise(va, ta, s0); mx8_quantise(vla, tla, s1); mx8_quantise(vb, tb, s2); mx8_quantise(vlb, tlb, s3);
+            // this lane keeps elements 16 hh .. 16 hh + 15 of the block (4 dwords) in dwords 4 blk .. 4 blk + 3
+            for (int d = 0; d < 4; ++d) {
+                qa[4 * blk + d] = hh ? ta[4 + d] : ta[d];   qla[4 * blk + d] = hh ? tla[4 + d] : tla[d];
+                qb[4 * blk + d] = hh ? tb[4 + d] : tb[d];   qlb[4 * blk + d] = hh ? tlb[4 + d] : tlb[d];
+            }
+            if (hh == blk) { sa = s0; sla = s1; sb = s2; slb = s3; }
+        }
         acc2 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(qla, qb, acc2, 0, 0, 0, sla, 0, sb);
         acc2 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(qa, qlb, acc2, 0, 0, 0, sa, 0, slb);
     }

@@ -225,6 +225,11 @@ class _Plan:
         assert hp % 8 == 0 and wp % 8 == 0
         self.eng, self.hp, self.wp = eng, hp, wp
         self.prec = eng.precision
+        if eng.precision != "fp32" and (hp // 8 < 8 or wp // 8 < 16) and os.environ.get("WOFT_ALLOW_SMALL") != "1":
+            # Known limit (round 4, tools/micro/dbg_small_flow.py): below 8 x 16 feature pixels the GRU's two-source 1x5 / 5x1 convs
+            # fall back from the pixel-tile kernels to the per-tap kernel, which faults there (seen at 64 x 72: 8 x 9).  A clean
+            # error instead of a GPU memory fault; the exact-fp32 precision has its own kernel and no such limit.
+            raise ValueError(f"inputs smaller than 64 x 128 pixels ({hp} x {wp}) need precision='fp32' on this path")
         self.source_tag = None
         self.lookup_events = None
         self.wh_events = None      # bench hook: list collecting (start, end) HIP events per lookup launch
