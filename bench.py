@@ -40,7 +40,7 @@ CLIP = 48      # frames per clip of the synthetic sequence
 # flow EPE of the GPU path against the oracle, (mean, max) px at 12 iterations.  fp32 and the fp32-emulating
 # bf16x3 share the GPU-fp32 budget; bf16: 0.05 px mean (max: the bf16 tests' 0.25 px); fp16 (mixed_precision scoping):
 # the tested budgets of tests/test_flow_gpu.py
-EPE_BUDGET = {"fp32": (1e-3, 1e-2), "bf16x3": (1e-3, 1e-2), "bf16": (0.05, 0.25), "fp16": (0.01, 0.05)}
+EPE_BUDGET = {"fp32": (1e-3, 1e-2), "bf16x3": (1e-3, 1e-2), "bf16": (0.05, 0.25), "fp16": (0.01, 0.05), "f16mx8": (1e-3, 1e-2)}
 
 
 def restart_clip(tracker):
@@ -110,7 +110,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--iters", type=int, default=12)
-    ap.add_argument("--precision", default=None, choices=["fp32", "bf16x3", "bf16", "fp16"],
+    ap.add_argument("--precision", default=None, choices=["fp32", "bf16x3", "bf16", "fp16", "f16mx8"],
                     help="conv / correlation-GEMM arithmetic: exact fp32 MFMA, split-bf16 (fp32-emulating), bf16, fp16 scoping. "
                          "Default: whatever the SHIPPED flow config selects (pytracking/optical_flow/configs/"
                          "v2_SNOB_large_g05_RAFT.py: the configuration a drop-in user runs) -- reported as config.precision_source")
@@ -247,7 +247,8 @@ def main():
     peak_gb = torch.cuda.max_memory_allocated() / 2 ** 30        # every device buffer of the path is a torch tensor
 
     mask_region = not args.full_weight_head
-    terms = {"fp32": 1, "bf16x3": 3, "bf16": 1, "fp16": 1}[args.precision]
+    # (matrix-pipe passes per product, in units of one bf16 MFMA pass: f16mx8 = 1 fp16 pass + 2 block-scaled fp8 passes at twice the rate)
+    terms = {"fp32": 1, "bf16x3": 3, "bf16": 1, "fp16": 1, "f16mx8": 2}[args.precision]
     mfma_peak = 157.3 if args.precision == "fp32" else 2500.0      # TFLOP/s dense: f32-input MFMA / bf16 MFMA (MI355X_MICROARCH.md)
 
     def lookup_roofline(evs, P, storage="fp32"):
@@ -349,7 +350,9 @@ def main():
         "dtype": {"fp32": "f32", "bf16x3": "bf16x3 (split-bf16 MFMA operands emulating fp32, fp32 accumulate)",
                   "bf16": "bf16 (fp32 accumulate)",
                   "fp16": "fp16 convolutions (fp32 accumulate) in the encoders and the update block, bf16x3 correlation and "
-                          "weight head: the reference's mixed_precision scoping"}[args.precision], "data": "synthetic",
+                          "weight head: the reference's mixed_precision scoping",
+                  "f16mx8": "fp16 x fp16 + two block-scaled fp8 cross terms per product (fp32-emulating in 2 matrix-pipe passes, fp32 "
+                            "accumulate) in the update block's convolutions; bf16x3 elsewhere"}[args.precision], "data": "synthetic",
         "config": {"workload": f"{H}x{W} synthetic sequence per GPU ({CLIP}-frame clips): WeightedRAFT-full {args.iters} iters + "
                                + ("weighted LSq homography on Sobol-500 correspondences (reference default config WOFT.py)"
                                 if args.tracker_config == "WOFT" else
@@ -448,7 +451,7 @@ def main():
         # the other arithmetic modes on the same sequence, each its own engine + buffers.  The STRICT fp32 operating
         # point (exact fp32 MFMA products, all-pairs volume: the reference's precision class) runs the full K steps.
         alt = {}
-        for prec in ("fp32", "bf16x3", "bf16", "fp16"):
+        for prec in ("fp32", "bf16x3", "bf16", "fp16", "f16mx8"):
             if prec == args.precision:
                 continue
             r, trk, pl, _ = side_run(K2 if prec == "fp32" else min(K, 8), precision=prec)

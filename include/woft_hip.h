@@ -75,7 +75,7 @@ typedef struct woft_conv_params {
     const float* wgt;      /* [cout_pad][taps_y*taps_x*cin_pad] fp32, K contiguous (precision 0) */
     const void* wgt_hi;    /* same shape, bf16: hi = bf16(w)          (precision 1, 2); fp16(w) (precision 3) */
     const void* wgt_lo;    /* same shape, bf16: lo = bf16(w - hi)     (precision 1)            */
-    int32_t precision;     /* 0: fp32 MFMA; 1: split-bf16 x3 (fp32-emulating); 2: bf16; 3: fp16 operands, fp32
+    int32_t precision;     /* (4: see wgt_mx)  0: fp32 MFMA; 1: split-bf16 x3 (fp32-emulating); 2: bf16; 3: fp16 operands, fp32
                               accumulation (the reference's mixed_precision autocast, weighted_raft.py:204,215,233;
                               not for the 9 x 9 weight-head windows, which the reference keeps in fp32)   */
     const float* bias;     /* [cout_pad] or NULL                                               */
@@ -158,6 +158,16 @@ typedef struct woft_conv_params {
                 a split-packed COPY of the new state (out keeps the fp32 state the next gates read).
        Results are bit-identical to the fp32-activation path (same hi / lo values reach the matrix cores). */
     int32_t in_fmt, out_fmt;
+    /* precision 4 ("f16mx8", round 4; halo 8 / 12 with 3x3 / 1x5 / 5x1 taps only): an fp32-emulating product in two matrix-pipe
+       passes -- fp16(a) * fp16(w) on v_mfma_f32_32x32x16_f16 + the two cross terms (a - fp16(a)) * w and a * (w - fp16(w)) on the
+       block-scaled fp8 form v_mfma_scale_f32_32x32x64_f8f6f4, one scaled MFMA per PAIR of taps (K = 2 taps x 32 channels; an odd
+       last tap pairs with zero weights).  wgt_frag: the fp16 fragments (the precision-3 format).  wgt_mx: per 32-column band, 32-
+       channel chunk, tap pair and term (0: w, multiplied with the activations' remainder; 1: w - fp16(w), multiplied with the
+       activations): 64 lanes x 32 bytes fp8 e4m3 (lane L: column 32 band + L % 32; bytes 0-15 = channels 16 (L / 32) .. + 15 of
+       the chunk at the pair's first tap, bytes 16-31 = at its second tap), then 64 x int32 whose low byte is the E8M0 scale of the
+       (column, tap, chunk) block the lane half supplies (L / 32 = 0: first tap, 1: second tap; value = 2^(scale - 127)).
+       Measured: 2.2-2.3 x the error of precision 1 at 1.64 x its matrix-pipe rate (tools/micro/mx_split_probe.hip). */
+    const void* wgt_mx;
 } woft_conv_params;
 
 int woft_conv2d(const woft_conv_params* p, void* stream);

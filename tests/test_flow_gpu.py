@@ -565,3 +565,24 @@ def test_split_packed_update_block_is_bit_identical(monkeypatch, precision, h, w
         flow2, _ = prov.compute_flow(a, b, mode="flow")          # (second call: buffers hold the previous flow's packed data)
         assert torch.equal(flow2, flow)
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+@torch.no_grad()
+def test_f16mx8_operating_point_vs_reference(golden_dir):
+    """precision "f16mx8" (the update block's convolutions in two matrix-pipe passes per product: fp16 main term + two block-scaled
+    fp8 cross terms; everything else bf16x3) against the REFERENCE's flow and weights at 12 and 32 iterations: inside the fp32
+    budget of SURVEY 8d (EPE mean <= 1e-3 px, max <= 1e-2 px, sigmoid(w) <= 1e-4)."""
+    for name in ("flow_full_136x200_it12", "flow_full_136x200_it32"):
+        g = np.load(golden_dir / f"{name}.npz")
+        sd = synth.make_state_dict(seed=int(g["seed"]))
+        fc = _flow_config(sd, int(g["iters"]), precision="f16mx8")
+        flower = fc.of_class(fc)
+        plan = flower.engine.plan(136, 200)
+        assert any(e[1].precision == 4 for e in plan.prog_iter if e[0] == "conv"), "no layer runs in f16mx8"
+        flow, w = flower.compute_flow(g["img1"], g["img2"], mode="flow", do_sigmoid=False)
+        torch.cuda.synchronize()
+        m, mx = _epe(flow, torch.from_numpy(g["flow_up"])[0])
+        dws = float((torch.sigmoid(w.cpu()) - torch.sigmoid(torch.from_numpy(g["w_up"])[0])).abs().max())
+        print(f"{name} f16mx8: EPE mean {m:.2e} max {mx:.2e}; sigmoid(w) {dws:.2e}")
+        scale = 1.0 if int(g["iters"]) <= 12 else 3.0
+        assert m < 1e-3 * scale and mx < 1e-2 * scale and dws < 1e-4 * scale, (m, mx, dws)

@@ -1347,3 +1347,63 @@ def test_gru_convs_on_the_per_tap_kernel(ops, kh, kw, h, w, precision):
     if 8 in outs:        # (different accumulation order -- tap-major vs chunk-major K steps: close, not bit-identical)
         for u, v_ in zip(outs[0], outs[8]):
             _close(u, v_, tol, what="per-tap vs pixel-tile kernel")
+
+
+# ------------------------------------------------------------------------------------------
+# precision "f16mx8": fp16 main term + two block-scaled fp8 cross terms (woft_conv_params.wgt_mx, round 4)
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kh,kw,cin,cout,h,w,tiles", [(3, 3, 256, 192, 24, 40, None), (3, 3, 128, 64, 17, 37, None), (1, 5, 128, 128, 24, 40, None),
+                                                      (5, 1, 128, 128, 9, 16, None), (3, 3, 256, 126, 135, 240, None),
+                                                      (3, 3, 128, 256, 24, 40, (128, 128)), (1, 5, 64, 128, 19, 37, None)])
+def test_conv_f16mx8(ops, kh, kw, cin, cout, h, w, tiles):
+    """The two-pass fp32-emulating product on the register-streamed kernel against fp64: error scale of bf16x3 (measured 2.2-2.3 x
+    its error on the matrix cores, tools/micro/mx_split_probe.hip) -- far below fp16's (67 x) and bf16's (530 x); ReLU-like
+    activations with a wide per-pixel amplitude range (the block scales' job), zero rows (scale byte 0) and ragged tiles."""
+    E = ops._lib
+    g = torch.Generator().manual_seed(7)
+    amp = torch.exp(torch.rand(1, 1, h, w, generator=g) * 8 - 6)                    # per-pixel amplitude over 3.5 decades
+    x = torch.relu(torch.randn(1, cin, h, w, generator=g)) * amp
+    x[:, :, 2, 3] = 0.0                                                             # an all-zero pixel: block maximum 0
+    wt = torch.randn(cout, cin, kh, kw, generator=g) / math.sqrt(cin * kh * kw)
+    b = _rand(cout, seed=13, scale=0.1)
+    ref = F.conv2d(x.double(), wt.double(), b.double(), padding=(kh // 2, kw // 2))
+    norm = F.conv2d(x.double().abs(), wt.double().abs(), None, padding=(kh // 2, kw // 2)) + 1e-30
+    pc = ops.pack_conv(wt, b, padding=(kh // 2, kw // 2))
+    xa = ops.act_from_nchw(x)
+    errs = {}
+    for prec in ("bf16x3", "f16mx8", "fp16"):
+        out = ops.new_act(1, h, w, cout, cs=ops._round_up(cout, 4), zero=True)
+        p = ops.conv_params(xa, pc, out, precision=prec, tiles=tiles, halo=8 if tiles else None)
+        assert p.halo in (8, 12) and p.precision == ops.PRECISION[prec]
+        ops.run_conv(p)
+        torch.cuda.synchronize()
+        e = (out.nchw().double().cpu() - ref) / norm
+        errs[prec] = float(torch.sqrt((e ** 2).mean()))
+    print(f"{kh}x{kw} {cin}->{cout} @{h}x{w}: rms error / sum|a||w|  bf16x3 {errs['bf16x3']:.2e}  f16mx8 {errs['f16mx8']:.2e} "
+          f"({errs['f16mx8'] / errs['bf16x3']:.1f} x)  fp16 {errs['fp16']:.2e}")
+    assert errs["f16mx8"] < 6 * errs["bf16x3"] and errs["f16mx8"] < 0.2 * errs["fp16"]
+
+
+def test_gru_half_step_f16mx8(ops):
+    """Two-source GRU convs with their gate epilogues in f16mx8 against the bf16x3 launches."""
+    E = ops._lib
+    n, h, w, kh, kw = 1, 24, 40, 1, 5
+    hprev = torch.tanh(_rand(n, 128, h, w, seed=4))
+    xin = torch.relu(_rand(n, 128, h, w, seed=5))
+    mk = lambda s: _rand(128, 256, kh, kw, seed=s, scale=1 / math.sqrt(256 * kh * kw))
+    pzr = ops.pack_conv(torch.cat([mk(6), mk(7)], 0), None, padding=(0, 2))
+    pq = ops.pack_conv(mk(8), None, padding=(0, 2))
+    gz, gq = ops.act_from_nchw(_rand(n, 256, h, w, seed=9, scale=0.3)), ops.act_from_nchw(_rand(n, 128, h, w, seed=10, scale=0.3))
+    ha, xa = ops.act_from_nchw(hprev), ops.act_from_nchw(xin)
+    res = {}
+    for prec in ("bf16x3", "f16mx8"):
+        z, rh, hn = (ops.new_act(n, h, w, 128, zero=True) for _ in range(3))
+        a = ops.conv_params(ha, pzr, z, x2=xa, c_split=128, epi=E.EPI_GRU_ZR, split=128, e0=ha, out1=rh, bias_map=gz, precision=prec)
+        b = ops.conv_params(rh, pq, hn, x2=xa, c_split=128, epi=E.EPI_GRU_Q, e0=ha, e1=z, bias_map=gq, precision=prec)
+        assert a.precision == ops.PRECISION[prec] and b.precision == ops.PRECISION[prec]
+        ops.run_conv(a)
+        ops.run_conv(b)
+        torch.cuda.synchronize()
+        res[prec] = (z.t.clone(), hn.t.clone())
+    _close(res["f16mx8"][0], res["bf16x3"][0], 2e-5, what="z")
+    _close(res["f16mx8"][1], res["bf16x3"][1], 3e-5, what="h")

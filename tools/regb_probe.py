@@ -68,6 +68,13 @@ if stamps is not None:
     print(f"  first chunk (incl. prologue) med {int(np.median(pro))}; later chunks med {int(np.median(chunks))} "
           f"p10 {int(np.percentile(chunks,10))} p90 {int(np.percentile(chunks,90))}; epilogue med {int(np.median(epi))}")
     print(f"  ticks per us: {end.max() / (ts[6]*1e3):.1f}")
+    if prec == "f16mx8":              # (its chunk loop also stamps "MFMAs of chunk c issued" at [16 + c]: epilogue phases are not stamped)
+        c = np.arange(1, min(nch, 8))
+        issued = st[:, 16 + c] - st[:, c]
+        tail = st[:, 1 + c] - st[:, 16 + c]
+        print(f"  chunk = issue phase (loads, halo rows, MFMAs) med {int(np.median(issued))} p10 {int(np.percentile(issued, 10))} p90 "
+              f"{int(np.percentile(issued, 90))} + tail (barrier) med {int(np.median(tail))} p10 {int(np.percentile(tail, 10))} p90 {int(np.percentile(tail, 90))}")
+        raise SystemExit
     ep = st[:, 16:26]
     d = np.diff(np.concatenate([st[:, 14:15], ep], axis=1), axis=1)
     print("  epilogue phases (median cycles): entry->", [int(np.median(d[:, k])) for k in range(d.shape[1]) if ep[:, k].max() > 0])

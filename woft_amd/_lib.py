@@ -31,7 +31,7 @@ class ConvParams(C.Structure):
         ("in_norm", i32), ("in_mean", vp), ("in_rstd", vp), ("bias_map", vp), ("ld_bias_map", i32),
         ("out_index", vp),
         ("wh0_lookup", vp), ("wh0_ld", i32), ("wh0_mean", vp), ("wh0_w", vp), ("wh0_bias", vp), ("wh0_index", vp),
-        ("wgt_frag", vp), ("in_fmt", i32), ("out_fmt", i32),
+        ("wgt_frag", vp), ("in_fmt", i32), ("out_fmt", i32), ("wgt_mx", vp),
     ]
 
 

@@ -22,7 +22,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math"
 # the parts run side by side.  Every part exports its own dispatcher symbol (woft_conv_dispatch_p<k>, woft_conv_regb_launch_p<k>_<pk>);
 # the C ABI entry points live in part 1 of conv.hip.
 PARTS = {"conv.hip": [("p1", ["-DWOFT_ONLY_PREC=1"]), ("p2", ["-DWOFT_ONLY_PREC=2"]), ("p3", ["-DWOFT_ONLY_PREC=3"])],
-         "conv_regb.hip": [(f"p{k}_{pk}", [f"-DWOFT_ONLY_PREC={k}", f"-DWOFT_ONLY_PK={pk}"]) for k in (1, 2, 3) for pk in (0, 1)]}
+         "conv_regb.hip": [(f"p{k}_{pk}", [f"-DWOFT_ONLY_PREC={k}", f"-DWOFT_ONLY_PK={pk}"]) for k in (1, 2, 3) for pk in (0, 1)]
+                          + [("p4_0", ["-DWOFT_ONLY_PREC=4", "-DWOFT_ONLY_PK=0"])]}     # precision 4 (f16mx8): fp32 activations in
 
 
 def _sources():
@@ -54,21 +55,44 @@ def build(force=False, verbose=True):
     if not force and LIB.exists() and STAMP.exists() and STAMP.read_text().strip() == dig:
         return LIB
     objs = []
-    for old in LIBDIR.glob("*.o"):            # (objects of an earlier unit list must not be linked)
-        old.unlink()
     units = _units()
+    wanted = {u[1] for u in units}
+    for old in LIBDIR.glob("*.o"):            # (objects of an earlier unit list must not be linked)
+        if old not in wanted:
+            old.unlink()
+    # per-unit stamps: a unit is recompiled when its source, any header or its flags changed (an edit of conv_regb.hip leaves the
+    # three 9-minute parts of conv.hip alone)
+    hdr = hashlib.sha256()
+    for h in sorted(list(CSRC.glob("*.h")) + [HERE.parent / "include" / "woft_hip.h"]):
+        hdr.update(h.name.encode())
+        hdr.update(h.read_bytes())
+
+    def unit_hash(src, extra):
+        u = hashlib.sha256(hdr.digest())
+        u.update(src.read_bytes())
+        u.update(" ".join(FLAGS + extra).encode())
+        return u.hexdigest()
     # heaviest units first; at most `jobs` compilers at a time
     jobs = int(os.environ.get("WOFT_BUILD_JOBS", os.cpu_count() or 4))
     units.sort(key=lambda u: -(u[0].stat().st_size * (4 if u[0].name in PARTS else 1)))
-    pending, running = list(units), []
+    pending, running = [], []
+    for src, obj, extra in units:
+        objs.append(obj)
+        uh = unit_hash(src, extra)
+        tag = Path(str(obj) + ".hash")
+        if not force and obj.exists() and tag.exists() and tag.read_text().strip() == uh:
+            continue
+        pending.append((src, obj, extra, uh))
     while pending or running:
         while pending and len(running) < jobs:
-            src, obj, extra = pending.pop(0)
-            objs.append(obj)
+            src, obj, extra, uh = pending.pop(0)
+            tag = Path(str(obj) + ".hash")
+            if tag.exists():
+                tag.unlink()
             cmd = [HIPCC, *FLAGS, *extra, "-c", str(src), "-o", str(obj)]
             if verbose:
                 print(" ".join(cmd), flush=True)
-            running.append((src, subprocess.Popen(cmd)))
+            running.append((src, subprocess.Popen(cmd), tag, uh))
         time.sleep(0.2)
         for ent in list(running):
             rc = ent[1].poll()
@@ -76,9 +100,10 @@ def build(force=False, verbose=True):
                 continue
             running.remove(ent)
             if rc != 0:
-                for _, other in running:
-                    other.kill()
+                for other in running:
+                    other[1].kill()
                 raise RuntimeError(f"hipcc failed on {ent[0]}")
+            ent[2].write_text(ent[3])
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB), *map(str, objs)]
     if verbose:
         print(" ".join(cmd), flush=True)

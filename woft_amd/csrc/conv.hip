@@ -243,12 +243,18 @@ __global__ __launch_bounds__(256) void conv_mfma_bf16_kernel(const woft_conv_par
         const int c0 = pf_chunk * BK;
         const bool second = (p.in1 != nullptr) && (c0 >= p.c_split);
         rpk = (p.in_fmt & (second ? 2 : 1)) != 0;
-        const float* src = (second ? p.in1 + (c0 - p.c_split) : p.in0 + (p.flat ? 0 : c0)) + 4 * v;
+        // (the chunk's channel offset goes into the 32-bit lane offset, the scalar base is in0 / in1 itself.  The former form --
+        //  `p.in1 + (c0 - p.c_split)` as the base -- was MISCOMPILED inside the K loop: the 64-bit shift of the index took its high
+        //  half from an unrelated live SGPR (s_lshl_b64 s[6:7], s[72:73], 2 with s73 never cleared: ISA of round 4), so every
+        //  two-source layer on this kernel faulted -- unnoticed for three rounds because the GRU's two-source convs run on the
+        //  pixel-tile kernels wherever the map is at least 8 x 16; tests/test_kernels_gpu.py::test_gru_convs_on_the_per_tap_kernel)
+        const float* base = second ? p.in1 : p.in0;
+        const uint32_t coff = (uint32_t)((second ? c0 - p.c_split : (p.flat ? 0 : c0)) + 4 * v);
         const int cs = second ? p.cs1 : p.cs0;
 #pragma unroll
         for (int j = 0; j < RA; ++j) {
             // (flat: poff may address up to dpix pixels left of a valid one; still inside the image row segment)
-            ra[j] = *(const f32x4*)(src + (int64_t)(int32_t)(poff[j] * (uint32_t)cs));
+            ra[j] = *(const f32x4*)(base + (int64_t)(int32_t)(poff[j] * (uint32_t)cs + coff));
             rok[j] = pok[j];
         }
     };
@@ -1017,7 +1023,10 @@ int woft_conv_dispatch_p3(const woft_conv_params& p, const woft_conv_params* sec
 #if WOFT_ONLY_PREC == 1
 static int conv_check(const woft_conv_params& p) {
     if (p.in0 == nullptr || p.out == nullptr) return WOFT_EINVAL;
-    if (p.precision < 0 || p.precision > 3) return WOFT_EINVAL;
+    if (p.precision < 0 || p.precision > 4) return WOFT_EINVAL;
+    if (p.precision == 4 && ((p.halo != 8 && p.halo != 12) || p.wgt_frag == nullptr || p.wgt_mx == nullptr || p.in_fmt != 0 ||
+                             p.in_norm != 0 || p.taps_y * p.taps_x == 1))
+        return WOFT_EINVAL;                   // f16mx8: the register-streamed kernel's multi-tap instances only (woft_conv_params.wgt_mx)
     if (p.precision == 0 && p.wgt == nullptr) return WOFT_EINVAL;
     if (p.precision >= 1 && p.wgt_hi == nullptr) return WOFT_EINVAL;
     if (p.precision == 1 && p.wgt_lo == nullptr) return WOFT_EINVAL;
@@ -1119,8 +1128,22 @@ int WOFT_CAT2(woft_conv_dispatch_p, WOFT_ONLY_PREC)(const woft_conv_params& p, c
 }
 
 #if WOFT_ONLY_PREC == 1
+int woft_conv_regb_launch_p4_0(const woft_conv_params& p, const woft_conv_params* second, void* stream);   // conv_regb.hip, part 4
+
+static int conv_dispatch_f16mx8(const woft_conv_params& p, const woft_conv_params* second, void* stream) {
+    for (const woft_conv_params* q : {&p, second}) {
+        if (q == nullptr) continue;
+        if (q->precision != 4 || q->halo != p.halo || q->tile_n != p.tile_n || q->flat || q->stride != 1) return WOFT_EINVAL;
+        if (q->ho != q->h + 2 * q->pad_y - q->taps_y + 1 || q->wo != q->w + 2 * q->pad_x - q->taps_x + 1) return WOFT_EINVAL;
+        const int64_t cs_max = (q->in1 != nullptr && q->cs1 > q->cs0) ? q->cs1 : q->cs0;
+        if ((int64_t)q->n_img * q->h * q->w * cs_max >= (1ll << 31)) return WOFT_EINVAL;     // 32-bit element offsets
+    }
+    return woft_conv_regb_launch_p4_0(p, second, stream);
+}
+
 static int conv_dispatch(const woft_conv_params& p, const woft_conv_params* second, void* stream) {
     switch (p.precision) {               // (the exact-fp32 kernel lives in the bf16 part)
+        case 4: return conv_dispatch_f16mx8(p, second, stream);
         case 1: return woft_conv_dispatch_p1(p, second, stream);
         case 3: return woft_conv_dispatch_p3(p, second, stream);
         default: return woft_conv_dispatch_p2(p, second, stream);

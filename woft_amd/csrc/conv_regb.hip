@@ -27,7 +27,7 @@ extern int g_regb_dyn_lds;          // conv.hip (woft_set_tuning key 3)
 // WOFT_ONLY_PK in {0, 1} -- each part exporting woft_conv_regb_launch_p<prec>_<pk>; conv.hip's dispatcher of the same precision
 // picks the part by the layer's in_fmt.
 #if !defined(WOFT_ONLY_PREC) || !defined(WOFT_ONLY_PK)
-#error "conv_regb.hip is compiled in parts: -DWOFT_ONLY_PREC=1|2|3 -DWOFT_ONLY_PK=0|1 (woft_amd/build.py)"
+#error "conv_regb.hip is compiled in parts: -DWOFT_ONLY_PREC=1|2|3|4 -DWOFT_ONLY_PK=0|1 (woft_amd/build.py)"
 #endif
 #define WOFT_CAT4_(a, b, c, d) a##b##c##d
 #define WOFT_CAT4(a, b, c, d) WOFT_CAT4_(a, b, c, d)
@@ -39,6 +39,15 @@ using woft::BK;
 
 // NORM (compile time; encoder layers, round 3): p.in_norm != 0 -- the producer's InstanceNorm (+ ReLU) applied while the halo is
 // converted, with conv_halo_bf16_kernel's expression (bit-identical); the per-channel statistics of the chunk travel with its halo rows.
+// TERMS = 28 (precision code 4, "f16mx8"; round 4): an fp32-emulating product in TWO matrix-pipe passes instead of
+// bf16x3's three --  a * w ~= fp16(a) * fp16(w) + mx8(a - fp16(a)) * mx8(w) + mx8(a) * mx8(w - fp16(w)):  main term on
+// v_mfma_f32_32x32x16_f16, both cross terms on the block-scaled v_mfma_scale_f32_32x32x64_f8f6f4 (fp8 e4m3, one E8M0 scale per
+// 32-element K block; twice the bf16 rate).  K = 64 of one scaled MFMA = TWO TAPS x this chunk's 32 channels: MX block 0 = tap t,
+// block 1 = tap t + 1 (operand convention pinned by tools/micro/mx_layout_probe.hip: block b = bytes 16 b .. 16 b + 15 of both
+// lane halves, lane half hh = channels 16 hh .. + 15, block b's scale = the scale operand of lane half b).  Per halo row and chunk
+// the LDS holds the fp16 plane (as TERMS = 16) plus two fp8 planes -- mx8(a), mx8(a - fp16(a)): 32 data bytes + the block's scale
+// byte, 48-byte pitch -- written by the loader; the weights' three forms come pre-packed (wgt_frag: fp16 fragments, wgt_mx: the
+// fp8 fragments of w and of w - fp16(w) per tap pair with their scales).  Measured error 2.2-2.3 x bf16x3's (mx_split_probe).
 // PK (compile time; round 4): both input sources are SPLIT-PACKED (woft_conv_params.in_fmt): a halo row's 16 bytes already
 // are [hi[0..3] | lo[0..3]] of its four channels -- the loader copies them into the two LDS planes, no conversion.
 template <int TY, int TX, int KY, int KX, int WM, int TERMS, int NBUF, int DIST, int AD, int CU = 1, int HD = 1, bool IL = true,
@@ -58,7 +67,11 @@ __global__ __launch_bounds__(256, 2) void conv_regb_kernel(const woft_conv_param
     constexpr int WROWS = BM / WM;
     constexpr int TM = WROWS / 32;
     constexpr int NP = (TERMS == 3) ? 2 : 1;
+    constexpr bool MX = (TERMS == 28);
+    constexpr int MT = MX ? 16 : TERMS;                                   // conversion / MFMA type of the (main) term
     constexpr int TAPS = KY * KX;
+    constexpr int NPAIR = (TAPS + 1) / 2;                                 // MX: tap pairs per chunk (an odd last tap pairs with zero weights)
+    static_assert(!MX || (!PK && !NORM), "f16mx8: fp32 activations in, no norm-on-load");
     // CU: chunks per unrolled group (the ring slot of step s = chunk * TAPS + tap must be a compile-time constant:
     // (CU * TAPS) % NBUF == 0; multi-tap layers: CU = 1, TAPS % NBUF == 0; 1x1 layers: TAPS = 1, CU = NBUF).
     // HD: how many chunks ahead the input tile is requested (1x1: a chunk is a single K step, too short to cover HBM latency)
@@ -66,7 +79,9 @@ __global__ __launch_bounds__(256, 2) void conv_regb_kernel(const woft_conv_param
     static_assert(BM % (32 * WM) == 0, "bad wave layout");
     constexpr int HX = TX + KX - 1, HY = TY + KY - 1, HROWS = HX * HY;
     constexpr int RH = (HROWS + 31) / 32;
-    constexpr int A_PLANE = HROWS * LDB, A_ELEMS = NP * A_PLANE;          // one halo buffer (bf16 elements)
+    constexpr int QPITCH = 48;                                            // MX: bytes per row of an fp8 plane (32 data + scale + pad)
+    constexpr int Q_PLANE = HROWS * QPITCH / 2;                           // ... in bf16-sized elements
+    constexpr int A_PLANE = HROWS * LDB, A_ELEMS = NP * A_PLANE + (MX ? 2 * Q_PLANE : 0);   // one halo buffer (bf16 elements)
     constexpr int STAGE_ELEMS = 2 * NWAVES * TM * woft::STAGE_FLOATS;     // epilogue staging: all TM tiles of every wave
     constexpr int SMEM_ELEMS = (2 * A_ELEMS > STAGE_ELEMS) ? 2 * A_ELEMS : STAGE_ELEMS;
     constexpr int STEP_ELEMS = NP * 2 * 64 * 8;                           // fragment elements of one K step of a band
@@ -139,6 +154,43 @@ __global__ __launch_bounds__(256, 2) void conv_regb_kernel(const woft_conv_param
             return;
         }
         const f32x4 val = hok[j] ? x : zero;
+        if constexpr (MX) {
+            // fp16 plane + the two block-scaled fp8 planes of this row's 32 channels (the row's 8 loader lanes = one MX block)
+            const bf16x4 h16 = cvt16<16>(val);
+            *(bf16x4*)(As + ht * LDB + 4 * v) = h16;
+            const f32x4 la = val - __builtin_convertvector(__builtin_bit_cast(f16x4, h16), f32x4);
+            float ma = fmaxf(fmaxf(fabsf(val[0]), fabsf(val[1])), fmaxf(fabsf(val[2]), fabsf(val[3])));
+            // block maximum over the row's eight loader lanes (an aligned group of 8): three DPP steps on the vector ALU -- half-row
+            // mirror (i <-> 7 - i), then the quad swaps xor 1 and xor 2.  (The first version used __shfl_xor = ds_bpermute: three
+            // dependent LDS round trips per row, and every lgkmcnt wait also drained the fragment prefetches behind them.)
+            auto dpp_max = [](float x, auto ctrl_tag) {
+                constexpr int ctrl = decltype(ctrl_tag)::value;
+                const int xi = __builtin_bit_cast(int, x);
+                const int yi = __builtin_amdgcn_update_dpp(xi, xi, ctrl, 0xf, 0xf, false);
+                return fmaxf(x, __builtin_bit_cast(float, yi));
+            };
+            ma = dpp_max(ma, std::integral_constant<int, 0x141>{});     // row_half_mirror
+            ma = dpp_max(ma, std::integral_constant<int, 0xB1>{});      // quad_perm [1,0,3,2]
+            ma = dpp_max(ma, std::integral_constant<int, 0x4E>{});      // quad_perm [2,3,0,1]
+            // E8M0 scale 2^(s - 127) with the block maximum scaled into [128, 256) (e4m3's largest: 448): s = biased exponent - 7.
+            // The remainder a - fp16(a) is at most 2^-11 of its element, so ITS block needs no maximum of its own: scale s - 11
+            // keeps it below 256 too, and e4m3's fourteen octaves leave room for blocks whose remainders happen to be smaller.
+            int sa = (int)((__builtin_bit_cast(uint32_t, ma) >> 23) & 0xffu) - 7;
+            sa = sa < 11 ? 11 : sa;
+            const int sl = sa - 11;
+            const float ia = __builtin_bit_cast(float, (uint32_t)(254 - sa) << 23), il = __builtin_bit_cast(float, (uint32_t)(254 - sl) << 23);
+            int qa = 0, ql = 0;
+            qa = __builtin_amdgcn_cvt_pk_fp8_f32(val[0] * ia, val[1] * ia, qa, false);
+            qa = __builtin_amdgcn_cvt_pk_fp8_f32(val[2] * ia, val[3] * ia, qa, true);
+            ql = __builtin_amdgcn_cvt_pk_fp8_f32(la[0] * il, la[1] * il, ql, false);
+            ql = __builtin_amdgcn_cvt_pk_fp8_f32(la[2] * il, la[3] * il, ql, true);
+            char* qpa = (char*)(As + A_PLANE) + ht * QPITCH;
+            char* qpl = qpa + 2 * Q_PLANE;
+            *(int*)(qpa + 4 * v) = qa;
+            *(int*)(qpl + 4 * v) = ql;
+            if (v == 0) { qpa[32] = (char)sa; qpl[32] = (char)sl; }
+            return;
+        }
         const bf16x4 hi = cvt16<TERMS>(val);
         *(bf16x4*)(As + ht * LDB + 4 * v) = hi;
         if (NP == 2) {
@@ -179,6 +231,33 @@ __global__ __launch_bounds__(256, 2) void conv_regb_kernel(const woft_conv_param
         a_off[i] = ((pl / TX) * HX + (pl % TX)) * LDB + hh * 8;
     }
 
+    // MX: byte offset of this lane's row inside an fp8 plane (tap (0, 0)): data of its channel half at + 16 hh, scale byte at + 32
+    int q_off[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        bool valid;
+        const int pl = halo_row_pixel<TY, TX>(wm * WROWS + i * 32 + r32, valid);
+        q_off[i] = ((pl / TX) * HX + (pl % TX)) * QPITCH;
+    }
+    // MX: this wave's fp8 weight stream -- per (chunk, tap pair, term): 64 lanes x 32 data bytes, then 64 scale dwords
+    typedef int i32x8 __attribute__((ext_vector_type(8)));
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    constexpr int MXQ = 64 * 32 + 64 * 4;                                  // bytes per (pair, term)
+    const char* wmx = MX ? (const char*)p.wgt_mx + (int64_t)(n0 / 32 + wn) * nchunk * NPAIR * 2 * MXQ : nullptr;
+    i32x8 wq[1][2];                                                        // [one register set][term: w (meets l_a), l_w (meets a)]
+    int wsc[1][2];
+    auto fetch_mx = [&](int pair_idx, auto slot_tag) {                     // pair_idx = chunk * NPAIR + pair (clamped at the end)
+        constexpr int slot = decltype(slot_tag)::value;
+        const int last = nchunk * NPAIR - 1;
+        const char* src = wmx + (int64_t)(pair_idx < last ? pair_idx : last) * (2 * MXQ);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const i32x4 lo = *(const i32x4*)(src + t * MXQ + lane * 32), hi = *(const i32x4*)(src + t * MXQ + lane * 32 + 16);
+            wq[slot][t] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            wsc[slot][t] = *(const int*)(src + t * MXQ + 64 * 32 + lane * 4);
+        }
+    };
+
     // developer probe (tools/regb_probe.py): s_memtime stamps of wave 0 -> in_rstd (unused by this kernel otherwise)
     unsigned long long* stamps = (p.in_mean == (const float*)1 && wave == 0 && lane == 0)
                                      ? (unsigned long long*)p.in_rstd + (size_t)bid * 32 : nullptr;
@@ -190,6 +269,7 @@ __global__ __launch_bounds__(256, 2) void conv_regb_kernel(const woft_conv_param
     [&]<int... S>(std::integer_sequence<int, S...>) {
         (fetch_b(S, std::integral_constant<int, S % NBUF>{}), ...);
     }(std::make_integer_sequence<int, DIST>{});
+    if constexpr (MX) fetch_mx(0, std::integral_constant<int, 0>{});
     store_halo(smem, std::integral_constant<int, 0>{});
     __syncthreads();
 
@@ -268,8 +348,142 @@ __global__ __launch_bounds__(256, 2) void conv_regb_kernel(const woft_conv_param
         if (more) __syncthreads();
         if (stamps && chunk < 12) stamps[1 + chunk] = __builtin_amdgcn_s_memtime();
     };
+    // ---- f16mx8: one chunk = TAPS fp16 steps (2 MFMAs per row tile) + NPAIR tap pairs of two scaled fp8 MFMAs per row tile.
+    //      Register diet (the first version spilled 170-900 bytes per lane): the main term's A fragments are two half sets --
+    //      k half 1 of tap t is requested before the MFMAs of its k half 0, k half 0 of tap t + 1 before the MFMAs of k half 1 --;
+    //      the fp8 fragments go row tile by row tile, one tile ahead; the fp8 weights of pair p + 1 are requested right after pair
+    //      p's MFMAs consumed the single register set (two taps of lead).
+    auto run_chunk_mx = [&](int chunk, auto more_tag) {
+        constexpr bool more = decltype(more_tag)::value;
+        static_assert(CU == 1 && HD == 1, "f16mx8: multi-tap layers");
+        const __bf16* As = smem + (chunk & 1) * A_ELEMS;
+        const char* Qa = (const char*)(As + A_PLANE);
+        const char* Ql = Qa + 2 * Q_PLANE;
+        // Two pipelines.  DEEP (two row tiles per wave: the 64-column and the 4 x 16-pixel layouts): ALL fragments of tap t + 1 -- and,
+        // at a pair's last tap, the pair's fp8 fragments and scales -- are requested before the MFMAs of tap t (two register sets by
+        // tap parity).  Four row tiles per wave (8 x 16 pixels x 128 columns) do not have the registers: the main term's fragments go
+        // as two half sets (k half 1 of tap t before the MFMAs of its k half 0, k half 0 of tap t + 1 before those of k half 1), the
+        // fp8 fragments row tile by row tile.
+        constexpr bool DEEP = TM <= 2;
+        constexpr bool AM2 = DEEP && TAPS <= 5;                            // (3x3: the two-set form spills -- half sets there too)
+        constexpr int NAM = AM2 ? 2 : 1;
+        bf16x8 am[NAM][2][TM];                                             // [tap parity][k half][row tile]
+        auto load_am = [&](auto tap_tag, auto s2_tag) {
+            constexpr int tap = decltype(tap_tag)::value, s2 = decltype(s2_tag)::value;
+            constexpr int ky = tap / KX, kx = tap - ky * KX;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) am[AM2 ? (tap & 1) : 0][s2][i] = *(const bf16x8*)(As + a_off[i] + (ky * HX + kx) * LDB + s2 * 16);
+        };
+        i32x8 qa[DEEP ? TM : 1], ql[DEEP ? TM : 1];
+        int sqa[DEEP ? TM : 1], sql[DEEP ? TM : 1];
+        auto load_q = [&](auto pr_tag, auto i_tag) {
+            constexpr int pr = decltype(pr_tag)::value, i = decltype(i_tag)::value, sb = DEEP ? i : 0;
+            constexpr int t0 = 2 * pr, t1 = (2 * pr + 1 < TAPS) ? 2 * pr + 1 : 2 * pr;                    // (odd tail: zero weights)
+            constexpr int o0 = ((t0 / KX) * HX + (t0 % KX)) * QPITCH, o1 = ((t1 / KX) * HX + (t1 % KX)) * QPITCH;
+            const char* ra = Qa + q_off[i] + 16 * hh;
+            const char* rl = Ql + q_off[i] + 16 * hh;
+            const i32x4 a0 = *(const i32x4*)(ra + o0), a1 = *(const i32x4*)(ra + o1);
+            const i32x4 l0 = *(const i32x4*)(rl + o0), l1 = *(const i32x4*)(rl + o1);
+            qa[sb] = i32x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            ql[sb] = i32x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+            const int so = q_off[i] + (hh ? o1 : o0) + 32;                 // lane half b supplies block b's scale
+            sqa[sb] = *(const unsigned char*)(Qa + so);
+            sql[sb] = *(const unsigned char*)(Ql + so);
+        };
+        load_am(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        if constexpr (AM2) load_am(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+        [&]<int... T>(std::integer_sequence<int, T...>) {
+            ([&] {
+                constexpr int tap = T, ab = AM2 ? (tap & 1) : 0;
+                constexpr int slot = tap % NBUF;                           // (CU == 1, TAPS % NBUF == 0: static ring slots)
+                constexpr bool pair_end = (tap & 1) == 1 || tap == TAPS - 1;
+                constexpr int pr = tap / 2;
+                fetch_b(chunk * TAPS + tap + DIST, std::integral_constant<int, (tap + DIST) % NBUF>{});
+                if (tap == 0 && chunk + 1 < nchunk) load_halo(chunk + 1, std::integral_constant<int, 0>{});
+                if constexpr (AM2) {
+                    if constexpr (tap + 1 < TAPS) {
+                        load_am(std::integral_constant<int, tap + 1>{}, std::integral_constant<int, 0>{});
+                        load_am(std::integral_constant<int, tap + 1>{}, std::integral_constant<int, 1>{});
+                    }
+                } else {
+                    load_am(std::integral_constant<int, tap>{}, std::integral_constant<int, 1>{});
+                }
+                if constexpr (DEEP) {
+                    // the pair's fp8 fragments a tap ahead (at the pair's first tap) where the registers allow it: the 1x5 / 5x1 instances
+                    // (41.7 -> 37.7 us on the GRU's q conv); the 3x3 instance spills with the longer live range (85 -> 125 us)
+                    constexpr bool QEARLY = TAPS <= 5;
+                    if constexpr (QEARLY ? (tap & 1) == 0 : pair_end)
+                        [&]<int... I>(std::integer_sequence<int, I...>) {
+                            (load_q(std::integral_constant<int, pr>{}, std::integral_constant<int, I>{}), ...);
+                        }(std::make_integer_sequence<int, TM>{});
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // DEEP: the next chunk's halo (requested at tap 0) is converted and written to the other buffer ONE thread-row per half
+                // tap over the last RH half taps, its ~80 vector / cross-lane / LDS instructions in the issue shadow of this half
+                // tap's MFMAs -- as one block after the last MFMA it cost ~3 k of a 9.4 k-cycle chunk (stamps, first version)
+                constexpr int NHS = 2 * TAPS;                              // half-tap slots per chunk
+                constexpr bool ILX = DEEP && NHS >= RH;
+                constexpr int rowa = 2 * tap - (NHS - RH), rowb = rowa + 1;
+                if constexpr (ILX && more && rowa >= 0 && rowa < RH)
+                    store_halo_row(smem + ((chunk + 1) & 1) * A_ELEMS, std::integral_constant<int, 0>{}, std::integral_constant<int, (rowa >= 0 && rowa < RH) ? rowa : 0>{});
+#pragma unroll
+                for (int i = 0; i < TM; ++i) acc[i] = mma16<16>(am[ab][0][i], bq[slot][0][0], acc[i]);
+                if constexpr (ILX && more && rowa >= 0 && rowa < RH) {
+#pragma unroll
+                    for (int g = 0; g < TM; ++g) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x002, 24, 0);     // then a share of the row's vector work
+                        __builtin_amdgcn_sched_group_barrier(0x080, 4, 0);      // and of its cross-lane / LDS instructions
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if constexpr (ILX && more && rowb >= 0 && rowb < RH)
+                    store_halo_row(smem + ((chunk + 1) & 1) * A_ELEMS, std::integral_constant<int, 0>{}, std::integral_constant<int, (rowb >= 0 && rowb < RH) ? rowb : 0>{});
+                if constexpr (!AM2) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (tap + 1 < TAPS) load_am(std::integral_constant<int, tap + 1>{}, std::integral_constant<int, 0>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i) acc[i] = mma16<16>(am[ab][1][i], bq[slot][0][1], acc[i]);
+                if constexpr (pair_end) {
+                    if constexpr (DEEP) {
+                        // term-major: consecutive MFMAs never chain on one accumulator (a dependent scaled MFMA waits out the whole
+                        // 16-pass latency of its predecessor: the tile-major first version gained nothing over bf16x3)
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+                            acc[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ql[i], wq[0][0], acc[i], 0, 0, 0, sql[i], 0, wsc[0][0]);
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+                            acc[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(qa[i], wq[0][1], acc[i], 0, 0, 0, sqa[i], 0, wsc[0][1]);
+                    } else {
+                        [&]<int... I>(std::integer_sequence<int, I...>) {
+                            ([&] {
+                                constexpr int i = I;
+                                load_q(std::integral_constant<int, pr>{}, std::integral_constant<int, i>{});
+                                acc[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ql[0], wq[0][0], acc[i], 0, 0, 0, sql[0], 0, wsc[0][0]);
+                                acc[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(qa[0], wq[0][1], acc[i], 0, 0, 0, sqa[0], 0, wsc[0][1]);
+                            }(), ...);
+                        }(std::make_integer_sequence<int, TM>{});
+                    }
+                    // the NEXT pair's fp8 weights into the register set these MFMAs just read
+                    fetch_mx(chunk * NPAIR + pr + 1, std::integral_constant<int, 0>{});
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }(), ...);
+        }(std::make_integer_sequence<int, TAPS>{});
+        // next chunk's halo -> the other buffer (its loads had the whole chunk to land)
+        if (stamps && chunk < 12) stamps[16 + chunk] = __builtin_amdgcn_s_memtime();        // (probe: MFMAs of the chunk issued)
+        if (more) {
+            if constexpr (!(DEEP && 2 * TAPS >= RH)) store_halo(smem + ((chunk + 1) & 1) * A_ELEMS, std::integral_constant<int, 0>{});
+            __syncthreads();
+        }
+        if (stamps && chunk < 12) stamps[1 + chunk] = __builtin_amdgcn_s_memtime();
+    };
     auto run_phase = [&](int chunk, auto more_tag) {     // chunk % CU selects the unrolled body with the right ring slots
-        if constexpr (CU == 1) {
+        if constexpr (MX) {
+            run_chunk_mx(chunk, more_tag);
+        } else if constexpr (CU == 1) {
             run_chunk(chunk, more_tag, std::integral_constant<int, 0>{});
         } else {
             const int ph = chunk % CU;
@@ -284,6 +498,8 @@ __global__ __launch_bounds__(256, 2) void conv_regb_kernel(const woft_conv_param
 
     const HaloRowMap<TY, TX> rowmap{img0, p.n_img, y0, x0, p.ho, p.wo};
     if (p.epi == WOFT_EPI_FLOWHEAD) {
+        // (f16mx8: the epilogue's small second conv keeps the split-bf16 arithmetic; its W2 fragments are packed for it)
+        constexpr int ET = MX ? 3 : TERMS, ENP = (ET == 3) ? 2 : 1;
         // Flow head, second conv folded into the first one's epilogue (update.py:10-17: conv2(relu(conv1(h))), 3 x 3, 2
         // output channels).  A 3 x 3 conv is linear in its input pixels: delta[q] = b2 + sum_taps <W2[tap], y[q + tap]>, so
         // this launch emits, per pixel p and tap, the 2 partial dot products s[p][tap][o] = <W2[o][:, tap], y[p]> over the
@@ -302,12 +518,12 @@ __global__ __launch_bounds__(256, 2) void conv_regb_kernel(const woft_conv_param
             bv[q] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (p.bias != nullptr) bv[q] = *(const f32x4*)(p.bias + ncol + (q >> 1) * 16 + 8 * hh + (q & 1) * 4);
         }
-        const __bf16* wf = (const __bf16*)p.e0 + (int64_t)(ncol / 32) * (2 * NP * 512) + lane * 8;
-        bf16x8 w2[2][NP];
+        const __bf16* wf = (const __bf16*)p.e0 + (int64_t)(ncol / 32) * (2 * ENP * 512) + lane * 8;
+        bf16x8 w2[2][ENP];
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-            for (int pl = 0; pl < NP; ++pl) w2[s2][pl] = *(const bf16x8*)(wf + (s2 * NP + pl) * 512);
+            for (int pl = 0; pl < ENP; ++pl) w2[s2][pl] = *(const bf16x8*)(wf + (s2 * ENP + pl) * 512);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -327,9 +543,9 @@ __global__ __launch_bounds__(256, 2) void conv_regb_kernel(const woft_conv_param
                     const f32x4 b4 = bv[2 * s2 + q];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) yv[e] = fmaxf(p.alpha * yv[e] + b4[e], 0.f);
-                    const bf16x4 hi = cvt16<TERMS>(yv);
+                    const bf16x4 hi = cvt16<ET>(yv);
                     bf16x4 lo = hi;
-                    if constexpr (NP == 2) lo = __builtin_convertvector(yv - widen_bf16x4(hi), bf16x4);
+                    if constexpr (ENP == 2) lo = __builtin_convertvector(yv - widen_bf16x4(hi), bf16x4);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { ah[s2][4 * q + e] = hi[e]; al[s2][4 * q + e] = lo[e]; }
                 }
@@ -338,11 +554,11 @@ __global__ __launch_bounds__(256, 2) void conv_regb_kernel(const woft_conv_param
             for (int r = 0; r < 16; ++r) sacc[i][r] = 0.f;
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                if (NP == 2) {
-                    sacc[i] = mma16<TERMS>(al[s2], w2[s2][0], sacc[i]);
-                    sacc[i] = mma16<TERMS>(ah[s2], w2[s2][NP - 1], sacc[i]);
+                if (ENP == 2) {
+                    sacc[i] = mma16<ET>(al[s2], w2[s2][0], sacc[i]);
+                    sacc[i] = mma16<ET>(ah[s2], w2[s2][ENP - 1], sacc[i]);
                 }
-                sacc[i] = mma16<TERMS>(ah[s2], w2[s2][0], sacc[i]);
+                sacc[i] = mma16<ET>(ah[s2], w2[s2][0], sacc[i]);
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -415,6 +631,13 @@ int launch_regb(const woft_conv_params& p, const woft_conv_params* second, hipSt
     REGB_TAPS(3);
 #elif WOFT_ONLY_PREC == 3
     REGB_TAPS(16);
+#elif WOFT_ONLY_PREC == 4
+    // f16mx8: the multi-tap instances only (no norm-on-load, no 1x1)
+    if (p.in_norm != 0 || p.wgt_mx == nullptr) return WOFT_EINVAL;
+    if (p.taps_y == 3 && p.taps_x == 3) REGB(3, 3, 28, 3, 2);
+    else if (p.taps_y == 1 && p.taps_x == 5) REGB(1, 5, 28, 5, 3);
+    else if (p.taps_y == 5 && p.taps_x == 1) REGB(5, 1, 28, 5, 3);
+    else return WOFT_EINVAL;
 #else
     REGB_TAPS(1);
 #endif

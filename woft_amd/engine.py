@@ -130,7 +130,9 @@ class RaftEngine:
             raise ValueError("corr must be 'volume' or 'otf'")
         self.precision = precision
         # arithmetic of the correlation (volume GEMM / volume-free lookup) and of the weight head's convolutions
-        self.prec_corr = self.prec_wh = "bf16x3" if precision == "fp16" else precision
+        # ("f16mx8": two matrix-pipe passes per product on the register-streamed conv kernel -- the update block; every other
+        #  kernel, the correlation and the weight head run in bf16x3)
+        self.prec_corr = self.prec_wh = "bf16x3" if precision in ("fp16", "f16mx8") else precision
         self.corr = corr
         self.volume_storage = volume_storage or ("bf16" if precision == "bf16" else "fp32")
         if self.volume_storage not in ("fp32", "bf16") or (self.volume_storage == "bf16" and precision == "fp32"):
@@ -155,7 +157,7 @@ class RaftEngine:
         self.fh1 = g("flow_head.conv1")
         self.fh2 = g("flow_head.conv2")
         # second conv of the flow head as MFMA fragments: folded into the first conv's epilogue (WOFT_EPI_FLOWHEAD)
-        self.fh2_frag = (ops.pack_flowhead_frags(sd[u + "flow_head.conv2.weight"], 2 if precision == "bf16x3" else 1,
+        self.fh2_frag = (ops.pack_flowhead_frags(sd[u + "flow_head.conv2.weight"], 2 if precision in ("bf16x3", "f16mx8") else 1,
                                                  f16=precision == "fp16")
                          if precision != "fp32" and FUSE_FLOWHEAD else None)
         if small:
@@ -225,11 +227,6 @@ class _Plan:
         assert hp % 8 == 0 and wp % 8 == 0
         self.eng, self.hp, self.wp = eng, hp, wp
         self.prec = eng.precision
-        if eng.precision != "fp32" and (hp // 8 < 8 or wp // 8 < 16) and os.environ.get("WOFT_ALLOW_SMALL") != "1":
-            # Known limit (round 4, tools/micro/dbg_small_flow.py): below 8 x 16 feature pixels the GRU's two-source 1x5 / 5x1 convs
-            # fall back from the pixel-tile kernels to the per-tap kernel, which faults there (seen at 64 x 72: 8 x 9).  A clean
-            # error instead of a GPU memory fault; the exact-fp32 precision has its own kernel and no such limit.
-            raise ValueError(f"inputs smaller than 64 x 128 pixels ({hp} x {wp}) need precision='fp32' on this path")
         self.source_tag = None
         self.lookup_events = None
         self.wh_events = None      # bench hook: list collecting (start, end) HIP events per lookup launch

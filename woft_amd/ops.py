@@ -122,6 +122,41 @@ class PackedConv:
             self._frag[key] = torch.stack(pl, dim=3).contiguous().to(self.wgt.device)
         return self._frag[key]
 
+    def frag_mx(self):
+        """fp8 fragments of the weights for precision "f16mx8" (woft_conv_params.wgt_mx): per 32-column band, 32-channel chunk, tap
+        pair and term (0: w, 1: w - fp16(w)) -- 64 lanes x 32 bytes e4m3 (lane L: column L % 32; bytes 0-15 = channels 16 (L // 32)
+        .. + 15 at the pair's first tap, bytes 16-31 at its second tap; an odd last tap pairs with zeros), then 64 int32 scales: lane
+        half 0 carries the E8M0 scale of the (column, first tap, chunk) block, lane half 1 that of the second tap's block.  A block's
+        scale puts its largest magnitude into [128, 256) (e4m3 holds up to 448)."""
+        if self._frag is None:
+            self._frag = {}
+        if "mx" not in self._frag:
+            taps, nchunk = self.taps_y * self.taps_x, self.cin_pad // 32
+            npair = (taps + 1) // 2
+            w = self.wgt.detach().cpu().reshape(self.cout_pad, taps, nchunk, 32)
+            if float(w.abs().max()) >= 65504.0:
+                raise ValueError("precision 'f16mx8': a weight exceeds the fp16 range")
+            lw = w - w.to(torch.float16).float()
+            bands = self.cout_pad // 32
+            out = torch.zeros(bands, nchunk, npair, 2, 64 * 32 + 64 * 4, dtype=torch.uint8)
+            for t, x in enumerate((w, lw)):
+                amax = x.abs().amax(dim=3)                                            # [cout_pad][taps][nchunk]
+                e = torch.floor(torch.log2(torch.clamp(amax, min=1e-38)))
+                sc = torch.where(amax > 0, e - 7 + 127, torch.full_like(e, 127.0)).clamp(0, 254)   # E8M0 byte
+                q = (x / torch.exp2(sc - 127)[..., None]).to(torch.float8_e4m3fn).view(torch.uint8)    # [cout_pad][taps][nchunk][32]
+                if taps % 2:                                                          # zero weights (and unit scale) behind an odd last tap
+                    q = torch.cat([q, torch.zeros_like(q[:, :1])], 1)
+                    sc = torch.cat([sc, torch.full_like(sc[:, :1], 127.0)], 1)
+                q = q.reshape(bands, 32, npair, 2, nchunk, 2, 16)                     # band, col, pair, tap-in-pair, chunk, hh, 16 channels
+                data = q.permute(0, 4, 2, 5, 1, 3, 6).reshape(bands, nchunk, npair, 64 * 32)    # lane = 32 hh + col; [tap0 16 B | tap1 16 B]
+                scl = sc.reshape(bands, 32, npair, 2, nchunk).permute(0, 4, 2, 3, 1).reshape(bands, nchunk, npair, 64)   # lane = 32 tap-in-pair + col
+                scl4 = torch.zeros(bands, nchunk, npair, 64, 4, dtype=torch.uint8)
+                scl4[..., 0] = scl.to(torch.uint8)
+                out[:, :, :, t, :64 * 32] = data
+                out[:, :, :, t, 64 * 32:] = scl4.reshape(bands, nchunk, npair, 256)
+            self._frag["mx"] = out.contiguous().to(self.wgt.device)
+        return self._frag["mx"]
+
     def __post_init__(self):
         if self.wgt is not None and self.wgt_hi is None and self.wgt.dtype == torch.float32:
             w = self.wgt.detach().cpu()
@@ -181,7 +216,9 @@ def fold_bn(weight, bias, bn_w, bn_b, mean, var, eps=1e-5):
     return w, b
 
 
-PRECISION = {"fp32": 0, "bf16x3": 1, "bf16": 2, "fp16": 3}
+# "f16mx8" (round 4): fp16 main term + two block-scaled fp8 cross terms -- an fp32-emulating product in two matrix-pipe passes instead
+# of bf16x3's three (woft_conv_params.wgt_mx); layers whose kernel has no such instance run in bf16x3
+PRECISION = {"fp32": 0, "bf16x3": 1, "bf16": 2, "fp16": 3, "f16mx8": 4}
 SLOW_GATES = os.environ.get("WOFT_SLOW_GATES", "0") != "0"     # developer A/B: libm sigmoid / tanh in the conv epilogues
 USE_HALO = os.environ.get("WOFT_HALO", "1") != "0"
 USE_REGB = os.environ.get("WOFT_REGB", "1") != "0"
@@ -328,11 +365,23 @@ def conv_params(x, pc, out, co_off=0, epi=_lib.EPI_LINEAR, x2=None, c_split=0, e
         halo, p.tile_n = 12, 128
     p.halo = halo
     p.wgt_frag = None
+    p.wgt_mx = None
+    if p.precision == 4 and not (halo in (8, 12) and pc.taps_y * pc.taps_x > 1 and not in_norm and not in_fmt):
+        p.precision = 1                 # f16mx8 exists on the register-streamed kernel's multi-tap instances: elsewhere bf16x3
+    if p.precision == 4 and halo == 8 and tiles is None and p.tile_n == 128:
+        # two row tiles per wave have the registers for the deep fragment pipeline; four (8 x 16 pixels x 128 columns) spill:
+        # 1x5 / 5x1 layers take the 4 x 16-pixel x 128-column layout, 3x3 layers 64-column tiles
+        if (pc.taps_y, pc.taps_x) in ((1, 5), (5, 1)) and pc.cout_pad % 128 == 0 and _round_up(p.cout, 128) == pc.cout_pad:
+            halo = p.halo = 12
+        else:
+            p.tile_n = 64
     if halo in (8, 12):                 # weights streamed to registers in MFMA-fragment order (conv_regb.hip)
         assert p.precision != 0 and not pc.flat and pc.stride == 1 and (not in_norm or (pc.taps_y, pc.taps_x) == (3, 3))
         assert (pc.taps_y, pc.taps_x) in ((3, 3), (1, 5), (5, 1), (1, 1)) and (ho, wo) == (x.h, x.w)
-        frag = pc.frag(2 if p.precision == 1 else 1, f16=p.precision == 3)
+        frag = pc.frag(2 if p.precision == 1 else 1, f16=p.precision in (3, 4))
         p.wgt_frag = ptr(frag)
+        if p.precision == 4:
+            p.wgt_mx = ptr(pc.frag_mx())
         if tiles is None and p.tile_n not in (64, 128):
             p.tile_n = 128 if pc.cout_pad % 128 == 0 else 64
         if halo == 12:
