@@ -370,10 +370,12 @@ def conv_params(x, pc, out, co_off=0, epi=_lib.EPI_LINEAR, x2=None, c_split=0, e
         p.precision = 1                 # f16mx8 exists on the register-streamed kernel's multi-tap instances: elsewhere bf16x3
     if p.precision == 4 and halo == 8 and tiles is None and p.tile_n == 128:
         # two row tiles per wave have the registers for the deep fragment pipeline; four (8 x 16 pixels x 128 columns) spill:
-        # 1x5 / 5x1 layers take the 4 x 16-pixel x 128-column layout, 3x3 layers 64-column tiles
-        if (pc.taps_y, pc.taps_x) in ((1, 5), (5, 1)) and pc.cout_pad % 128 == 0 and _round_up(p.cout, 128) == pc.cout_pad:
+        # 1x5 / 5x1 layers take the 4 x 16-pixel x 128-column layout (WOFT_MX_ZR = 12; 64: 64-column tiles; 128: keep)
+        # (3x3 layers keep their 128-column choice: that instance spills 40 bytes and still beats 64 columns, 52.7 vs 58.8 us on fh1)
+        if (pc.taps_y, pc.taps_x) in ((1, 5), (5, 1)) and pc.cout_pad % 128 == 0 and _round_up(p.cout, 128) == pc.cout_pad \
+                and os.environ.get("WOFT_MX_ZR", "12") == "12":
             halo = p.halo = 12
-        else:
+        elif (pc.taps_y, pc.taps_x) != (3, 3) and os.environ.get("WOFT_MX_ZR", "12") == "64":
             p.tile_n = 64
     if halo in (8, 12):                 # weights streamed to registers in MFMA-fragment order (conv_regb.hip)
         assert p.precision != 0 and not pc.flat and pc.stride == 1 and (not in_norm or (pc.taps_y, pc.taps_x) == (3, 3))
