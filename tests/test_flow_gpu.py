@@ -424,7 +424,8 @@ def test_degenerate_inputs_vs_reference(golden_dir, name, precision, epe_mean, e
 
 @torch.no_grad()
 @pytest.mark.parametrize("precision,corr,epe_mean,epe_max,wtol", [("bf16x3", "otf", 1e-3, 1e-2, 1e-4), ("fp32", "otf", 1e-3, 1e-2, 1e-4),
-                                                                    ("bf16", "otf", 5e-2, 0.5, 5e-3), ("fp16", "otf", 1e-2, 0.1, 1e-3)])
+                                                                    ("bf16", "otf", 5e-2, 0.5, 5e-3), ("fp16", "otf", 1e-2, 0.1, 1e-3),
+                                                                    ("f16mx8", "otf", 1e-3, 1e-2, 1e-4)])
 def test_real_frames_720p_vs_reference(golden_dir, precision, corr, epe_mean, epe_max, wtol):
     """BASELINE config 2 at its REAL size on REAL frames: a 720 x 1280 pair of the reference's demo sequence (decoded
     frames stored in tests/golden/real_720p.npz), 12 iterations, against the reference's flow and weight logits -- 1/8
@@ -487,7 +488,8 @@ def _crc(a):
 
 @torch.no_grad()
 @pytest.mark.parametrize("precision,epe_mean,epe_max,wtol", [("bf16x3", 1e-3, 1e-2, 1e-4), ("fp32", 1e-3, 1e-2, 1e-4),
-                                                             ("bf16", 5e-2, 0.5, 5e-3), ("fp16", 1e-2, 0.1, 1e-3)])
+                                                             ("bf16", 5e-2, 0.5, 5e-3), ("fp16", 1e-2, 0.1, 1e-3),
+                                                             ("f16mx8", 1e-3, 1e-2, 1e-4)])
 def test_metric_resolution_1080p_vs_reference(golden_dir, precision, epe_mean, epe_max, wtol):
     """The metric's own configuration (BASELINE.json: 1080 x 1920, WeightedRAFT-full, 12 iterations) against the REFERENCE's
     outputs on the same pair (tests/golden/metric_1080p_it12.npz, oracle/gen_golden.py: gen_metric -- weighted_raft.py:186-290

@@ -22,7 +22,7 @@ def _corners_err(Ha, Hb, H, W):
 
 
 @pytest.mark.parametrize("cfg,estimator,precision", [("WOFT.py", "qr", None), ("WOFT_IRLS.py", "irls_huber2", None),
-                                                     ("WOFT.py", "qr", "fp32")])
+                                                     ("WOFT.py", "qr", "fp32"), ("WOFT.py", "qr", "f16mx8")])
 def test_tracker_matches_oracle(cfg, estimator, precision):
     """precision None: what the SHIPPED flow config selects (bf16x3: split-bf16 MFMA emulating fp32 -- the path a drop-in
     user and the bench run); "fp32": exact fp32 MFMA products.  Volume-free correlation lookup in both."""
