@@ -570,16 +570,20 @@ def test_split_packed_update_block_is_bit_identical(monkeypatch, precision, h, w
 
 
 @torch.no_grad()
-def test_f16mx8_operating_point_vs_reference(golden_dir):
+@pytest.mark.parametrize("packed", [True, False])
+def test_f16mx8_operating_point_vs_reference(golden_dir, monkeypatch, packed):
     """precision "f16mx8" (the update block's convolutions in two matrix-pipe passes per product: fp16 main term + two block-scaled
     fp8 cross terms; everything else bf16x3) against the REFERENCE's flow and weights at 12 and 32 iterations: inside the fp32
     budget of SURVEY 8d (EPE mean <= 1e-3 px, max <= 1e-2 px, sigmoid(w) <= 1e-4)."""
+    from woft_amd import engine
+    monkeypatch.setattr(engine, "PACKED_MX", packed)         # (MXP activations between the update block's f16mx8 layers, or fp32 ones)
     for name in ("flow_full_136x200_it12", "flow_full_136x200_it32"):
         g = np.load(golden_dir / f"{name}.npz")
         sd = synth.make_state_dict(seed=int(g["seed"]))
         fc = _flow_config(sd, int(g["iters"]), precision="f16mx8")
         flower = fc.of_class(fc)
         plan = flower.engine.plan(136, 200)
+        assert plan.packed == packed
         assert any(e[1].precision == 4 for e in plan.prog_iter if e[0] == "conv"), "no layer runs in f16mx8"
         flow, w = flower.compute_flow(g["img1"], g["img2"], mode="flow", do_sigmoid=False)
         torch.cuda.synchronize()

@@ -1407,3 +1407,43 @@ def test_gru_half_step_f16mx8(ops):
         res[prec] = (z.t.clone(), hn.t.clone())
     _close(res["f16mx8"][0], res["bf16x3"][0], 2e-5, what="z")
     _close(res["f16mx8"][1], res["bf16x3"][1], 3e-5, what="h")
+
+
+@pytest.mark.parametrize("kh,kw,cin,cmid,cout,h,w", [(3, 3, 128, 256, 192, 24, 40), (1, 5, 128, 128, 128, 17, 37)])
+def test_f16mx8_on_mxp_activations(ops, kh, kw, cin, cmid, cout, h, w):
+    """MXP (csrc/mxp.h: fp16 | fp8 | fp8 images of 32-channel blocks, the block scale re-derived from the fp16 plane): an f16mx8
+    producer writes it (out_fmt), an f16mx8 consumer reads it (in_fmt) -- the chain against fp64, beside the same chain on fp32
+    activations and in bf16x3; also woft_pack_split(precision 4) as the producer."""
+    E = ops._lib
+    g = torch.Generator().manual_seed(11)
+    amp = torch.exp(torch.rand(1, 1, h, w, generator=g) * 6 - 4)
+    x = torch.relu(torch.randn(1, cin, h, w, generator=g)) * amp
+    w1 = torch.randn(cmid, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
+    w2 = torch.randn(cout, cmid, kh, kw, generator=g) / math.sqrt(cmid * kh * kw)
+    mid = torch.relu(F.conv2d(x.double(), w1.double(), None, padding=1))
+    ref = F.conv2d(mid, w2.double(), None, padding=(kh // 2, kw // 2))
+    norm = F.conv2d(mid.abs(), w2.double().abs(), None, padding=(kh // 2, kw // 2)) + 1e-30
+    p1, p2 = ops.pack_conv(w1, None, padding=1), ops.pack_conv(w2, None, padding=(kh // 2, kw // 2))
+    xa = ops.act_from_nchw(x)
+    errs = {}
+    for name, prec, packed in (("bf16x3", "bf16x3", False), ("f16mx8", "f16mx8", False), ("f16mx8 on MXP", "f16mx8", True)):
+        m = ops.new_act(1, h, w, cmid, zero=True)
+        out = ops.new_act(1, h, w, cout, cs=ops._round_up(cout, 4), zero=True)
+        ops.run_conv(ops.conv_params(xa, p1, m, epi=E.EPI_RELU, precision=prec, out_fmt=int(packed)))
+        q = ops.conv_params(m, p2, out, precision=prec, in_fmt=int(packed))
+        assert q.halo in (8, 12) and q.precision == ops.PRECISION[prec]
+        ops.run_conv(q)
+        torch.cuda.synchronize()
+        e = (out.nchw().double().cpu() - ref) / norm
+        errs[name] = float(torch.sqrt((e ** 2).mean()))
+    mf, mp = ops.new_act(1, h, w, cmid, zero=True), ops.new_act(1, h, w, cmid, zero=True)
+    ops.run_conv(ops.conv_params(xa, p1, mf, epi=E.EPI_RELU, precision="f16mx8"))
+    ops.pack_split(mf.t, mp.t, "f16mx8")
+    out2 = ops.new_act(1, h, w, cout, cs=ops._round_up(cout, 4), zero=True)
+    ops.run_conv(ops.conv_params(mp, p2, out2, precision="f16mx8", in_fmt=1))
+    torch.cuda.synchronize()
+    e = (out2.nchw().double().cpu() - ref) / norm
+    errs["pack kernel"] = float(torch.sqrt((e ** 2).mean()))
+    print(f"{kh}x{kw} chain @{h}x{w}: rms error / sum|a||w| " + "  ".join(f"{k} {v:.2e}" for k, v in errs.items()))
+    assert errs["f16mx8 on MXP"] < 1.5 * errs["f16mx8"] + 1e-8 and errs["pack kernel"] < 1.5 * errs["f16mx8"] + 1e-8
+    assert errs["f16mx8"] < 6 * errs["bf16x3"]

@@ -23,7 +23,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math"
 # the C ABI entry points live in part 1 of conv.hip.
 PARTS = {"conv.hip": [("p1", ["-DWOFT_ONLY_PREC=1"]), ("p2", ["-DWOFT_ONLY_PREC=2"]), ("p3", ["-DWOFT_ONLY_PREC=3"])],
          "conv_regb.hip": [(f"p{k}_{pk}", [f"-DWOFT_ONLY_PREC={k}", f"-DWOFT_ONLY_PK={pk}"]) for k in (1, 2, 3) for pk in (0, 1)]
-                          + [("p4_0", ["-DWOFT_ONLY_PREC=4", "-DWOFT_ONLY_PK=0"])]}     # precision 4 (f16mx8): fp32 activations in
+                          + [(f"p4_{pk}", ["-DWOFT_ONLY_PREC=4", f"-DWOFT_ONLY_PK={pk}"]) for pk in (0, 1)]}   # precision 4 (f16mx8): fp32 / MXP in
 
 
 def _sources():

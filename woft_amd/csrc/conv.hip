@@ -1024,7 +1024,7 @@ int woft_conv_dispatch_p3(const woft_conv_params& p, const woft_conv_params* sec
 static int conv_check(const woft_conv_params& p) {
     if (p.in0 == nullptr || p.out == nullptr) return WOFT_EINVAL;
     if (p.precision < 0 || p.precision > 4) return WOFT_EINVAL;
-    if (p.precision == 4 && ((p.halo != 8 && p.halo != 12) || p.wgt_frag == nullptr || p.wgt_mx == nullptr || p.in_fmt != 0 ||
+    if (p.precision == 4 && ((p.halo != 8 && p.halo != 12) || p.wgt_frag == nullptr || p.wgt_mx == nullptr ||
                              p.in_norm != 0 || p.taps_y * p.taps_x == 1))
         return WOFT_EINVAL;                   // f16mx8: the register-streamed kernel's multi-tap instances only (woft_conv_params.wgt_mx)
     if (p.precision == 0 && p.wgt == nullptr) return WOFT_EINVAL;
@@ -1128,7 +1128,8 @@ int WOFT_CAT2(woft_conv_dispatch_p, WOFT_ONLY_PREC)(const woft_conv_params& p, c
 }
 
 #if WOFT_ONLY_PREC == 1
-int woft_conv_regb_launch_p4_0(const woft_conv_params& p, const woft_conv_params* second, void* stream);   // conv_regb.hip, part 4
+int woft_conv_regb_launch_p4_0(const woft_conv_params& p, const woft_conv_params* second, void* stream);   // conv_regb.hip, parts 4:
+int woft_conv_regb_launch_p4_1(const woft_conv_params& p, const woft_conv_params* second, void* stream);   // fp32 / MXP activations in
 
 static int conv_dispatch_f16mx8(const woft_conv_params& p, const woft_conv_params* second, void* stream) {
     for (const woft_conv_params* q : {&p, second}) {
@@ -1138,7 +1139,7 @@ static int conv_dispatch_f16mx8(const woft_conv_params& p, const woft_conv_param
         const int64_t cs_max = (q->in1 != nullptr && q->cs1 > q->cs0) ? q->cs1 : q->cs0;
         if ((int64_t)q->n_img * q->h * q->w * cs_max >= (1ll << 31)) return WOFT_EINVAL;     // 32-bit element offsets
     }
-    return woft_conv_regb_launch_p4_0(p, second, stream);
+    return p.in_fmt != 0 ? woft_conv_regb_launch_p4_1(p, second, stream) : woft_conv_regb_launch_p4_0(p, second, stream);
 }
 
 static int conv_dispatch(const woft_conv_params& p, const woft_conv_params* second, void* stream) {

@@ -124,6 +124,20 @@ struct GPtr {
     __device__ __forceinline__ f32x4 ld4(int64_t off) const { return *(const g_f32x4*)(a + 4 * (uint64_t)off); }
     __device__ __forceinline__ void st4(int64_t off, f32x4 v) const { *(g_f32x4*)(a + 4 * (uint64_t)off) = v; }
     __device__ __forceinline__ void st1(int64_t off, float v) const { *(g_f32*)(a + 4 * (uint64_t)off) = v; }
+#ifdef WOFT_EPI_MXP
+    // (conv_regb.hip's precision-4 parts only, mxp.h) the lane's share of its 32-channel block's MXP image: 8 + 4 + 4 bytes; all
+    // eight lanes of the block call together
+    __device__ __forceinline__ void st_mxp(int64_t row_off, int ch, f32x4 y) const {
+        typedef __attribute__((address_space(1))) uint32_t g_u32;
+        const MxpWords w = mxp_pack(y);
+        const uint64_t blk = a + 4 * (uint64_t)(row_off + (ch & ~31));
+        const uint32_t j = (uint32_t)(ch & 31) >> 2;
+        *(g_u32*)(blk + 8 * j) = w.h0;
+        *(g_u32*)(blk + 8 * j + 4) = w.h1;
+        *(g_u32*)(blk + 64 + 4 * j) = w.qa;
+        *(g_u32*)(blk + 96 + 4 * j) = w.ql;
+    }
+#endif
 };
 __device__ __forceinline__ GPtr keep_gptr(const void* p) { return GPtr{keep_sgpr((uint64_t)(uintptr_t)p)}; }
 
@@ -201,6 +215,9 @@ __device__ __forceinline__ f32x4 epi_finish(const EpiRegs& a, const f32x4 v, con
             if (n >= a.split) {                        // split % 4 == 0 (validated): whole vector is r
 #pragma unroll
                 for (int e = 0; e < 4; ++e) y[e] *= o.o0[e];
+#ifdef WOFT_EPI_MXP
+                if (a.pk1 == 4) { if (!a.no_store) a.out1.st_mxp(m * a.ldo1, n - a.split, y); } else
+#endif
                 if (!a.no_store) a.out1.st4(m * a.ldo1 + (n - a.split), a.pk1 != 0 ? pack_split_rt(y, a.pk1) : y);
                 stored = true;
             }
@@ -209,6 +226,9 @@ __device__ __forceinline__ f32x4 epi_finish(const EpiRegs& a, const f32x4 v, con
 #pragma unroll
             for (int e = 0; e < 4; ++e) y[e] = (1.f - o.o1[e]) * o.o0[e] + o.o1[e] * tanh_t<FAST>(y[e]);
             // (the state in both forms: fp32 for the next gates' element-wise reads, split-packed for the convs that read it)
+#ifdef WOFT_EPI_MXP
+            if (a.pk1 == 4) { if (!a.no_store) a.out1.st_mxp(m * a.ldo1, n, y); } else
+#endif
             if (a.pk1 != 0 && !a.no_store) a.out1.st4(m * a.ldo1 + n, pack_split_rt(y, a.pk1));
             break;
         default: break;
@@ -220,6 +240,9 @@ __device__ __forceinline__ f32x4 epi_finish(const EpiRegs& a, const f32x4 v, con
             for (int e = 1; e < 4; ++e)
                 if (e >= nrag) y[e] = o.o0[e - nrag];
         }
+#ifdef WOFT_EPI_MXP
+        if (a.pk == 4) a.out.st_mxp(m * a.ldo, a.co_off + n, y); else
+#endif
         a.out.st4(m * a.ldo + a.co_off + n, pack_split_rt(y, a.pk));
     } else if (nok) {
         a.out.st4(m * a.ldo + a.co_off + n, y);

@@ -18,6 +18,10 @@
 //           the second), for layers with too few 128-wide tiles.
 #include <type_traits>
 
+#if defined(WOFT_ONLY_PREC) && WOFT_ONLY_PREC == 4
+#define WOFT_EPI_MXP 1                 // the shared epilogue's MXP stores exist in these parts only (mxp.h)
+#include "mxp.h"
+#endif
 #include "conv_common.h"
 #include "halo_map.h"
 
@@ -71,7 +75,7 @@ __global__ __launch_bounds__(256, 2) void conv_regb_kernel(const woft_conv_param
     constexpr int MT = MX ? 16 : TERMS;                                   // conversion / MFMA type of the (main) term
     constexpr int TAPS = KY * KX;
     constexpr int NPAIR = (TAPS + 1) / 2;                                 // MX: tap pairs per chunk (an odd last tap pairs with zero weights)
-    static_assert(!MX || (!PK && !NORM), "f16mx8: fp32 activations in, no norm-on-load");
+    static_assert(!MX || !NORM, "f16mx8: no norm-on-load");
     // CU: chunks per unrolled group (the ring slot of step s = chunk * TAPS + tap must be a compile-time constant:
     // (CU * TAPS) % NBUF == 0; multi-tap layers: CU = 1, TAPS % NBUF == 0; 1x1 layers: TAPS = 1, CU = NBUF).
     // HD: how many chunks ahead the input tile is requested (1x1: a chunk is a single K step, too short to cover HBM latency)
@@ -147,6 +151,28 @@ __global__ __launch_bounds__(256, 2) void conv_regb_kernel(const woft_conv_param
                 x[e] = y;
             }
         }
+#ifdef WOFT_EPI_MXP
+        if constexpr (PK && MX) {
+            // MXP input (mxp.h): the row's 128 bytes are [fp16 x 32 | fp8(a) x 32 | fp8(a - fp16(a)) x 32] -- lanes v = 0 .. 3 carry the
+            // fp16 plane's 16-byte pieces, 4 / 5 the first fp8 plane's, 6 / 7 the second's: one LDS write each, no conversion; the
+            // block's scale is re-derived from the fp16 magnitudes (the producer's rule) and written by lane 0.
+            typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+            char* qpa = (char*)(As + A_PLANE) + ht * QPITCH;
+            char* fp = (char*)(As + ht * LDB);
+            char* dst = v < 4 ? fp + 16 * v : (v < 6 ? qpa + 16 * (v - 4) : qpa + 2 * Q_PLANE + 16 * (v - 6));
+            *(f32x4*)dst = x;
+            const u32x4_t w = __builtin_bit_cast(u32x4_t, x) & 0x7fff7fffu;
+            uint32_t m = max(max(w[0] & 0xffffu, w[0] >> 16), max(w[1] & 0xffffu, w[1] >> 16));
+            m = max(m, max(max(w[2] & 0xffffu, w[2] >> 16), max(w[3] & 0xffffu, w[3] >> 16)));
+            m = dpp_max8_u32(v < 4 ? m : 0u);
+            if (v == 0) {
+                const uint32_t sa = (m >> 10) + 105u;
+                qpa[32] = (char)sa;
+                (qpa + 2 * Q_PLANE)[32] = (char)(sa - 11u);
+            }
+            return;
+        }
+#endif
         if constexpr (PK) {                              // (the zero row supplied the padding: a plain copy)
             static_assert(!NORM, "split-packed inputs are final activations");
             *(bf16x4*)(As + ht * LDB + 4 * v) = packed_hi(x);
@@ -633,7 +659,11 @@ int launch_regb(const woft_conv_params& p, const woft_conv_params* second, hipSt
     REGB_TAPS(16);
 #elif WOFT_ONLY_PREC == 4
     // f16mx8: the multi-tap instances only (no norm-on-load, no 1x1)
-    if (p.in_norm != 0 || p.wgt_mx == nullptr) return WOFT_EINVAL;
+    if (p.in_norm != 0 || p.wgt_mx == nullptr || pb.wgt_mx == nullptr) return WOFT_EINVAL;
+    for (const woft_conv_params* q : {&p, &pb})      // MXP outputs (out_fmt with this precision): whole 32-channel blocks
+        if (((q->out_fmt & 1) != 0 && (q->co_off % 32 != 0 || q->ldo % 32 != 0)) ||
+            ((q->out_fmt & 2) != 0 && (q->ldo1 % 32 != 0 || q->split % 32 != 0)))
+            return WOFT_EINVAL;
     if (p.taps_y == 3 && p.taps_x == 3) REGB(3, 3, 28, 3, 2);
     else if (p.taps_y == 1 && p.taps_x == 5) REGB(1, 5, 28, 5, 3);
     else if (p.taps_y == 5 && p.taps_x == 1) REGB(5, 1, 28, 5, 3);

@@ -1,6 +1,7 @@
 // Streaming (HBM-bound) helpers: input normalisation, InstanceNorm finalize/apply, 2x2 pooling.
 #include "common.h"
 #include "halo_map.h"
+#include "mxp.h"
 
 namespace {
 
@@ -339,11 +340,32 @@ extern "C" int woft_feature_pyramid(const float* in, int32_t h, int32_t w, int32
     return woft_launch_status();
 }
 
+// MXP (precision 4, mxp.h): one thread per four channels, the eight threads of a 32-channel block adjacent
+__global__ void pack_mxp_kernel(const float* __restrict__ x, int64_t rows, int32_t c4, int32_t ldx, float* __restrict__ out, int32_t ldo) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * c4) return;                       // (c4 % 8 == 0, 256 threads per block: whole 8-lane groups leave together)
+    const int64_t r = i / c4;
+    const int g = (int)(i - r * c4);
+    const MxpWords w = mxp_pack(*(const f32x4*)(x + r * ldx + 4 * g));
+    char* blk = (char*)(out + r * ldo + 32 * (g >> 3));
+    const int j = g & 7;
+    *(uint32_t*)(blk + 8 * j) = w.h0;
+    *(uint32_t*)(blk + 8 * j + 4) = w.h1;
+    *(uint32_t*)(blk + 64 + 4 * j) = w.qa;
+    *(uint32_t*)(blk + 96 + 4 * j) = w.ql;
+}
+
 extern "C" int woft_pack_split(const float* x, int64_t rows, int32_t channels, int32_t ldx, int32_t precision, float* out,
                                int32_t ldo, void* stream) {
     if (!x || !out || rows <= 0 || channels <= 0 || channels % 4 != 0 || ldx % 4 != 0 || ldo % 4 != 0 || ldx < channels ||
-        ldo < channels || precision < 1 || precision > 3)
+        ldo < channels || precision < 1 || precision > 4)
         return WOFT_EINVAL;
+    if (precision == 4) {                             // MXP: whole 32-channel blocks, not in place
+        if (channels % 32 != 0 || ldx % 32 != 0 || ldo % 32 != 0 || x == out) return WOFT_EINVAL;
+        hipLaunchKernelGGL(pack_mxp_kernel, dim3((unsigned)ceil_div64(rows * (channels / 4), 256)), dim3(256), 0, (hipStream_t)stream, x, rows,
+                           channels / 4, ldx, out, ldo);
+        return woft_launch_status();
+    }
     const int64_t n = rows * (channels / 4);
     const dim3 grid((unsigned)ceil_div64(n, 256));
     hipStream_t s = (hipStream_t)stream;

@@ -51,6 +51,12 @@ GRU_FUSE = os.environ.get("WOFT_GRU_FUSE", "0")          # "1": always, "auto": 
 # store) in three A/B runs: the main loops are bound by the matrix pipe that the two resident waves of a SIMD share, not by vector
 # issue.
 PACKED_ACTS = os.environ.get("WOFT_PACKED", "0") != "0"
+# ... and in precision "f16mx8": MXP (csrc/mxp.h: fp16 | fp8 | fp8 images of 32-channel blocks) between the layers that both run on the
+# register-streamed kernel's f16mx8 instances -- there the loader's conversion is ~60 vector instructions and ~25 registers per float4
+# in a main loop that is NOT matrix-pipe bound.  convc1 / convf1 (per-tap kernel) keep fp32 outputs.  (WOFT_PACKED_MX)
+# OPT-IN like the bf16x3 form, and for the same reason: measured -1 % frames/s (iteration 0.542 -> 0.560 ms: the three stores per lane of
+# the producing epilogues cost more than the copy-only loaders save; the conversion was not what held the f16mx8 main loops back either)
+PACKED_MX = os.environ.get("WOFT_PACKED_MX", "0") != "0"
 
 
 def _ru(x, m):
@@ -310,7 +316,8 @@ class _Plan:
         # split-packed update block (see PACKED_ACTS): packed copies of the GRU states; c1 / cf / fl1 / rh / the motion
         # channels of xbuf simply hold the packed form.  Decided per plan: every layer that would read a packed tensor must
         # select a kernel that takes one (the register-streamed or the per-tap kernel)
-        self.packed = bool(PACKED_ACTS and self.prec != "fp32" and not sp.small and ops.USE_REGB and ops.USE_HALO)
+        self.packed = bool((PACKED_MX if self.prec == "f16mx8" else PACKED_ACTS) and self.prec != "fp32" and not sp.small
+                           and ops.USE_REGB and ops.USE_HALO)
         self.net0p = self.hAp = self.hBp = None
         if self.packed:
             self.net0p, self.hAp, self.hBp = (new_act(1, hf, wf, sp.hdim, zero=True) for _ in range(3))
@@ -546,6 +553,7 @@ class _Plan:
         hd = sp.hdim
         h_in = self.net0 if first else self.hB
         pk = int(self.packed)               # split-packed activations between the update block's layers (PACKED_ACTS)
+        pk1 = 0 if self.prec == "f16mx8" else pk   # ... of the per-tap kernel's layers (convc1, convf1): fp32 in f16mx8 (no MXP epilogue there)
         packed_of = {id(self.net0): self.net0p, id(self.hA): self.hAp, id(self.hB): self.hBp}
         prog = [("lookup", self.lookup)]
         if sp.small:            # SmallMotionEncoder update.py:71-77: cor(96) | flo(32) -> 80, cat flow
@@ -554,10 +562,10 @@ class _Plan:
                      ("conv", cp(self.fl1, e.convf2, self.cf, co_off=96, epi=EPI.EPI_RELU)),
                      ("conv", cp(self.cf, e.convm, self.xbuf, co_off=sp.cdim, epi=EPI.EPI_RELU))]
         else:                   # BasicMotionEncoder update.py:89-97: cor(192) | flo(64) -> 126, cat flow
-            flo = [("conv", cp(self.flow4, e.convf1, self.fl1, epi=EPI.EPI_RELU, out_fmt=pk), "convf1"),
-                   ("conv", cp(self.fl1, e.convf2, self.cf, co_off=192, epi=EPI.EPI_RELU, in_fmt=pk, out_fmt=pk), "convf2")]
-            cor = [("conv", cp(self.corr, e.convc1, self.c1, epi=EPI.EPI_RELU, out_fmt=pk), "convc1"),
-                   ("conv", cp(self.c1, e.convc2, self.cf, co_off=0, epi=EPI.EPI_RELU, in_fmt=pk, out_fmt=pk), "convc2")]
+            flo = [("conv", cp(self.flow4, e.convf1, self.fl1, epi=EPI.EPI_RELU, out_fmt=pk1), "convf1"),
+                   ("conv", cp(self.fl1, e.convf2, self.cf, co_off=192, epi=EPI.EPI_RELU, in_fmt=pk1, out_fmt=pk), "convf2")]
+            cor = [("conv", cp(self.corr, e.convc1, self.c1, epi=EPI.EPI_RELU, out_fmt=pk1), "convc1"),
+                   ("conv", cp(self.c1, e.convc2, self.cf, co_off=0, epi=EPI.EPI_RELU, in_fmt=pk1, out_fmt=pk), "convc2")]
             if SIDE_STREAM:     # the flow branch (reads flow4, writes fl1 and cf[:, 192:]) beside lookup + correlation branch
                 prog = [("fork", flo)] + prog + cor + [("join", None)]
             elif PAIR_BRANCHES:

@@ -366,7 +366,7 @@ def conv_params(x, pc, out, co_off=0, epi=_lib.EPI_LINEAR, x2=None, c_split=0, e
     p.halo = halo
     p.wgt_frag = None
     p.wgt_mx = None
-    if p.precision == 4 and not (halo in (8, 12) and pc.taps_y * pc.taps_x > 1 and not in_norm and not in_fmt):
+    if p.precision == 4 and not (halo in (8, 12) and pc.taps_y * pc.taps_x > 1 and not in_norm):
         p.precision = 1                 # f16mx8 exists on the register-streamed kernel's multi-tap instances: elsewhere bf16x3
     if p.precision == 4 and halo == 8 and tiles is None and p.tile_n == 128:
         # two row tiles per wave have the registers for the deep fragment pipeline; four (8 x 16 pixels x 128 columns) spill:
@@ -395,6 +395,9 @@ def conv_params(x, pc, out, co_off=0, epi=_lib.EPI_LINEAR, x2=None, c_split=0, e
             p.tile_n = 64
         p.cout_pad = pc.cout_pad if stats is not None else _round_up(p.cout, p.tile_n)
     p.in_fmt, p.out_fmt = int(in_fmt), int(out_fmt)
+    if (p.in_fmt or p.out_fmt) and PRECISION.get(precision, precision) == 4 and p.precision != 4:
+        # f16mx8's packed form is MXP (csrc/mxp.h): written and read by the register-streamed kernel's f16mx8 instances only
+        raise ValueError("MXP activations: this layer does not run in f16mx8")
     if p.in_fmt and (p.precision == 0 or halo not in (0, 8, 12) or pc.flat or in_norm):
         raise ValueError(f"split-packed input: not supported by the kernel this layer selects (halo {halo})")
     if p.in_fmt and halo in (8, 12) and p.in_fmt != (3 if x2 is not None else 1):
@@ -501,6 +504,7 @@ def gru_ok(zr, q):
 def pack_split(x, out, precision, channels=None):
     """fp32 activation rows x (tensor [rows][ld]) -> split-packed rows (woft_pack_split); in place when out is x."""
     c = channels or x.shape[1]
+    assert PRECISION.get(precision, precision) != 4 or x.data_ptr() != out.data_ptr(), "MXP packing is not in place"
     check(_lib.load().woft_pack_split(ptr(x), x.shape[0], c, x.stride(0), PRECISION.get(precision, precision), ptr(out),
                                       out.stride(0), stream_ptr()), "woft_pack_split")
 
