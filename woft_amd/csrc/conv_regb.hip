@@ -379,6 +379,9 @@ __global__ __launch_bounds__(256, 2) void conv_regb_kernel(const woft_conv_param
     //      k half 1 of tap t is requested before the MFMAs of its k half 0, k half 0 of tap t + 1 before the MFMAs of k half 1 --;
     //      the fp8 fragments go row tile by row tile, one tile ahead; the fp8 weights of pair p + 1 are requested right after pair
     //      p's MFMAs consumed the single register set (two taps of lead).
+#ifndef MX_FENCE
+#define MX_FENCE __builtin_amdgcn_sched_barrier(0)
+#endif
     auto run_chunk_mx = [&](int chunk, auto more_tag) {
         constexpr bool more = decltype(more_tag)::value;
         static_assert(CU == 1 && HD == 1, "f16mx8: multi-tap layers");
@@ -443,7 +446,7 @@ __global__ __launch_bounds__(256, 2) void conv_regb_kernel(const woft_conv_param
                             (load_q(std::integral_constant<int, pr>{}, std::integral_constant<int, I>{}), ...);
                         }(std::make_integer_sequence<int, TM>{});
                 }
-                __builtin_amdgcn_sched_barrier(0);
+                MX_FENCE;
                 // DEEP: the next chunk's halo (requested at tap 0) is converted and written to the other buffer ONE thread-row per half
                 // tap over the last RH half taps, its ~80 vector / cross-lane / LDS instructions in the issue shadow of this half
                 // tap's MFMAs -- as one block after the last MFMA it cost ~3 k of a 9.4 k-cycle chunk (stamps, first version)
@@ -461,14 +464,14 @@ __global__ __launch_bounds__(256, 2) void conv_regb_kernel(const woft_conv_param
                         __builtin_amdgcn_sched_group_barrier(0x002, 24, 0);     // then a share of the row's vector work
                         __builtin_amdgcn_sched_group_barrier(0x080, 4, 0);      // and of its cross-lane / LDS instructions
                     }
-                    __builtin_amdgcn_sched_barrier(0);
+                    MX_FENCE;
                 }
                 if constexpr (ILX && more && rowb >= 0 && rowb < RH)
                     store_halo_row(smem + ((chunk + 1) & 1) * A_ELEMS, std::integral_constant<int, 0>{}, std::integral_constant<int, (rowb >= 0 && rowb < RH) ? rowb : 0>{});
                 if constexpr (!AM2) {
-                    __builtin_amdgcn_sched_barrier(0);
+                    MX_FENCE;
                     if constexpr (tap + 1 < TAPS) load_am(std::integral_constant<int, tap + 1>{}, std::integral_constant<int, 0>{});
-                    __builtin_amdgcn_sched_barrier(0);
+                    MX_FENCE;
                 }
 #pragma unroll
                 for (int i = 0; i < TM; ++i) acc[i] = mma16<16>(am[ab][1][i], bq[slot][0][1], acc[i]);
@@ -495,7 +498,7 @@ __global__ __launch_bounds__(256, 2) void conv_regb_kernel(const woft_conv_param
                     // the NEXT pair's fp8 weights into the register set these MFMAs just read
                     fetch_mx(chunk * NPAIR + pr + 1, std::integral_constant<int, 0>{});
                 }
-                __builtin_amdgcn_sched_barrier(0);
+                MX_FENCE;
             }(), ...);
         }(std::make_integer_sequence<int, TAPS>{});
         // next chunk's halo -> the other buffer (its loads had the whole chunk to land)
