@@ -440,7 +440,7 @@ __global__ __launch_bounds__(256, 2) void conv_regb_kernel(const woft_conv_param
                 if constexpr (DEEP) {
                     // the pair's fp8 fragments a tap ahead (at the pair's first tap) where the registers allow it: the 1x5 / 5x1 instances
                     // (41.7 -> 37.7 us on the GRU's q conv); the 3x3 instance spills with the longer live range (85 -> 125 us)
-                    constexpr bool QEARLY = TAPS <= 5;
+                    constexpr bool QEARLY = TAPS <= 5 && TY == 4;     // (the 8 x 16-pixel 1x5 / 5x1 instances spill with it)
                     if constexpr (QEARLY ? (tap & 1) == 0 : pair_end)
                         [&]<int... I>(std::integer_sequence<int, I...>) {
                             (load_q(std::integral_constant<int, pr>{}, std::integral_constant<int, I>{}), ...);
