@@ -570,13 +570,14 @@ def test_split_packed_update_block_is_bit_identical(monkeypatch, precision, h, w
 
 
 @torch.no_grad()
-@pytest.mark.parametrize("packed", [True, False])
-def test_f16mx8_operating_point_vs_reference(golden_dir, monkeypatch, packed):
+@pytest.mark.parametrize("packed,layers", [(True, "all"), (False, "all"), (False, "auto")])
+def test_f16mx8_operating_point_vs_reference(golden_dir, monkeypatch, packed, layers):
     """precision "f16mx8" (the update block's convolutions in two matrix-pipe passes per product: fp16 main term + two block-scaled
     fp8 cross terms; everything else bf16x3) against the REFERENCE's flow and weights at 12 and 32 iterations: inside the fp32
     budget of SURVEY 8d (EPE mean <= 1e-3 px, max <= 1e-2 px, sigmoid(w) <= 1e-4)."""
-    from woft_amd import engine
+    from woft_amd import engine, ops
     monkeypatch.setattr(engine, "PACKED_MX", packed)         # (MXP activations between the update block's f16mx8 layers, or fp32 ones)
+    monkeypatch.setattr(ops, "MX_LAYERS", layers)            # every multi-tap layer / the default: the 3x3 layers with 256 input channels
     for name in ("flow_full_136x200_it12", "flow_full_136x200_it32"):
         g = np.load(golden_dir / f"{name}.npz")
         sd = synth.make_state_dict(seed=int(g["seed"]))
@@ -584,7 +585,8 @@ def test_f16mx8_operating_point_vs_reference(golden_dir, monkeypatch, packed):
         flower = fc.of_class(fc)
         plan = flower.engine.plan(136, 200)
         assert plan.packed == packed
-        assert any(e[1].precision == 4 for e in plan.prog_iter if e[0] == "conv"), "no layer runs in f16mx8"
+        n_mx = sum(q.precision == 4 for e in plan.prog_iter if e[0] in ("conv", "conv2") for q in (e[1] if e[0] == "conv2" else (e[1],)))
+        assert n_mx >= (5 if layers == "all" else 3), f"{n_mx} update-block layers run in f16mx8"
         flow, w = flower.compute_flow(g["img1"], g["img2"], mode="flow", do_sigmoid=False)
         torch.cuda.synchronize()
         m, mx = _epe(flow, torch.from_numpy(g["flow_up"])[0])

@@ -1355,11 +1355,12 @@ def test_gru_convs_on_the_per_tap_kernel(ops, kh, kw, h, w, precision):
 @pytest.mark.parametrize("kh,kw,cin,cout,h,w,tiles", [(3, 3, 256, 192, 24, 40, None), (3, 3, 128, 64, 17, 37, None), (1, 5, 128, 128, 24, 40, None),
                                                       (5, 1, 128, 128, 9, 16, None), (3, 3, 256, 126, 135, 240, None),
                                                       (3, 3, 128, 256, 24, 40, (128, 128)), (1, 5, 64, 128, 19, 37, None)])
-def test_conv_f16mx8(ops, kh, kw, cin, cout, h, w, tiles):
+def test_conv_f16mx8(ops, monkeypatch, kh, kw, cin, cout, h, w, tiles):
     """The two-pass fp32-emulating product on the register-streamed kernel against fp64: error scale of bf16x3 (measured 2.2-2.3 x
     its error on the matrix cores, tools/micro/mx_split_probe.hip) -- far below fp16's (67 x) and bf16's (530 x); ReLU-like
     activations with a wide per-pixel amplitude range (the block scales' job), zero rows (scale byte 0) and ragged tiles."""
     E = ops._lib
+    monkeypatch.setattr(ops, "MX_LAYERS", "all")             # (the engine's default keeps f16mx8 to the layers it is faster on)
     g = torch.Generator().manual_seed(7)
     amp = torch.exp(torch.rand(1, 1, h, w, generator=g) * 8 - 6)                    # per-pixel amplitude over 3.5 decades
     x = torch.relu(torch.randn(1, cin, h, w, generator=g)) * amp
@@ -1384,9 +1385,10 @@ def test_conv_f16mx8(ops, kh, kw, cin, cout, h, w, tiles):
     assert errs["f16mx8"] < 6 * errs["bf16x3"] and errs["f16mx8"] < 0.2 * errs["fp16"]
 
 
-def test_gru_half_step_f16mx8(ops):
+def test_gru_half_step_f16mx8(ops, monkeypatch):
     """Two-source GRU convs with their gate epilogues in f16mx8 against the bf16x3 launches."""
     E = ops._lib
+    monkeypatch.setattr(ops, "MX_LAYERS", "all")
     n, h, w, kh, kw = 1, 24, 40, 1, 5
     hprev = torch.tanh(_rand(n, 128, h, w, seed=4))
     xin = torch.relu(_rand(n, 128, h, w, seed=5))
@@ -1410,11 +1412,12 @@ def test_gru_half_step_f16mx8(ops):
 
 
 @pytest.mark.parametrize("kh,kw,cin,cmid,cout,h,w", [(3, 3, 128, 256, 192, 24, 40), (1, 5, 128, 128, 128, 17, 37)])
-def test_f16mx8_on_mxp_activations(ops, kh, kw, cin, cmid, cout, h, w):
+def test_f16mx8_on_mxp_activations(ops, monkeypatch, kh, kw, cin, cmid, cout, h, w):
     """MXP (csrc/mxp.h: fp16 | fp8 | fp8 images of 32-channel blocks, the block scale re-derived from the fp16 plane): an f16mx8
     producer writes it (out_fmt), an f16mx8 consumer reads it (in_fmt) -- the chain against fp64, beside the same chain on fp32
     activations and in bf16x3; also woft_pack_split(precision 4) as the producer."""
     E = ops._lib
+    monkeypatch.setattr(ops, "MX_LAYERS", "all")
     g = torch.Generator().manual_seed(11)
     amp = torch.exp(torch.rand(1, 1, h, w, generator=g) * 6 - 4)
     x = torch.relu(torch.randn(1, cin, h, w, generator=g)) * amp

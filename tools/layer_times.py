@@ -65,7 +65,7 @@ def main():
             desc = kind
             if kind in ("conv", "conv2"):
                 desc = " + ".join(f"conv {p.taps_y}x{p.taps_x} s{p.stride} {p.n_img}x{p.h}x{p.w} cin {p.cin_pad} -> {p.cout}"
-                                  f" tile {p.tile_m}x{p.tile_n} halo {p.halo} epi {p.epi}{' flat' if p.flat else ''}"
+                                  f" tile {p.tile_m}x{p.tile_n} halo {p.halo} epi {p.epi}{' flat' if p.flat else ''}{' mx' if p.precision == 4 else ''}"
                                   for p in (arg if kind == "conv2" else [arg]))
             print(f"  {name:7s}[{idx:2d}] {t:9.1f} us  {desc}")
         print(f"{name}: {sub / 1e3:.3f} ms x {mult}")

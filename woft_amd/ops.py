@@ -219,6 +219,9 @@ def fold_bn(weight, bias, bn_w, bn_b, mean, var, eps=1e-5):
 # "f16mx8" (round 4): fp16 main term + two block-scaled fp8 cross terms -- an fp32-emulating product in two matrix-pipe passes instead
 # of bf16x3's three (woft_conv_params.wgt_mx); layers whose kernel has no such instance run in bf16x3
 PRECISION = {"fp32": 0, "bf16x3": 1, "bf16": 2, "fp16": 3, "f16mx8": 4}
+# which layers precision "f16mx8" actually runs in two passes: "auto" (default) = where it measured faster than bf16x3; "all" = every
+# multi-tap layer of the register-streamed kernel (the kernel tests use it)
+MX_LAYERS = os.environ.get("WOFT_MX_LAYERS", "auto")
 SLOW_GATES = os.environ.get("WOFT_SLOW_GATES", "0") != "0"     # developer A/B: libm sigmoid / tanh in the conv epilogues
 USE_HALO = os.environ.get("WOFT_HALO", "1") != "0"
 USE_REGB = os.environ.get("WOFT_REGB", "1") != "0"
@@ -368,6 +371,14 @@ def conv_params(x, pc, out, co_off=0, epi=_lib.EPI_LINEAR, x2=None, c_split=0, e
     p.wgt_mx = None
     if p.precision == 4 and not (halo in (8, 12) and pc.taps_y * pc.taps_x > 1 and not in_norm):
         p.precision = 1                 # f16mx8 exists on the register-streamed kernel's multi-tap instances: elsewhere bf16x3
+    if p.precision == 4 and MX_LAYERS == "auto":
+        # measured per layer at 1080p (profiles/r04_layer_times_f16mx8*.txt against ..._bf16x3.txt): the 3x3 layers are 8-10 % faster in
+        # f16mx8 than in bf16x3 (motion encoder, flow head, context encoder); the GRU's 1x5 / 5x1 z|r layers are 4-7 % slower (four row
+        # tiles per wave do not fit the 256 registers: half-size workgroups), the q layers equal, and the 128-column instance with a
+        # full-width store epilogue (mask head conv: spills) 75 vs 55 us -> those stay bf16x3
+        tn_mx = p.tile_n if p.tile_n in (64, 128) else (128 if pc.cout_pad % 128 == 0 else 64)
+        if (pc.taps_y, pc.taps_x) != (3, 3) or (tn_mx == 128 and pc.cout_pad % 128 == 0 and epi != _lib.EPI_FLOWHEAD):
+            p.precision = 1
     if p.precision == 4 and halo == 8 and tiles is None and p.tile_n == 128:
         # two row tiles per wave have the registers for the deep fragment pipeline; four (8 x 16 pixels x 128 columns) spill:
         # 1x5 / 5x1 layers take the 4 x 16-pixel x 128-column layout (WOFT_MX_ZR = 12; 64: 64-column tiles; 128: keep)
