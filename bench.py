@@ -454,7 +454,7 @@ def main():
         for prec in ("fp32", "bf16x3", "bf16", "fp16", "f16mx8"):
             if prec == args.precision:
                 continue
-            r, trk, pl, _ = side_run(K2 if prec == "fp32" else min(K, 8), precision=prec)
+            r, trk, pl, _ = side_run(K2 if prec in ("fp32", "f16mx8") else min(K, 8), precision=prec)
             _, dst, _ = trk.flower.compute_flow(template, frames[0], mode="TC", do_sigmoid=True)
             tc_gpu[prec] = dst.cpu()
             r["correlation"] = trk.flower.engine.corr
@@ -639,6 +639,7 @@ def main():
     cfgd["fps_bf16x3_full_head"] = r1(g(out, "reference_work", "bf16x3_full_weight_head", "frames_per_s"))
     cfgd["fps_strict_fp32"] = r1(g(out, "strict_fp32", "frames_per_s"))
     cfgd["fps_host_frames"] = r1(g(out, "host_frames", "frames_per_s"))
+    cfgd["fps_f16mx8"] = r1(g(out, "alt_precisions", "f16mx8", "frames_per_s"))     # (opt-in: 2 matrix-pipe passes per product on the 3x3 layers)
     cfgd["epe_mean_px"] = g(out, "flow_epe_vs_cpu_oracle", "mean_px")
     cfgd["epe_gate_passed"] = out["epe_gate"]["passed"]
     print(json.dumps(out), flush=True)
