@@ -494,7 +494,7 @@ def main():
         drop()
         # each flow's launch list replayed as ONE hipGraph (flow config key `graph`; the timed run launches eagerly
         # because its per-launch HIP events cannot live inside a graph): same tracks, short run
-        r, trk, pl, _ = side_run(min(K, 8), check_tracks=True, graph=True)
+        r, trk, pl, _ = side_run(K2, check_tracks=True, graph=True)
         r["graphs_replayed"] = bool(any(g is not None for g in getattr(pl, "_graphs", {}).values()))
         out["alt_graph"] = r
         del trk, pl

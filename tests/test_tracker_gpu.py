@@ -540,3 +540,37 @@ def test_host_frames_through_pinned_staging_equal_device_frames():
     assert [l for _, l in a] == [l for _, l in b] and any(l for _, l in a)
     for (Ha, _), (Hb, _) in zip(a, b):
         assert np.array_equal(Ha, Hb)
+
+
+@pytest.mark.gpu
+@torch.no_grad()
+def test_graph_replay_keeps_the_deferred_weight_head():
+    """Flow config key `graph` with the tracker's default weight head (evaluated after the draw, under the drawn correspondences only):
+    the flow's launch list up to the upsampling is replayed as one hipGraph, the deferred head follows eagerly -- same poses as the
+    all-eager tracker, bit for bit.  (Until round 4 the graph path switched the deferral off: its flows did the head on the whole
+    mask region, which is what made `alt_graph` read 5 % below the eager run.)"""
+    from pytracking.utils.config import load_config
+    H, W, iters = 128, 160, 3
+    sd = synth.make_state_dict(seed=7)
+    template = synth.make_template(H, W, seq_id=2)
+    frames = [synth.make_frame(template, t) for t in range(1, 7)]
+    mask = synth.make_init_mask(H, W)
+    outs = {}
+    for graph in (False, True):
+        conf = load_config(ROOT / "pytracking" / "configs" / "WOFT.py")
+        conf.flow_config.model, conf.flow_config.iters, conf.flow_config.graph = sd, iters, graph
+        trk = conf.tracker_class(conf)
+        trk.flower.defer_min_ratio = 0                   # (a frame this small has too few windows for the deferral to be chosen)
+        assert trk.flower.use_graph == graph
+        trk.init(template, mask)
+        res = []
+        for f in frames:
+            Hc, m = trk.track(torch.from_numpy(f).cuda())
+            assert trk.flower.weights_deferred and not m.lost
+            res.append(Hc.copy())
+        outs[graph] = res
+        if graph:
+            plan = next(iter(trk.flower.engine._plans.values()))
+            assert any(g is not None for g in plan._graphs.values()), "nothing was replayed"
+    for a, b in zip(outs[False], outs[True]):
+        assert np.array_equal(a, b)

@@ -100,11 +100,11 @@ class RAFTWrapper:
             # (mode "TC" hands out dst = grid + flow only: the (2, H, W) flow map is then not written at all)
             plan.flow(iters, crop, oh, ow, flow_up=o["flow"] if want_flow else None, dst=o["dst"], wout=o["w"] if weighted else None,
                       do_sigmoid=do_sigmoid, defer_wh=defer_wh)
-        if defer_wh or not self.use_graph or plan.lookup_events is not None or plan.wh_events is not None or plan.conv_events is not None:
+        if not self.use_graph or plan.lookup_events is not None or plan.wh_events is not None or plan.conv_events is not None:
             return eager()
         graphs = plan.__dict__.setdefault("_graphs", {})
         region = plan.wh_region
-        key = (iters, crop, oh, ow, weighted, do_sigmoid, want_flow, o["flow"].data_ptr(),
+        key = (iters, crop, oh, ow, weighted, do_sigmoid, want_flow, bool(defer_wh), o["flow"].data_ptr(),
                region[0].data_ptr() if region is not None else 0)
         g = graphs.get(key)
         if g is None:
@@ -300,7 +300,7 @@ class RAFTWrapper:
         # (defer_weights = the number of pixels the caller will name: worth it only if their 3x3 supports cannot cover most
         # of the region anyway -- measured with 500 pixels: +0.7 % at 720p (3 900 windows), +6 % at 1080p, +11 % at 4K)
         self.weights_deferred = bool(defer_weights and weighted and not self.engine.small and plan.wh_region is not None
-                                     and not self.use_graph and mode == "TC" and not numpy_out
+                                     and mode == "TC" and not numpy_out
                                      and int(plan.wh_region[0].numel()) > self.defer_min_ratio * int(defer_weights))
         self._deferred = (plan, (top, left), oh, ow, o, bool(do_sigmoid)) if self.weights_deferred else None
         self._run_flow(plan, int(self.C.iters), (top, left), oh, ow, o, weighted, bool(do_sigmoid) and not post,
