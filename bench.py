@@ -454,7 +454,7 @@ def main():
         for prec in ("fp32", "bf16x3", "bf16", "fp16", "f16mx8"):
             if prec == args.precision:
                 continue
-            r, trk, pl, _ = side_run(K2 if prec in ("fp32", "f16mx8") else min(K, 8), precision=prec)
+            r, trk, pl, _ = side_run(K2, precision=prec)
             _, dst, _ = trk.flower.compute_flow(template, frames[0], mode="TC", do_sigmoid=True)
             tc_gpu[prec] = dst.cpu()
             r["correlation"] = trk.flower.engine.corr
