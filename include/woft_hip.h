@@ -98,9 +98,7 @@ typedef struct woft_conv_params {
     int32_t tile_m, tile_n;/* block tile: 128 or 64 each                                       */
     int32_t halo;          /* 0: gather A per tap.  Split-bf16 precisions, stride 1, 3x3/1x5/5x1 only:
                               input halo of the output tile resident in LDS for all taps; tile_m ignored:
-                              1 = 8x16 px, 4 = 4x16 px, 6 = 6x16 px with one wave per 32-column band (tile_n 128, no
-                              statistics / in_norm; in plain-bf16 mode 10-17 % faster than 8x16 x 128, but 8x16 x 64
-                              is faster still: not chosen by the Python host), 2 = one 9x9 image per workgroup (weight-head patches;
+                              1 = 8x16 px, 4 = 4x16 px, 2 = one 9x9 image per workgroup (weight-head patches;
                               ho = wo = 9).  (Larger tiles / several patches per workgroup were measured
                               1.5-3x slower: one workgroup per CU cannot hide its own latencies.)
                               7 = the encoders' first layer (extractor.py:127-129: 7x7, stride 2, pad 3) on its own kernel:
@@ -139,25 +137,6 @@ typedef struct woft_conv_params {
        32-column band and all 128 rows; tile_n 64: 2 x 2 waves.  halo == 12: the same kernel on 4x16-pixel tiles x 128
        columns (tile_n 128, cout_pad % 128 == 0, multi-tap layers): one wave per band and all 64 rows.            */
     const void* wgt_frag;
-    /* Split-packed activations (round 4; split-bf16 / fp16 precisions).  A tensor in this format has the geometry of the
-       fp32 NHWC tensor it replaces (same pixel stride, same channel offsets, 4 bytes per channel), but the 16 bytes of every
-       aligned group of four channels hold the MFMA operand form of the four values instead of the values:
-           bytes 0-7 : hi[0..3] = bf16(x) (precision 1, 2) / fp16(x) (precision 3)
-           bytes 8-15: lo[0..3] = bf16(x - hi) (precision 1); zero otherwise
-       -- exactly what every consumer tile computed from the fp32 value while filling its LDS tile (those
-       conversions were ~a quarter of the vector instructions of the update block's conv launches, and every consumer tile
-       repeated them: 3 column tiles x 1.4 halo overlap for convc2).  The PRODUCER's epilogue converts once, consumers copy.
-       in_fmt : bit 0: in0 is split-packed, bit 1: in1 is (both or neither for halo 8 / 12; never with `flat` or in_norm).
-                halo 8 / 12: each split-packed source must be FOLLOWED BY ONE PIXEL ROW OF ZEROS (pixel index n_img * h * w of its
-                buffer, the channels this layer reads): the halo loader points the taps outside the image there instead of
-                selecting zeros per element.  (The per-tap kernel, halo 0, has no such requirement.)
-       out_fmt: bit 0: `out` is written split-packed (element-wise kinds, WOFT_EPI_GRU_Q's state); a ragged last group
-                (cout % 4 != 0) is completed from e0 (WOFT_EPI_RELU only: out[m][cout .. group end) = the first values of
-                e0[m * lde0 ...], or zero when e0 is NULL -- the motion encoder's `cat([out, flow])`, update.py:96-97);
-                bit 1: `out1` is split-packed: the r*h output of WOFT_EPI_GRU_ZR; with WOFT_EPI_GRU_Q, out1 != NULL receives
-                a split-packed COPY of the new state (out keeps the fp32 state the next gates read).
-       Results are bit-identical to the fp32-activation path (same hi / lo values reach the matrix cores). */
-    int32_t in_fmt, out_fmt;
     /* precision 4 ("f16mx8", round 4; halo 8 / 12 with 3x3 / 1x5 / 5x1 taps only): an fp32-emulating product in two matrix-pipe
        passes -- fp16(a) * fp16(w) on v_mfma_f32_32x32x16_f16 + the two cross terms (a - fp16(a)) * w and a * (w - fp16(w)) on the
        block-scaled fp8 form v_mfma_scale_f32_32x32x64_f8f6f4, one scaled MFMA per PAIR of taps (K = 2 taps x 32 channels; an odd
@@ -171,12 +150,6 @@ typedef struct woft_conv_params {
 } woft_conv_params;
 
 int woft_conv2d(const woft_conv_params* p, void* stream);
-/* fp32 activation rows -> the split-packed form consumed through in_fmt (see woft_conv_params): x [rows][ldx] fp32, the first
- * `channels` (% 4 == 0) of every row -> out [rows][ldo] (same geometry; in place allowed: out == x, ldo == ldx), in the operand form
- * of `precision` (1 bf16x3: hi | lo, 2 bf16, 3 fp16: hi | zero).  For activations that no conv epilogue produces in that form (the
- * GRU's initial state: the context encoder's tanh output, weighted_raft.py:217-218). */
-int woft_pack_split(const float* x, int64_t rows, int32_t channels, int32_t ldx, int32_t precision, float* out, int32_t ldo,
-                    void* stream);
 /* Two INDEPENDENT layers in one launch: both must select the same kernel instance -- same precision (split-bf16 only),
  * halo mode (0 = per-tap kernel, any tap shapes; 8 / 12 = register-streamed kernel, equal tap shape), tile_m / tile_n;
  * no InstanceNorm statistics.  The first layer's workgroups are dispatched first.  Results are those of two woft_conv2d
@@ -184,13 +157,6 @@ int woft_pack_split(const float* x, int64_t rows, int32_t channels, int32_t ldx,
  * encoder's correlation and flow branches, update.py:91-95, are independent until `conv` joins them).  WOFT_EINVAL when the
  * layers do not share a kernel: the caller launches them one after the other. */
 int woft_conv2d_pair(const woft_conv_params* a, const woft_conv_params* b, void* stream);
-/* One SepConvGRU half step (update.py:45-60) in one launch: zr and q are the argument structs the two launches of the step
- * take -- zr: the z|r conv (1x5 or 5x1, in0 = e0 = h, in1 = motion features, c_split 128, cin_pad 256, cout 256 = z | r,
- * wgt_frag, bias_map = the context features' share); q: the q conv (same taps, in1 = the same motion features, wgt_frag,
- * bias_map, e0 = h, out = the new state; its in0 -- r*h -- is NOT read: r*h is recomputed on the conv's halo and kept in
- * LDS, z stays in registers).  One image; split-bf16 / fp16 precisions.  Bit-identical to woft_conv2d(zr with
- * WOFT_EPI_GRU_ZR) followed by woft_conv2d(q with WOFT_EPI_GRU_Q).  One 4-wave workgroup per 8 x 16 pixels and per CU. */
-int woft_gru_halfstep(const woft_conv_params* zr, const woft_conv_params* q, void* stream);
 /* fp32 array (n % 4 == 0) -> bf16 planes hi = bf16(x), lo = bf16(x - hi) (lo may be NULL): the
  * split form of a dynamic B operand (fmap2 in the correlation GEMM). */
 int woft_split_bf16(const float* x, int64_t n, void* hi, void* lo, void* stream);
@@ -277,7 +243,6 @@ typedef struct woft_lookup_params {
     float* out;
     int32_t ldo;
     int32_t vol_bf16;       /* 0: fp32 volume (2896 B per pixel and call, r = 4), 1: bf16 storage (2096 B), fp32 out */
-    int32_t tile_w;         /* columns of a tile (tiles are 4 rows x tile_w): 4 (0 = 4) or 8; plane >= ht*wt*4*tile_w */
     int32_t ablate;         /* developer knob of tools/bench_lookup.py (1: no volume reads, 2: no output); 0 in production */
 } woft_lookup_params;
 int woft_corr_lookup(const woft_lookup_params* p, void* stream);
@@ -316,9 +281,9 @@ typedef struct woft_lookup_otf_params {
     int32_t fh_planes, fh_ld, fh_ld_delta, fh_ld_cat;
 } woft_lookup_otf_params;
 int woft_corr_lookup_otf(const woft_lookup_otf_params* p, void* stream);
-/* NHWC map [h][w][c] -> its rows in (4 x tile_w)-tile order [(ceil(h/4)*ceil(w/tile_w)*4*tile_w)][c], zero rows outside
- * the map: the B operand of the correlation GEMM that yields the tiled volume layout above.  tile_w: 4 or 8. */
-int woft_tile_rows(const float* in, int32_t h, int32_t w, int32_t c, int32_t tile_w, float* out, void* stream);
+/* NHWC map [h][w][c] -> its rows in 4x4-tile order [(ceil(h/4)*ceil(w/4)*16)][c], zero rows outside
+ * the map: the B operand of the correlation GEMM that yields the tiled volume layout above. */
+int woft_tile_rows(const float* in, int32_t h, int32_t w, int32_t c, float* out, void* stream);
 
 /* coords1 += delta; flow = coords1 - coords0 (weighted_raft.py:232,237).
  * delta: [P][ld_delta] (first two channels); flow4: [P][4] = (fx, fy, 0, 0);

@@ -454,18 +454,18 @@ def test_real_frames_720p_vs_reference(golden_dir, precision, corr, epe_mean, ep
 def test_launch_merging_switches_are_bit_identical(monkeypatch, small):
     """Round-3 launch merging -- the motion encoder's branches in shared launches (woft_conv2d_pair), the last iteration's
     flow-head and mask-head convs in one launch, the flow-head gather of iteration k inside the lookup launch of iteration
-    k + 1, each SepConvGRU half step (z|r -> q) in one launch -- changes which launch does the work, not the operations or
-    their order: flows and weights are bit-identical with every switch off."""
+    k + 1 -- changes which launch does the work, not the operations or their order: flows and weights are bit-identical with
+    every switch off."""
     from woft_amd import engine
     sd = synth.make_state_dict(seed=21, small=small, weighted=not small)
     rt = "orig" if small else "weighted"
     a = synth.make_template(136, 200, seq_id=6)
     b = synth.make_frame(a, 3)
     outs = []
-    for pair, fold, gru in ((True, True, "1"), (False, True, "0"), (True, False, "1"), (False, False, "0"), (True, True, "0")):
+    for pair, fold in ((True, True), (False, True), (True, False), (False, False)):
         monkeypatch.setattr(engine, "PAIR_BRANCHES", pair)
         monkeypatch.setattr(engine, "FOLD_GATHER", fold)
-        monkeypatch.setattr(engine, "GRU_FUSE", gru)
+        monkeypatch.setattr(engine, "UPDATE_PK", "0")        # (the per-layer launch programs: the persistent kernel has its own test)
         c = _flow_config(sd, 5, raft_type=rt, padding_mode="nopad", small=small, precision="bf16x3")
         prov = c.of_class(c)
         flow, w = prov.compute_flow(a, b, mode="flow")
@@ -476,9 +476,8 @@ def test_launch_merging_switches_are_bit_identical(monkeypatch, small):
     for f, w, _ in outs[1:]:
         assert torch.equal(f, outs[0][0]) and (w is None or torch.equal(w, outs[0][1]))
     if not small:
-        # launches per refinement iteration: everything merged (GRU half steps in one launch each) / one per layer / merged
-        # without the GRU fusion
-        assert outs[0][2] == 7 and outs[3][2] == 12 and outs[4][2] == 9
+        # launches per refinement iteration: everything merged / one per layer
+        assert outs[0][2] == 9 and outs[3][2] == 12
 
 
 def _crc(a):
@@ -546,37 +545,12 @@ def test_config1_small_480x640_vs_reference(golden_dir, precision, epe_mean, epe
 
 
 @torch.no_grad()
-@pytest.mark.parametrize("precision", ["bf16x3", "bf16", "fp16"])
-@pytest.mark.parametrize("h,w", [(136, 200), (72, 136)])
-def test_split_packed_update_block_is_bit_identical(monkeypatch, precision, h, w):
-    """The update block on split-packed activations (engine.PACKED_ACTS: producers' epilogues write the MFMA operand form,
-    consumers copy) gives bit-identical flows and weights to fp32 activations -- the same hi / lo values reach the matrix
-    cores.  (Opt-in, WOFT_PACKED=1: measured neutral to -1.5 % frames/s)"""
-    from woft_amd import engine
-    sd = synth.make_state_dict(seed=21)
-    a = synth.make_template(h, w, seq_id=6)
-    b = synth.make_frame(a, 2)
-    outs = []
-    for on in (True, False):
-        monkeypatch.setattr(engine, "PACKED_ACTS", on)
-        c = _flow_config(sd, 5, precision=precision)
-        prov = c.of_class(c)
-        flow, wts = prov.compute_flow(a, b, mode="flow")
-        assert prov.engine.plan(h, w).packed == on
-        outs.append((flow.clone(), wts.clone()))
-        flow2, _ = prov.compute_flow(a, b, mode="flow")          # (second call: buffers hold the previous flow's packed data)
-        assert torch.equal(flow2, flow)
-    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
-
-
-@torch.no_grad()
-@pytest.mark.parametrize("packed,layers", [(True, "all"), (False, "all"), (False, "auto")])
-def test_f16mx8_operating_point_vs_reference(golden_dir, monkeypatch, packed, layers):
+@pytest.mark.parametrize("layers", ["all", "auto"])
+def test_f16mx8_operating_point_vs_reference(golden_dir, monkeypatch, layers):
     """precision "f16mx8" (the update block's convolutions in two matrix-pipe passes per product: fp16 main term + two block-scaled
     fp8 cross terms; everything else bf16x3) against the REFERENCE's flow and weights at 12 and 32 iterations: inside the fp32
     budget of SURVEY 8d (EPE mean <= 1e-3 px, max <= 1e-2 px, sigmoid(w) <= 1e-4)."""
-    from woft_amd import engine, ops
-    monkeypatch.setattr(engine, "PACKED_MX", packed)         # (MXP activations between the update block's f16mx8 layers, or fp32 ones)
+    from woft_amd import ops
     monkeypatch.setattr(ops, "MX_LAYERS", layers)            # every multi-tap layer / the default: the 3x3 layers with 256 input channels
     for name in ("flow_full_136x200_it12", "flow_full_136x200_it32"):
         g = np.load(golden_dir / f"{name}.npz")
@@ -584,7 +558,6 @@ def test_f16mx8_operating_point_vs_reference(golden_dir, monkeypatch, packed, la
         fc = _flow_config(sd, int(g["iters"]), precision="f16mx8")
         flower = fc.of_class(fc)
         plan = flower.engine.plan(136, 200)
-        assert plan.packed == packed
         n_mx = sum(q.precision == 4 for e in plan.prog_iter if e[0] in ("conv", "conv2") for q in (e[1] if e[0] == "conv2" else (e[1],)))
         assert n_mx >= (5 if layers == "all" else 3), f"{n_mx} update-block layers run in f16mx8"
         flow, w = flower.compute_flow(g["img1"], g["img2"], mode="flow", do_sigmoid=False)

@@ -89,36 +89,6 @@ def test_conv_halo_norm_on_load(ops, mode):
     _close(o1.nchw(), ref, 2e-4, what="norm-on-load conv")
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "bf16", "fp16"])
-@pytest.mark.parametrize("c,h,w", [(64, 40, 56), (96, 21, 37), (128, 17, 33)])
-def test_conv_regb_instance_norm_plumbing(ops, c, h, w, precision):
-    """The fnet encoder's 3x3 layers on the register-streamed-weights kernel (conv_regb.hip, NORM instance): partial
-    InstanceNorm statistics out, the producer's InstanceNorm + ReLU applied while the halo is converted -- against the
-    LDS-halo kernel it replaces there: every output bit-identical, statistics equal up to their fp32 grouping
-    (extractor.py:28-56,168-192)."""
-    x = _rand(1, c, h, w, seed=96, scale=2.0) + 0.3
-    wt = _rand(c, c, 3, 3, seed=97, scale=1 / math.sqrt(c * 9))
-    b = _rand(c, seed=98, scale=0.1)
-    mean, rstd = _rand(c, seed=94, scale=0.5).cuda(), (_rand(c, seed=95).abs() + 0.5).cuda()
-    pc = ops.pack_conv(wt, b)
-    xa = ops.act_from_nchw(x)
-    res = {}
-    for halo in (None, 1):
-        out = ops.new_act(1, h, w, c, zero=True)
-        stats = (torch.zeros(256 * pc.cout_pad, device="cuda"), torch.zeros(256 * pc.cout_pad, device="cuda"))
-        p = ops.conv_params(xa, pc, out, precision=precision, in_norm=2, in_stats=(mean, rstd), stats=stats, halo=halo or 8,
-                            tiles=None if halo else (128, 64))
-        assert p.halo == (8 if halo is None else 1) and p.in_norm == 2 and (halo or p.tile_n == 64)
-        ops.run_conv(p)
-        mu, rs = torch.zeros(c, device="cuda"), torch.zeros(c, device="cuda")
-        ops.inorm_finalize(stats, 2 * p._m_tiles, pc.cout_pad, c, h * w, mu, rs)
-        res[halo] = (out.t.clone(), mu.clone(), rs.clone())
-    torch.cuda.synchronize()
-    assert torch.equal(res[None][0], res[1][0]), f"max diff {float((res[None][0] - res[1][0]).abs().max()):.3e}"
-    _close(res[None][1], res[1][1], 2e-6, what="mean")
-    _close(res[None][2], res[1][2], 0.0, rtol=1e-5, what="rstd")
-
-
 @pytest.mark.parametrize("precision,tol", [("bf16x3", 2e-5), ("bf16", 2e-2)])
 def test_wh_mean_epilogue(ops, precision, tol):
     """Last weight-head layer with ReLU + 1x1 conv + patch mean fused into the whole-patch kernel's epilogue
@@ -401,54 +371,6 @@ def test_conv_gru_epilogues(ops, kh, kw, precision, tol):
                                          precision=precision, halo=halo, tiles=tiles))
             torch.cuda.synchronize()
             assert torch.equal(z2.t, zb.t) and torch.equal(rh2.t, rh.t) and torch.equal(h2.t, hn.t), (halo, tiles)
-
-
-@pytest.mark.parametrize("precision", ["bf16x3", "bf16", "fp16"])
-@pytest.mark.parametrize("kh,kw", [(1, 5), (5, 1)])
-@pytest.mark.parametrize("h,w", [(135, 240), (19, 37), (8, 16)])
-def test_gru_half_step_in_one_launch(ops, h, w, kh, kw, precision):
-    """woft_gru_halfstep: z|r -> q of a SepConvGRU half step (update.py:45-60) in one launch -- r*h recomputed on the q conv's
-    halo and kept in LDS, z in registers, the context features' share as per-pixel bias maps and the motion features as the
-    second source, exactly as the engine drives the two-launch path (EPI_GRU_ZR, then EPI_GRU_Q): bit-identical new state,
-    also on ragged tiles and on a map of a single tile; and close to torch."""
-    hprev = torch.tanh(_rand(1, 128, h, w, seed=4))
-    inp = F.relu(_rand(1, 128, h, w, seed=9))
-    mot = F.relu(_rand(1, 128, h, w, seed=5))
-    mk = lambda s: (_rand(128, 384, kh, kw, seed=s, scale=1 / math.sqrt(384 * kh * kw)), _rand(128, seed=s + 50, scale=0.1))
-    (wz, bz), (wr, br), (wq, bq) = mk(6), mk(7), mk(8)
-    pad = (kh // 2, kw // 2)
-    hx = torch.cat([hprev, inp, mot], 1)
-    z = torch.sigmoid(F.conv2d(hx, wz, bz, padding=pad))
-    r = torch.sigmoid(F.conv2d(hx, wr, br, padding=pad))
-    q = torch.tanh(F.conv2d(torch.cat([r * hprev, inp, mot], 1), wq, bq, padding=pad))
-    ref = (1 - z) * hprev + z * q
-    dyn, ctx = [(0, 128, 0), (256, 384, 128)], [(128, 256, 0)]
-    wzr, bzr = torch.cat([wz, wr], 0), torch.cat([bz, br], 0)
-    zr_dyn, q_dyn = ops.pack_conv(wzr, None, padding=pad, cin_layout=dyn), ops.pack_conv(wq, None, padding=pad, cin_layout=dyn)
-    zr_inp, q_inp = ops.pack_conv(wzr, bzr, padding=pad, cin_layout=ctx), ops.pack_conv(wq, bq, padding=pad, cin_layout=ctx)
-    ha, ia = ops.act_from_nchw(hprev), ops.act_from_nchw(inp)
-    xbuf = ops.new_act(1, h, w, 256, zero=True)                  # [inp | motion] as in the engine; the convs read from channel 128
-    xbuf.t[:, 128:256] = ops.act_from_nchw(mot).t
-    gz, gq = ops.new_act(1, h, w, 256, zero=True), ops.new_act(1, h, w, 128, zero=True)
-    ops.run_conv(ops.conv_params(ia, zr_inp, gz, precision=precision))
-    ops.run_conv(ops.conv_params(ia, q_inp, gq, precision=precision))
-    zb, rh, h2, h1 = (ops.new_act(1, h, w, 128, zero=True) for _ in range(4))
-    pzr = ops.conv_params(ha, zr_dyn, zb, x2=xbuf, x2_off=128, c_split=128, epi=ops._lib.EPI_GRU_ZR, split=128, e0=ha, out1=rh,
-                          bias_map=gz, precision=precision)
-    pq2 = ops.conv_params(rh, q_dyn, h2, x2=xbuf, x2_off=128, c_split=128, epi=ops._lib.EPI_GRU_Q, e0=ha, e1=zb, bias_map=gq,
-                          precision=precision)
-    ops.run_conv(pzr)
-    ops.run_conv(pq2)
-    pq1 = ops.conv_params(rh, q_dyn, h1, x2=xbuf, x2_off=128, c_split=128, epi=ops._lib.EPI_GRU_Q, e0=ha, e1=zb, bias_map=gq,
-                          precision=precision)
-    assert ops.gru_ok(pzr, pq1)
-    rh.t.fill_(float("nan"))                                     # (the one-launch path must not read r*h or z from memory)
-    zb.t.fill_(float("nan"))
-    ops.run_gru_halfstep(pzr, pq1)
-    torch.cuda.synchronize()
-    assert torch.equal(h1.t, h2.t)
-    tol = {"bf16x3": 2e-4, "bf16": 4e-2, "fp16": 6e-3}[precision]
-    _close(h1.nchw(), ref, tol, what=f"gru half step {precision}")
 
 
 @pytest.mark.parametrize("precision,tol", [("bf16x3", 2e-4), ("bf16", 5e-2)])
@@ -806,9 +728,8 @@ def test_lookup_on_the_fly_wanted_blocks(ops):
 @pytest.mark.parametrize("h,w,dtype", [(17, 25, torch.float32), (24, 40, torch.float32), (33, 47, torch.bfloat16),
                                        (8, 9, torch.bfloat16)])
 def test_lookup_tile_shapes(ops, h, w, dtype):
-    """The volume layout's tile shape (4 x 4 or 4 x 8 elements) is invisible in the result: the same planes tiled either way
-    give bit-identical lookups (smooth, scattered and out-of-map coordinates), and woft_tile_rows orders the GEMM's B rows
-    the way tile_planes orders a plane."""
+    """Tiled volume layout (4 x 4 elements): tile_planes / untile_planes round-trip, lookups on hand-made planes run (smooth,
+    scattered and out-of-map coordinates), and woft_tile_rows orders the GEMM's B rows the way tile_planes orders a plane."""
     P = h * w
     g = torch.Generator().manual_seed(7)
     dims, planes = [], []
@@ -822,26 +743,21 @@ def test_lookup_tile_shapes(ops, h, w, dtype):
     coords[0, :, h - 1, w - 1] = torch.tensor([w + 9.5, h + 3.0])
     coords[0, :, 1, 1] = torch.tensor([-30.0, -30.0])
     cg = coords[0].permute(1, 2, 0).reshape(P, 2).contiguous().cuda()
-    outs = {}
-    for tw in (4, 8):
-        vols = [ops.tile_planes(pl, tw) for pl in planes]
-        for v, pl, (a, b) in zip(vols, planes, dims):
-            assert torch.equal(ops.untile_planes(v, a, b, tw), pl)
-        out = torch.zeros(P, 352, device="cuda")
-        ops.run_lookup(ops.make_lookup_params(vols, dims, cg, out, 4, tw=tw))
-        outs[tw] = out
+    vols = [ops.tile_planes(pl) for pl in planes]
+    for v, pl, (a, b) in zip(vols, planes, dims):
+        assert torch.equal(ops.untile_planes(v, a, b), pl)
+    out = torch.zeros(P, 352, device="cuda")
+    ops.run_lookup(ops.make_lookup_params(vols, dims, cg, out, 4))
     torch.cuda.synchronize()
-    assert torch.equal(outs[4], outs[8])
-    assert float(outs[8][:, :324].abs().max()) > 0
-    # woft_tile_rows: row (tile, dy, dx) of the output = pixel (4 ty + dy, tw tx + dx) of the map, zero rows outside
+    assert float(out[:, :324].abs().max()) > 0
+    # woft_tile_rows: row (tile, dy, dx) of the output = pixel (4 ty + dy, 4 tx + dx) of the map, zero rows outside
     x = ops.new_act(1, h, w, 8)
     x.t.normal_()
-    for tw in (4, 8):
-        ht, wt, n = ops.tiled_dims(h, w, tw)
-        rows = torch.full((n, 8), 7.0, device="cuda")
-        ops.tile_rows(x, rows, tw)
-        want = ops.tile_planes(x.t.reshape(h, w, 8).permute(2, 0, 1).contiguous(), tw)      # (8, n)
-        assert torch.equal(rows.t().contiguous(), want)
+    ht, wt, n = ops.tiled_dims(h, w)
+    rows = torch.full((n, 8), 7.0, device="cuda")
+    ops.tile_rows(x, rows)
+    want = ops.tile_planes(x.t.reshape(h, w, 8).permute(2, 0, 1).contiguous())      # (8, n)
+    assert torch.equal(rows.t().contiguous(), want)
 
 
 @pytest.mark.parametrize("h,w,precision", [(17, 25, "bf16"), (24, 40, "bf16"), (16, 20, "bf16x3")])
@@ -1170,146 +1086,6 @@ def test_bf16x3_stress_against_fp64(ops, case):
 
 
 @pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
-@pytest.mark.parametrize("cin,cout,h,w,epi", [(352, 256, 19, 37, "relu"), (256, 576, 17, 25, "linear"), (128, 126, 9, 16, "relu")])
-def test_conv_1x1_register_streamed(ops, precision, cin, cout, h, w, epi):
-    """1x1 stride-1 layers (update.py:82 convc1, :124 mask head; extractor.py:147 conv2) on conv_regb_kernel with the tap
-    dimension collapsed (three 32-channel chunks per unrolled group): against fp64 torch and against the per-tap gather
-    kernel (halo 0), incl. a ragged channel count and a K that is not a multiple of three chunks."""
-    x = F.relu(_rand(1, cin, h, w, seed=70)) + 0.1
-    wt = _rand(cout, cin, 1, 1, seed=71, scale=1 / math.sqrt(cin))
-    b = _rand(cout, seed=72, scale=0.1)
-    ref = F.conv2d(x.double(), wt.double(), b.double()).float()
-    if epi == "relu":
-        ref = F.relu(ref)
-    code = ops._lib.EPI_RELU if epi == "relu" else ops._lib.EPI_LINEAR
-    pc = ops.pack_conv(wt, b)
-    xa = ops.act_from_nchw(x, cs=ops._round_up(cin, 32))
-    outs = {}
-    for halo in (8, 0):
-        out = ops.new_act(1, h, w, cout, cs=ops._round_up(cout, 4) + 8, zero=True)
-        p = ops.conv_params(xa, pc, out, epi=code, precision=precision, halo=halo)
-        assert p.halo == halo and (halo == 0 or p.tile_n == 64)
-        ops.run_conv(p)
-        torch.cuda.synchronize()
-        outs[halo] = out
-        _close(out.nchw(), ref, 1e-4 if precision == "bf16x3" else 3e-2, what=f"1x1 halo {p.halo}")
-        assert float(out.t[:, cout:].abs().max()) == 0.0
-    assert float((outs[8].t - outs[0].t).abs().max()) < 2e-5
-
-
-# ------------------------------------------------------------------------------------------
-# split-packed activations (woft_conv_params.in_fmt / out_fmt, round 4)
-# ------------------------------------------------------------------------------------------
-def _packed_ref(t, precision):
-    """Host restatement of the split-packed form of fp32 rows [rows][c] (c % 4 == 0): per 4-channel group the 16 bytes
-    [hi[0..3] | lo[0..3]], hi = bf16(x) / fp16(x), lo = bf16(x - hi) (bf16x3) or zero -- as int16 words."""
-    x = t.detach().cpu().float()
-    rows, c = x.shape
-    if precision == "fp16":
-        hi = x.to(torch.float16)
-        lo = torch.zeros_like(hi)
-    else:
-        hi = x.to(torch.bfloat16)
-        lo = (x - hi.float()).to(torch.bfloat16) if precision == "bf16x3" else torch.zeros_like(hi)
-    g = torch.stack([hi.view(torch.int16).reshape(rows, c // 4, 4), lo.view(torch.int16).reshape(rows, c // 4, 4)], 2)
-    return g.reshape(rows, 2 * c)
-
-
-@pytest.mark.parametrize("precision", ["bf16x3", "bf16", "fp16"])
-def test_pack_split_kernel(ops, precision):
-    x = _rand(301, 136, seed=3, scale=3.0).cuda()
-    x[5, :8] = torch.tensor([0.0, -0.0, 1e-30, -1e-30, 65000.0, -3.0e4, 1.0, -1.0])
-    out = torch.zeros_like(x)
-    ops.pack_split(x[:, :128], out, precision, channels=128)
-    torch.cuda.synchronize()
-    assert torch.equal(out[:, :128].contiguous().view(torch.int16).cpu(), _packed_ref(x[:, :128], precision))
-    assert float(out[:, 128:].abs().max()) == 0.0
-    y = x.clone()
-    ops.pack_split(y, y, precision)                          # in place
-    torch.cuda.synchronize()
-    assert torch.equal(y.view(torch.int16).cpu(), _packed_ref(x, precision))
-
-
-@pytest.mark.parametrize("precision", ["bf16x3", "bf16", "fp16"])
-@pytest.mark.parametrize("kh,kw,cin,cout,h,w,tiles", [(3, 3, 256, 192, 24, 40, None), (3, 3, 128, 64, 17, 37, None),
-                                                      (1, 5, 128, 128, 24, 40, None), (5, 1, 128, 128, 9, 16, None),
-                                                      (3, 3, 256, 126, 24, 40, None), (1, 1, 256, 96, 17, 25, None),
-                                                      (3, 3, 128, 256, 24, 40, (128, 128)), (3, 3, 64, 64, 5, 9, None)])
-def test_conv_split_packed_activations(ops, precision, kh, kw, cin, cout, h, w, tiles):
-    """A conv reading split-packed input (in_fmt) / writing split-packed output (out_fmt) -- on the register-streamed kernel
-    (8x16 / 4x16 tiles, both column widths) and the per-tap kernel (1x1, tiny maps) -- computes exactly what the fp32-activation
-    path computes: the output of the packed-input launch is bit-identical, the packed output is the packed form of the fp32
-    output.  Ragged last group (cout 126): completed from e0's row (the motion encoder's cat([out, flow]), update.py:96-97)."""
-    E = ops._lib
-    x = _rand(1, cin, h, w, seed=11, scale=2.0)
-    wt = _rand(cout, cin, kh, kw, seed=12, scale=1.0 / math.sqrt(cin * kh * kw))
-    b = _rand(cout, seed=13, scale=0.1)
-    pc = ops.pack_conv(wt, b, padding=(kh // 2, kw // 2))
-    xa = ops.act_from_nchw(x)
-    xp = ops.new_act(1, h, w, cin, cs=xa.cs, zero=True)       # (new_act: followed by the zero pixel row the halo loader reads)
-    ops.pack_split(xa.t, xp.t, precision)
-    cs_out = ops._round_up(cout, 4)
-    o_ref, o_in, o_out = (ops.new_act(1, h, w, cout, cs=cs_out, zero=True) for _ in range(3))
-    kw_ = dict(epi=E.EPI_RELU, precision=precision, tiles=tiles, halo=8 if tiles else None)    # (explicit tiles: 8x16 x 128 columns)
-    p_ref = ops.conv_params(xa, pc, o_ref, **kw_)
-    p_in = ops.conv_params(xp, pc, o_in, in_fmt=1, **kw_)
-    assert p_in.halo == p_ref.halo and p_in.halo in (0, 8, 12)
-    tail = _rand(h * w, 4, seed=14).cuda()
-    p_out = ops.conv_params(xp, pc, o_out, in_fmt=1, out_fmt=1, e0=ops.Act(tail, 1, h, w, 4) if cout % 4 else None, **kw_)
-    for p in (p_ref, p_in, p_out):
-        ops.run_conv(p)
-    torch.cuda.synchronize()
-    assert torch.equal(o_in.t, o_ref.t)
-    want = o_ref.t.clone()
-    if cout % 4:
-        want[:, cout:cs_out] = tail[:, :cs_out - cout]
-    assert torch.equal(o_out.t.view(torch.int16).cpu(), _packed_ref(want, precision))
-
-
-@pytest.mark.parametrize("precision", ["bf16x3", "fp16"])
-@pytest.mark.parametrize("kh,kw", [(1, 5), (5, 1)])
-def test_gru_half_step_split_packed(ops, kh, kw, precision):
-    """SepConvGRU half step on split-packed [h | motion] / [r*h | motion]: z, the fp32 state and (unpacked) r*h bit-identical to
-    the fp32-activation launches; the state's packed copy (GRU_Q's out1) = the packed form of the fp32 state."""
-    E = ops._lib
-    n, h, w = 1, 24, 40
-    hprev = torch.tanh(_rand(n, 128, h, w, seed=4))
-    xin = _rand(n, 128, h, w, seed=5)
-    mk = lambda s: _rand(128, 256, kh, kw, seed=s, scale=1 / math.sqrt(256 * kh * kw))
-    pad = (kh // 2, kw // 2)
-    pzr = ops.pack_conv(torch.cat([mk(6), mk(7)], 0), None, padding=pad)
-    pq = ops.pack_conv(mk(8), None, padding=pad)
-    gz, gq = ops.act_from_nchw(_rand(n, 256, h, w, seed=9, scale=0.3)), ops.act_from_nchw(_rand(n, 128, h, w, seed=10, scale=0.3))
-    ha, xa = ops.act_from_nchw(hprev), ops.act_from_nchw(xin)
-    hp, xp = ops.new_act(n, h, w, 128, zero=True), ops.new_act(n, h, w, 128, zero=True)
-    ops.pack_split(ha.t, hp.t, precision)
-    ops.pack_split(xa.t, xp.t, precision)
-    z0, rh0, h0 = (ops.new_act(n, h, w, 128, zero=True) for _ in range(3))
-    z1, rh1, h1, h1p = (ops.new_act(n, h, w, 128, zero=True) for _ in range(4))
-    kw_zr = dict(c_split=128, epi=E.EPI_GRU_ZR, split=128, e0=ha, precision=precision)
-    kw_q = dict(c_split=128, epi=E.EPI_GRU_Q, e0=ha, precision=precision)
-    ops.run_conv(ops.conv_params(ha, pzr, z0, x2=xa, out1=rh0, bias_map=gz, **kw_zr))
-    ops.run_conv(ops.conv_params(rh0, pq, h0, x2=xa, e1=z0, bias_map=gq, **kw_q))
-    a = ops.conv_params(hp, pzr, z1, x2=xp, out1=rh1, bias_map=gz, in_fmt=3, out_fmt=2, **kw_zr)
-    b = ops.conv_params(rh1, pq, h1, x2=xp, e1=z1, bias_map=gq, in_fmt=3, out_fmt=2, out1=h1p, **kw_q)
-    assert a.halo in (8, 12) and b.halo in (8, 12)
-    ops.run_conv(a)
-    ops.run_conv(b)
-    torch.cuda.synchronize()
-    assert torch.equal(z1.t, z0.t) and torch.equal(h1.t, h0.t)
-    assert torch.equal(rh1.t.view(torch.int16).cpu(), _packed_ref(rh0.t, precision))
-    assert torch.equal(h1p.t.view(torch.int16).cpu(), _packed_ref(h0.t, precision))
-    # what the ABI refuses: packed input on a kernel without the path, mixed sources on the register-streamed kernel
-    with pytest.raises(ValueError):
-        ops.conv_params(hp, pzr, z1, x2=xp, out1=rh1, in_fmt=3, halo=1, **kw_zr)
-    bad = ops.conv_params(hp, pzr, z1, x2=xp, out1=rh1, in_fmt=3, **kw_zr)
-    bad.in_fmt = 1
-    assert ops._lib.load().woft_conv2d(bad, ops.stream_ptr()) != 0
-    with pytest.raises(ValueError):            # (a tensor without the zero pixel row behind it)
-        ops.conv_params(ops.Act(torch.zeros_like(hp.t), n, h, w, 128), pzr, z1, x2=xp, out1=rh1, in_fmt=3, **kw_zr)
-
-
-@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
 @pytest.mark.parametrize("kh,kw,h,w", [(1, 5, 18, 22), (5, 1, 18, 22), (1, 5, 8, 9), (5, 1, 8, 9), (3, 3, 5, 7)])
 def test_gru_convs_on_the_per_tap_kernel(ops, kh, kw, h, w, precision):
     """The GRU's two-source convs with their gate epilogues on the PER-TAP kernel (halo 0) -- the kernel they fall back to on
@@ -1385,6 +1161,41 @@ def test_conv_f16mx8(ops, monkeypatch, kh, kw, cin, cout, h, w, tiles):
     assert errs["f16mx8"] < 6 * errs["bf16x3"] and errs["f16mx8"] < 0.2 * errs["fp16"]
 
 
+def test_conv_f16mx8_tiny_blocks_stay_finite(ops, monkeypatch):
+    """Round-4 advisor finding: a 32-channel block whose largest |a| is non-zero but below fp16's normal range (2^-14) has
+    remainders a - fp16(a) of up to 2^-25 REGARDLESS of the block maximum; with the remainder's scale derived as (block scale - 11)
+    and no floor, the scaled remainder exceeded e4m3's 448 and v_cvt_pk_fp8_f32 (which does not saturate) produced NaNs that the
+    scaled MFMA spread.  The loader now floors the block scale at 105 (conv_regb_body.h): ReLU-like blocks of tiny values and
+    zeros must give finite outputs with the usual error against fp64."""
+    E = ops._lib
+    monkeypatch.setattr(ops, "MX_LAYERS", "all")
+    g = torch.Generator().manual_seed(3)
+    h, w, cin, cout = 24, 40, 128, 128
+    mag = torch.exp(torch.rand(1, cin, h, w, generator=g) * (math.log(2e-5) - math.log(1e-7)) + math.log(1e-7))   # 1e-7 .. 2e-5
+    x = mag * (torch.rand(1, cin, h, w, generator=g) > 0.4)                        # ReLU-like: 40 % zeros
+    x[:, :, 5:9] *= 1e3                                                            # some rows in fp16's normal range beside them
+    x[:, :32, 0, 0] = 1e-30                                                        # a block far below every grid
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
+    ref = F.conv2d(x.double(), wt.double(), None, padding=1)
+    norm = F.conv2d(x.double().abs(), wt.double().abs(), None, padding=1) + 1e-30
+    pc = ops.pack_conv(wt, None)
+    xa = ops.act_from_nchw(x)
+    errs = {}
+    for prec in ("bf16x3", "f16mx8"):
+        out = ops.new_act(1, h, w, cout, zero=True)
+        p = ops.conv_params(xa, pc, out, precision=prec)
+        assert p.halo in (8, 12) and p.precision == ops.PRECISION[prec]
+        ops.run_conv(p)
+        torch.cuda.synchronize()
+        o = out.nchw().double().cpu()
+        assert bool(torch.isfinite(o).all()), prec
+        e = (o - ref) / norm
+        errs[prec] = float(torch.sqrt((e ** 2).mean()))
+    print(f"tiny blocks: rms error / sum|a||w|  bf16x3 {errs['bf16x3']:.2e}  f16mx8 {errs['f16mx8']:.2e}")
+    # (values below fp16's subnormal grid reach the product through the fp8 image of a alone: 2^-4 relative on those terms)
+    assert errs["f16mx8"] < 0.05
+
+
 def test_gru_half_step_f16mx8(ops, monkeypatch):
     """Two-source GRU convs with their gate epilogues in f16mx8 against the bf16x3 launches."""
     E = ops._lib
@@ -1411,42 +1222,3 @@ def test_gru_half_step_f16mx8(ops, monkeypatch):
     _close(res["f16mx8"][1], res["bf16x3"][1], 3e-5, what="h")
 
 
-@pytest.mark.parametrize("kh,kw,cin,cmid,cout,h,w", [(3, 3, 128, 256, 192, 24, 40), (1, 5, 128, 128, 128, 17, 37)])
-def test_f16mx8_on_mxp_activations(ops, monkeypatch, kh, kw, cin, cmid, cout, h, w):
-    """MXP (csrc/mxp.h: fp16 | fp8 | fp8 images of 32-channel blocks, the block scale re-derived from the fp16 plane): an f16mx8
-    producer writes it (out_fmt), an f16mx8 consumer reads it (in_fmt) -- the chain against fp64, beside the same chain on fp32
-    activations and in bf16x3; also woft_pack_split(precision 4) as the producer."""
-    E = ops._lib
-    monkeypatch.setattr(ops, "MX_LAYERS", "all")
-    g = torch.Generator().manual_seed(11)
-    amp = torch.exp(torch.rand(1, 1, h, w, generator=g) * 6 - 4)
-    x = torch.relu(torch.randn(1, cin, h, w, generator=g)) * amp
-    w1 = torch.randn(cmid, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
-    w2 = torch.randn(cout, cmid, kh, kw, generator=g) / math.sqrt(cmid * kh * kw)
-    mid = torch.relu(F.conv2d(x.double(), w1.double(), None, padding=1))
-    ref = F.conv2d(mid, w2.double(), None, padding=(kh // 2, kw // 2))
-    norm = F.conv2d(mid.abs(), w2.double().abs(), None, padding=(kh // 2, kw // 2)) + 1e-30
-    p1, p2 = ops.pack_conv(w1, None, padding=1), ops.pack_conv(w2, None, padding=(kh // 2, kw // 2))
-    xa = ops.act_from_nchw(x)
-    errs = {}
-    for name, prec, packed in (("bf16x3", "bf16x3", False), ("f16mx8", "f16mx8", False), ("f16mx8 on MXP", "f16mx8", True)):
-        m = ops.new_act(1, h, w, cmid, zero=True)
-        out = ops.new_act(1, h, w, cout, cs=ops._round_up(cout, 4), zero=True)
-        ops.run_conv(ops.conv_params(xa, p1, m, epi=E.EPI_RELU, precision=prec, out_fmt=int(packed)))
-        q = ops.conv_params(m, p2, out, precision=prec, in_fmt=int(packed))
-        assert q.halo in (8, 12) and q.precision == ops.PRECISION[prec]
-        ops.run_conv(q)
-        torch.cuda.synchronize()
-        e = (out.nchw().double().cpu() - ref) / norm
-        errs[name] = float(torch.sqrt((e ** 2).mean()))
-    mf, mp = ops.new_act(1, h, w, cmid, zero=True), ops.new_act(1, h, w, cmid, zero=True)
-    ops.run_conv(ops.conv_params(xa, p1, mf, epi=E.EPI_RELU, precision="f16mx8"))
-    ops.pack_split(mf.t, mp.t, "f16mx8")
-    out2 = ops.new_act(1, h, w, cout, cs=ops._round_up(cout, 4), zero=True)
-    ops.run_conv(ops.conv_params(mp, p2, out2, precision="f16mx8", in_fmt=1))
-    torch.cuda.synchronize()
-    e = (out2.nchw().double().cpu() - ref) / norm
-    errs["pack kernel"] = float(torch.sqrt((e ** 2).mean()))
-    print(f"{kh}x{kw} chain @{h}x{w}: rms error / sum|a||w| " + "  ".join(f"{k} {v:.2e}" for k, v in errs.items()))
-    assert errs["f16mx8 on MXP"] < 1.5 * errs["f16mx8"] + 1e-8 and errs["pack kernel"] < 1.5 * errs["f16mx8"] + 1e-8
-    assert errs["f16mx8"] < 6 * errs["bf16x3"]

@@ -15,7 +15,7 @@ python bench.py --iters 32 --no-cpu-baseline --no-alt-precisions > $out/${tag}_b
 python bench.py --height 2160 --width 3840 --steps 10 --no-cpu-baseline --no-alt-precisions > $out/${tag}_bench_4k.json 2>/dev/null
 python bench.py --height 480 --width 640 --no-cpu-baseline --no-ladder --no-alt-precisions --no-alt-corr > $out/${tag}_bench_480p.json 2>/dev/null
 python tools/bench_hfit.py > $out/${tag}_hfit_fullframe.txt 2>/dev/null
-{ python tools/bench_lookup.py; python tools/bench_lookup.py --tw 8; python tools/bench_lookup.py --storage bf16; python tools/bench_lookup.py --storage bf16 --tw 8;
+{ python tools/bench_lookup.py; python tools/bench_lookup.py --storage bf16;
   for abl in 1 2 3; do LOOKUP_ABL=$abl python tools/bench_lookup.py; done; } 2>/dev/null | grep lookup > $out/${tag}_lookup_isolated.txt
 { OTF_ABL=16 python tools/bench_lookup_otf.py; for abl in 1 2 3 15; do OTF_ABL=$abl python tools/bench_lookup_otf.py; done; } 2>/dev/null | grep -v amdgpu > $out/${tag}_lookup_otf_timeline.txt
 python tools/layer_times.py 2>/dev/null | grep -v amdgpu > $out/${tag}_layer_times_bf16x3.txt

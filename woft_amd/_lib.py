@@ -31,7 +31,7 @@ class ConvParams(C.Structure):
         ("in_norm", i32), ("in_mean", vp), ("in_rstd", vp), ("bias_map", vp), ("ld_bias_map", i32),
         ("out_index", vp),
         ("wh0_lookup", vp), ("wh0_ld", i32), ("wh0_mean", vp), ("wh0_w", vp), ("wh0_bias", vp), ("wh0_index", vp),
-        ("wgt_frag", vp), ("in_fmt", i32), ("out_fmt", i32), ("wgt_mx", vp),
+        ("wgt_frag", vp), ("wgt_mx", vp),
     ]
 
 
@@ -39,7 +39,7 @@ class LookupParams(C.Structure):
     _fields_ = [
         ("vol", vp * 4), ("ht", i32 * 4), ("wt", i32 * 4), ("plane", i64 * 4),
         ("levels", i32), ("radius", i32), ("coords", vp), ("n_pix", i64), ("out", vp), ("ldo", i32),
-        ("vol_bf16", i32), ("tile_w", i32), ("ablate", i32),
+        ("vol_bf16", i32), ("ablate", i32),
     ]
 
 
@@ -59,8 +59,6 @@ _SIGS = {
     "woft_set_tuning": (i32, [i32, i32]),
     "woft_conv2d": (i32, [C.POINTER(ConvParams), vp]),
     "woft_conv2d_pair": (i32, [C.POINTER(ConvParams), C.POINTER(ConvParams), vp]),
-    "woft_gru_halfstep": (i32, [C.POINTER(ConvParams), C.POINTER(ConvParams), vp]),
-    "woft_pack_split": (i32, [vp, i64, i32, i32, i32, vp, i32, vp]),
     "woft_split_bf16": (i32, [vp, i64, vp, vp, vp]),
     "woft_split_bf16_lines": (i32, [vp, i64, vp, vp]),
     "woft_flow_to_tc": (i32, [vp, vp, i32, i32, vp, vp, i32, vp]),
@@ -76,7 +74,7 @@ _SIGS = {
     "woft_avgpool2_nhwc": (i32, [vp, i32, i32, i32, vp, vp]),
     "woft_feature_pyramid": (i32, [vp, i32, i32, i32, i32, vp, vp, i32, vp]),
     "woft_corr_lookup": (i32, [C.POINTER(LookupParams), vp]),
-    "woft_tile_rows": (i32, [vp, i32, i32, i32, i32, vp, vp]),
+    "woft_tile_rows": (i32, [vp, i32, i32, i32, vp, vp]),
     "woft_coords_update": (i32, [vp, vp, i32, i32, i64, vp, vp, i32, vp]),
     "woft_coords_init": (i32, [vp, i32, i32, vp, vp, i32, vp]),
     "woft_colsum": (i32, [vp, i64, i32, vp, i32, vp, vp]),

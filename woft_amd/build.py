@@ -17,13 +17,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math"
 
 
 # Translation units.  The two template-heavy sources are compiled once per arithmetic mode (-DWOFT_ONLY_PREC = the precision code
-# of woft_conv_params: 1 bf16x3, 2 bf16 (+ the exact-fp32 kernels), 3 fp16; conv_regb.hip additionally per input format,
-# -DWOFT_ONLY_PK = 0 fp32 / 1 split-packed activations): hipcc compiles a unit on ONE core (conv.hip as a single unit: 9+ minutes),
-# the parts run side by side.  Every part exports its own dispatcher symbol (woft_conv_dispatch_p<k>, woft_conv_regb_launch_p<k>_<pk>);
-# the C ABI entry points live in part 1 of conv.hip.
+# of woft_conv_params: 1 bf16x3, 2 bf16 (+ the exact-fp32 kernels), 3 fp16, 4 f16mx8 (conv_regb.hip only)): hipcc compiles a unit on
+# ONE core (conv.hip as a single unit: 9+ minutes), the parts run side by side.  Every part exports its own dispatcher symbol
+# (woft_conv_dispatch_p<k>, woft_conv_regb_launch_p<k>); the C ABI entry points live in part 1 of conv.hip.
 PARTS = {"conv.hip": [("p1", ["-DWOFT_ONLY_PREC=1"]), ("p2", ["-DWOFT_ONLY_PREC=2"]), ("p3", ["-DWOFT_ONLY_PREC=3"])],
-         "conv_regb.hip": [(f"p{k}_{pk}", [f"-DWOFT_ONLY_PREC={k}", f"-DWOFT_ONLY_PK={pk}"]) for k in (1, 2, 3) for pk in (0, 1)]
-                          + [(f"p4_{pk}", ["-DWOFT_ONLY_PREC=4", f"-DWOFT_ONLY_PK={pk}"]) for pk in (0, 1)]}   # precision 4 (f16mx8): fp32 / MXP in
+         "conv_regb.hip": [(f"p{k}", [f"-DWOFT_ONLY_PREC={k}"]) for k in (1, 2, 3, 4)]}
 
 
 def _sources():

@@ -238,11 +238,9 @@ __global__ __launch_bounds__(256) void conv_mfma_bf16_kernel(const woft_conv_par
     // HBM latency of its activation rows in every step
     f32x4 ra0[RA], ra1[RA];
     bool rok0[RA], rok1[RA];
-    bool rpk0 = false, rpk1 = false;                    // the set's rows are split-packed (woft_conv_params.in_fmt): copy, do not convert
-    auto load_a = [&](f32x4 (&ra)[RA], bool (&rok)[RA], bool& rpk) {   // the step at the prefetch position
+    auto load_a = [&](f32x4 (&ra)[RA], bool (&rok)[RA]) {   // the step at the prefetch position
         const int c0 = pf_chunk * BK;
         const bool second = (p.in1 != nullptr) && (c0 >= p.c_split);
-        rpk = (p.in_fmt & (second ? 2 : 1)) != 0;
         // (the chunk's channel offset goes into the 32-bit lane offset, the scalar base is in0 / in1 itself.  The former form --
         //  `p.in1 + (c0 - p.c_split)` as the base -- was MISCOMPILED inside the K loop: the 64-bit shift of the index took its high
         //  half from an unrelated live SGPR (s_lshl_b64 s[6:7], s[72:73], 2 with s73 never cleared: ISA of round 4), so every
@@ -265,18 +263,8 @@ __global__ __launch_bounds__(256) void conv_mfma_bf16_kernel(const woft_conv_par
             tap_rows();
         }
     };
-    auto store_a = [&](int stage, f32x4 (&ra)[RA], bool (&rok)[RA], const bool rpk) {
+    auto store_a = [&](int stage, f32x4 (&ra)[RA], bool (&rok)[RA]) {
         __bf16* As = Asm + stage * A_STAGE;
-        if (rpk) {                                      // (wave-uniform)
-#pragma unroll
-            for (int j = 0; j < RA; ++j) {
-                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-                const f32x4 val = rok[j] ? ra[j] : zero;
-                *(bf16x4*)(As + (r0 + 32 * j) * LDB + 4 * v) = packed_hi(val);
-                if (NP == 2) *(bf16x4*)(As + A_PLANE + (r0 + 32 * j) * LDB + 4 * v) = packed_lo(val);
-            }
-            return;
-        }
 #pragma unroll
         for (int j = 0; j < RA; ++j) {
             const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -353,11 +341,11 @@ __global__ __launch_bounds__(256) void conv_mfma_bf16_kernel(const woft_conv_par
 
     tap_rows();
     dma_b(0, 0);
-    load_a(ra0, rok0, rpk0);
-    store_a(0, ra0, rok0, rpk0);
+    load_a(ra0, rok0);
+    store_a(0, ra0, rok0);
     if (nk > 1) {                                        // step 1 -> set 0 (stays in flight across the barrier)
         advance();
-        load_a(ra0, rok0, rpk0);
+        load_a(ra0, rok0);
         dma_wait<RA>();
     } else {
         dma_wait<0>();
@@ -365,23 +353,23 @@ __global__ __launch_bounds__(256) void conv_mfma_bf16_kernel(const woft_conv_par
     __syncthreads();
     int stage = 0;
     // one K step: `cur` holds the rows of step ks + 1 (requested a step ago), `nxt` receives those of step ks + 2
-    auto step = [&](int ks, f32x4 (&cur)[RA], bool (&cok)[RA], const bool cpk, f32x4 (&nxt)[RA], bool (&nok)[RA], bool& npk) {
+    auto step = [&](int ks, f32x4 (&cur)[RA], bool (&cok)[RA], f32x4 (&nxt)[RA], bool (&nok)[RA]) {
         dma_b(ks + 1, stage ^ 1);                       // lands in the idle stage while this step computes
         const bool ahead = ks + 2 < nk;
         if (ahead) {
             advance();
-            load_a(nxt, nok, npk);
+            load_a(nxt, nok);
         }
         compute(stage);
-        store_a(stage ^ 1, cur, cok, cpk);                 // idle A stage: last read in step ks-1, a barrier ago
+        store_a(stage ^ 1, cur, cok);                 // idle A stage: last read in step ks-1, a barrier ago
         if (ahead) dma_wait<RA>();                      // (the RA loads of `nxt` were issued after the DMA)
         else dma_wait<0>();
         __syncthreads();
         stage ^= 1;
     };
     for (int ks = 0; ks + 1 < nk; ks += 2) {
-        step(ks, ra0, rok0, rpk0, ra1, rok1, rpk1);
-        if (ks + 2 < nk) step(ks + 1, ra1, rok1, rpk1, ra0, rok0, rpk0);
+        step(ks, ra0, rok0, ra1, rok1);
+        if (ks + 2 < nk) step(ks + 1, ra1, rok1, ra0, rok0);
     }
     compute(stage);
     __syncthreads();
@@ -785,7 +773,7 @@ int launch_halo(const woft_conv_params& p, hipStream_t s) {
     else if (p.taps_y == 1 && p.taps_x == 5) HALO_LAUNCH(1, 5, T, false);                       \
     else if (p.taps_y == 5 && p.taps_x == 1) HALO_LAUNCH(5, 1, T, false);                       \
     else return WOFT_EINVAL
-    if (p.precision != WOFT_ONLY_PREC || p.in_fmt != 0) return WOFT_EINVAL;      // (fp32-activation inputs only: see conv_regb.hip)
+    if (p.precision != WOFT_ONLY_PREC) return WOFT_EINVAL;
 #if WOFT_ONLY_PREC == 3
     if constexpr (TY == 9) return WOFT_EINVAL;           /* (the weight head keeps the split-bf16 arithmetic) */
     else { HALO_TAPS(16); }
@@ -992,7 +980,7 @@ int launch_conv(const woft_conv_params& p, const woft_conv_params* second, hipSt
     dim3 grid((unsigned)(blocks(p) + (second ? blocks(pb) : 0)));       // 1-D: see woft::tile_of_block
     if (p.precision == 0) {
 #if WOFT_ONLY_PREC == 2
-        if (second || p.in_fmt != 0 || p.out_fmt != 0) return WOFT_EINVAL;
+        if (second) return WOFT_EINVAL;
         woft_launch(0, conv_mfma_f32_kernel<BM, BN>, grid, dim3(256), 0, s, p);
         return woft_launch_status();
 #else
@@ -1012,9 +1000,8 @@ int launch_conv(const woft_conv_params& p, const woft_conv_params* second, hipSt
 
 }  // namespace
 
-// conv_regb.hip, the parts of this precision: fp32 / split-packed input activations
-int WOFT_CAT4(woft_conv_regb_launch_p, WOFT_ONLY_PREC, _, 0)(const woft_conv_params& p, const woft_conv_params* second, void* stream);
-int WOFT_CAT4(woft_conv_regb_launch_p, WOFT_ONLY_PREC, _, 1)(const woft_conv_params& p, const woft_conv_params* second, void* stream);
+// conv_regb.hip, the part of this precision
+int WOFT_CAT2(woft_conv_regb_launch_p, WOFT_ONLY_PREC)(const woft_conv_params& p, const woft_conv_params* second, void* stream);
 int woft_conv_stem_launch(const woft_conv_params& p, void* stream);                                     // conv_stem.hip
 int woft_conv_dispatch_p1(const woft_conv_params& p, const woft_conv_params* second, void* stream);
 int woft_conv_dispatch_p2(const woft_conv_params& p, const woft_conv_params* second, void* stream);
@@ -1072,20 +1059,6 @@ static int conv_check(const woft_conv_params& p) {
          p.in_norm != 0 || p.ho != 9 || p.wo != 9 || p.wh0_ld < 324 || p.wh0_ld % 4 != 0 || p.wh0_mean == nullptr ||
          p.wh0_w == nullptr || p.wh0_bias == nullptr))
         return WOFT_EINVAL;
-    // split-packed activations (in_fmt / out_fmt): split-bf16 / fp16 precisions; inputs of the per-tap kernel (halo 0, not flat)
-    // and of the register-streamed kernel (halo 8 / 12: both sources or neither); outputs of the shared epilogue's kinds
-    if ((p.in_fmt & ~3) != 0 || (p.out_fmt & ~3) != 0) return WOFT_EINVAL;
-    if (p.in_fmt != 0) {
-        if (p.precision == 0 || p.flat || p.in_norm != 0 || (p.halo != 0 && p.halo != 8 && p.halo != 12)) return WOFT_EINVAL;
-        if ((p.in_fmt & 2) != 0 && p.in1 == nullptr) return WOFT_EINVAL;
-        if (p.halo != 0 && p.in_fmt != (p.in1 != nullptr ? 3 : 1)) return WOFT_EINVAL;
-    }
-    if (p.out_fmt != 0) {
-        if (p.precision == 0 || p.epi == WOFT_EPI_WH_MEAN || p.epi == WOFT_EPI_FLOWHEAD || p.epi == WOFT_EPI_CTX) return WOFT_EINVAL;
-        if ((p.out_fmt & 1) != 0 && p.epi == WOFT_EPI_GRU_ZR) return WOFT_EINVAL;             // (z stays fp32: only the blend reads it)
-        if ((p.out_fmt & 2) != 0 && ((p.epi != WOFT_EPI_GRU_ZR && p.epi != WOFT_EPI_GRU_Q) || p.out1 == nullptr)) return WOFT_EINVAL;
-        if ((p.out_fmt & 1) != 0 && p.cout % 4 != 0 && p.epi != WOFT_EPI_RELU) return WOFT_EINVAL;   // (ragged group completed from e0)
-    } else if (p.epi == WOFT_EPI_GRU_Q && p.out1 != nullptr) return WOFT_EINVAL;
     return WOFT_OK;
 }
 #endif  // WOFT_ONLY_PREC == 1 (argument checks)
@@ -1098,7 +1071,7 @@ int WOFT_CAT2(woft_conv_dispatch_p, WOFT_ONLY_PREC)(const woft_conv_params& p, c
                               second->tile_n != p.tile_n || p.precision == 0 || (p.halo != 0 && p.halo != 8 && p.halo != 12)))
         return WOFT_EINVAL;
     if (p.halo == 7)                      // the encoders' 7x7 / stride-2 first layer on its own kernel (conv_stem.hip)
-        return (second != nullptr || p.in_fmt != 0) ? WOFT_EINVAL : woft_conv_stem_launch(p, stream);
+        return second != nullptr ? WOFT_EINVAL : woft_conv_stem_launch(p, stream);
     for (const woft_conv_params* q : {&p, second}) {
         if (q == nullptr || q->halo == 0) continue;
         // LDS-halo kernels: split-bf16 precisions, stride 1, 3x3 / 1x5 / 5x1 taps, non-flat, same-size output
@@ -1110,14 +1083,11 @@ int WOFT_CAT2(woft_conv_dispatch_p, WOFT_ONLY_PREC)(const woft_conv_params& p, c
     }
     if (p.halo != 0) {
         if (p.halo == 8 || p.halo == 12)
-            return p.in_fmt != 0 ? WOFT_CAT4(woft_conv_regb_launch_p, WOFT_ONLY_PREC, _, 1)(p, second, stream)
-                                 : WOFT_CAT4(woft_conv_regb_launch_p, WOFT_ONLY_PREC, _, 0)(p, second, stream);
+            return WOFT_CAT2(woft_conv_regb_launch_p, WOFT_ONLY_PREC)(p, second, stream);
         if (p.halo == 1 && p.tile_n == 128) return launch_halo<8, 16, 128, 2, 2>(p, s);
         if (p.halo == 1 && p.tile_n == 64) return launch_halo<8, 16, 64, 2, 2>(p, s);
         if (p.halo == 2 && p.tile_n == 128 && p.ho == 9 && p.wo == 9) return launch_halo<9, 9, 128, 1, 2>(p, s);
         if (p.halo == 4 && p.tile_n == 128) return launch_halo<4, 16, 128, 2, 2>(p, s);
-        if (p.halo == 6 && p.tile_n == 128 && p.in_norm == 0 && p.stat_sum == nullptr)
-            return launch_halo<6, 16, 128, 1, 2>(p, s);
         if (p.halo == 4 && p.tile_n == 64) return launch_halo<4, 16, 64, 2, 2>(p, s);
         return WOFT_EINVAL;
     }
@@ -1128,8 +1098,7 @@ int WOFT_CAT2(woft_conv_dispatch_p, WOFT_ONLY_PREC)(const woft_conv_params& p, c
 }
 
 #if WOFT_ONLY_PREC == 1
-int woft_conv_regb_launch_p4_0(const woft_conv_params& p, const woft_conv_params* second, void* stream);   // conv_regb.hip, parts 4:
-int woft_conv_regb_launch_p4_1(const woft_conv_params& p, const woft_conv_params* second, void* stream);   // fp32 / MXP activations in
+int woft_conv_regb_launch_p4(const woft_conv_params& p, const woft_conv_params* second, void* stream);   // conv_regb.hip, part 4
 
 static int conv_dispatch_f16mx8(const woft_conv_params& p, const woft_conv_params* second, void* stream) {
     for (const woft_conv_params* q : {&p, second}) {
@@ -1139,7 +1108,7 @@ static int conv_dispatch_f16mx8(const woft_conv_params& p, const woft_conv_param
         const int64_t cs_max = (q->in1 != nullptr && q->cs1 > q->cs0) ? q->cs1 : q->cs0;
         if ((int64_t)q->n_img * q->h * q->w * cs_max >= (1ll << 31)) return WOFT_EINVAL;     // 32-bit element offsets
     }
-    return p.in_fmt != 0 ? woft_conv_regb_launch_p4_1(p, second, stream) : woft_conv_regb_launch_p4_0(p, second, stream);
+    return woft_conv_regb_launch_p4(p, second, stream);
 }
 
 static int conv_dispatch(const woft_conv_params& p, const woft_conv_params* second, void* stream) {

@@ -122,21 +122,25 @@ struct GPtr {
     uint64_t a;
     __device__ __forceinline__ bool null() const { return a == 0; }
     __device__ __forceinline__ f32x4 ld4(int64_t off) const { return *(const g_f32x4*)(a + 4 * (uint64_t)off); }
+#ifdef WOFT_STORE_WT
+    // Write-through (sc1) stores: the persistent update-block kernel (update_pk.hip) hands its output tiles to workgroups on
+    // other CUs / XCDs INSIDE the launch -- payload stored through to memory, then a flag (guide: Guideline 16, form R1; a
+    // release fence instead would write back the whole XCD L2, 6-8 us per 64 KB tile).  Buffer-descriptor form, 32-bit byte
+    // offsets: the launcher checks that every output is smaller than 2 GiB.
+    __device__ __forceinline__ void st4(int64_t off, f32x4 v) const {
+        typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v),
+                                               __builtin_amdgcn_make_buffer_rsrc((void*)a, 0, 0x7fffffff, 0x00020000),
+                                               (int)(4 * off), 0, 16);
+    }
+    __device__ __forceinline__ void st1(int64_t off, float v) const {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v),
+                                              __builtin_amdgcn_make_buffer_rsrc((void*)a, 0, 0x7fffffff, 0x00020000),
+                                              (int)(4 * off), 0, 16);
+    }
+#else
     __device__ __forceinline__ void st4(int64_t off, f32x4 v) const { *(g_f32x4*)(a + 4 * (uint64_t)off) = v; }
     __device__ __forceinline__ void st1(int64_t off, float v) const { *(g_f32*)(a + 4 * (uint64_t)off) = v; }
-#ifdef WOFT_EPI_MXP
-    // (conv_regb.hip's precision-4 parts only, mxp.h) the lane's share of its 32-channel block's MXP image: 8 + 4 + 4 bytes; all
-    // eight lanes of the block call together
-    __device__ __forceinline__ void st_mxp(int64_t row_off, int ch, f32x4 y) const {
-        typedef __attribute__((address_space(1))) uint32_t g_u32;
-        const MxpWords w = mxp_pack(y);
-        const uint64_t blk = a + 4 * (uint64_t)(row_off + (ch & ~31));
-        const uint32_t j = (uint32_t)(ch & 31) >> 2;
-        *(g_u32*)(blk + 8 * j) = w.h0;
-        *(g_u32*)(blk + 8 * j + 4) = w.h1;
-        *(g_u32*)(blk + 64 + 4 * j) = w.qa;
-        *(g_u32*)(blk + 96 + 4 * j) = w.ql;
-    }
 #endif
 };
 __device__ __forceinline__ GPtr keep_gptr(const void* p) { return GPtr{keep_sgpr((uint64_t)(uintptr_t)p)}; }
@@ -158,7 +162,6 @@ struct EpiRegs {
     float alpha;
     bool no_store;
     bool fast;             // gate functions on the hardware exp2 / rcp (split-bf16 / fp16 precisions), see common.h
-    int pk, pk1;           // != 0: `out` / `out1` are written split-packed in this precision's operand form (woft_conv_params.out_fmt)
 };
 
 // One row group (8 rows x 32 columns of a transposed tile) in two steps, so that a caller can issue the operand loads of
@@ -173,11 +176,7 @@ __device__ __forceinline__ EpiOps epi_load(const EpiRegs& a, const int64_t m, co
     EpiOps o;
     o.b4 = bias4;
     o.o0 = o.o1 = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (!nok) {
-        // split-packed output, ragged last group (WOFT_EPI_RELU): the group is stored whole, its tail = the first values of e0's row
-        if (EPI == WOFT_EPI_RELU && a.pk != 0 && !a.e0.null()) o.o0 = a.e0.ld4(m * a.lde0);
-        return o;
-    }
+    if (!nok) return o;
     if (!a.bias_map.null()) o.b4 = a.bias_map.ld4(m * a.ld_bias_map + n);
     if (EPI == WOFT_EPI_RELU_RES_RELU || EPI == WOFT_EPI_GRU_Q) o.o0 = a.e0.ld4(m * a.lde0 + n);
     if (EPI == WOFT_EPI_GRU_ZR && n >= a.split) o.o0 = a.e0.ld4(m * a.lde0 + (n - a.split));
@@ -215,36 +214,18 @@ __device__ __forceinline__ f32x4 epi_finish(const EpiRegs& a, const f32x4 v, con
             if (n >= a.split) {                        // split % 4 == 0 (validated): whole vector is r
 #pragma unroll
                 for (int e = 0; e < 4; ++e) y[e] *= o.o0[e];
-#ifdef WOFT_EPI_MXP
-                if (a.pk1 == 4) { if (!a.no_store) a.out1.st_mxp(m * a.ldo1, n - a.split, y); } else
-#endif
-                if (!a.no_store) a.out1.st4(m * a.ldo1 + (n - a.split), a.pk1 != 0 ? pack_split_rt(y, a.pk1) : y);
+                if (!a.no_store) a.out1.st4(m * a.ldo1 + (n - a.split), y);
                 stored = true;
             }
             break;
         case WOFT_EPI_GRU_Q:
 #pragma unroll
             for (int e = 0; e < 4; ++e) y[e] = (1.f - o.o1[e]) * o.o0[e] + o.o1[e] * tanh_t<FAST>(y[e]);
-            // (the state in both forms: fp32 for the next gates' element-wise reads, split-packed for the convs that read it)
-#ifdef WOFT_EPI_MXP
-            if (a.pk1 == 4) { if (!a.no_store) a.out1.st_mxp(m * a.ldo1, n, y); } else
-#endif
-            if (a.pk1 != 0 && !a.no_store) a.out1.st4(m * a.ldo1 + n, pack_split_rt(y, a.pk1));
             break;
         default: break;
     }
     if (stored) return ypre;
-    if (a.pk != 0) {
-        if (!nok) {                                    // ragged group: completed from e0 (epi_load) or with zeros
-#pragma unroll
-            for (int e = 1; e < 4; ++e)
-                if (e >= nrag) y[e] = o.o0[e - nrag];
-        }
-#ifdef WOFT_EPI_MXP
-        if (a.pk == 4) a.out.st_mxp(m * a.ldo, a.co_off + n, y); else
-#endif
-        a.out.st4(m * a.ldo + a.co_off + n, pack_split_rt(y, a.pk));
-    } else if (nok) {
+    if (nok) {
         a.out.st4(m * a.ldo + a.co_off + n, y);
     } else {                                           // ragged group (element-wise kinds only)
 #pragma unroll
@@ -353,8 +334,6 @@ __device__ __forceinline__ void conv_epilogue_t(const woft_conv_params& p, f32x1
     a.split = keep_sgpr(p.split); a.epi = keep_sgpr(p.epi); a.alpha = keep_sgpr(p.alpha);
     a.no_store = p.out_w == -12345;                            // (micro-benchmark ablation, tools/bench_conv.py)
     a.fast = p.precision != 0 && p.out_w != -12346;            // (-12346: developer ablation, library gate functions)
-    a.pk = keep_sgpr((p.out_fmt & 1) ? p.precision : 0);
-    a.pk1 = keep_sgpr((p.out_fmt & 2) ? p.precision : 0);
     const GPtr stat_sum = keep_gptr(p.stat_sum), stat_sq = keep_gptr(p.stat_sq);
     const int cout_pad = keep_sgpr(p.cout_pad);
     const bool do_stats = !stat_sum.null();

@@ -1,61 +1,21 @@
-// LDS-halo convolution with the WEIGHT operand streamed global -> registers (no LDS stage, no LDS-DMA, no
-// per-tap barrier).  Same GEMM formulation, arithmetic modes and epilogues as conv_halo_bf16_kernel (conv.hip):
-// stride 1, taps 3x3 / 1x5 / 5x1, split-bf16 operands on v_mfma_f32_32x32x16_bf16, fp32 accumulation.
-//
-// Why: in conv_halo_bf16_kernel every (tap, 32-channel chunk) K step copies a weight tile global -> LDS with LDS-DMA
-// and publishes it with a workgroup barrier; measured per step of a 128 x 128 tile (round-1 in-kernel timeline):
-// 300 cycles of DMA issue + 930 of fragment reads / MFMAs + 260-350 waiting for the DMA + 230 in the barrier, i.e.
-// the matrix pipe idles more than half of a step.  Here a wave owns a 32-column band of the output tile for ALL of
-// the tile's rows, so nobody else needs its weights: they are pre-packed on the host in MFMA-fragment order
-// ([32-column band][chunk][tap][plane hi, lo][k half][64 lanes][8 bf16] -- the wave's whole K loop is ONE contiguous
-// stream, every fragment one fully coalesced 1-KiB global_load_dwordx4) and fetched straight into VGPRs a few steps
-// ahead (a register ring).  What remains in LDS is the input halo (double buffered), what remains of the
-// synchronisation is ONE barrier per 32-channel chunk (= per 5 or 9 K steps), and between barriers the four waves
-// of a workgroup drift freely, so that one wave's memory waits sit beside another's MFMAs on the CU.
-//
-//   WM = 1: 4 waves x (128 rows x 32 columns): BN = 128, weights read once per workgroup.
-//   WM = 2: 2 x 2 waves x (64 rows x 32 columns): BN = 64 (the two row halves fetch the same fragments; L1 serves
-//           the second), for layers with too few 128-wide tiles.
-#include <type_traits>
-
-#if defined(WOFT_ONLY_PREC) && WOFT_ONLY_PREC == 4
-#define WOFT_EPI_MXP 1                 // the shared epilogue's MXP stores exist in these parts only (mxp.h)
-#include "mxp.h"
-#endif
-#include "conv_common.h"
-#include "halo_map.h"
+// conv_regb_kernel: one output tile of the register-streamed convolution (conv_regb_body.h) per workgroup; one layer per launch,
+// or two independent layers that select the same instance (woft_conv2d_pair).
+#include "conv_regb_body.h"
 
 extern int g_regb_dyn_lds;          // conv.hip (woft_set_tuning key 3)
 
-// Build parts (woft_amd/build.py): this file is compiled once per (precision code, input format) -- WOFT_ONLY_PREC in {1, 2, 3},
-// WOFT_ONLY_PK in {0, 1} -- each part exporting woft_conv_regb_launch_p<prec>_<pk>; conv.hip's dispatcher of the same precision
-// picks the part by the layer's in_fmt.
-#if !defined(WOFT_ONLY_PREC) || !defined(WOFT_ONLY_PK)
-#error "conv_regb.hip is compiled in parts: -DWOFT_ONLY_PREC=1|2|3|4 -DWOFT_ONLY_PK=0|1 (woft_amd/build.py)"
+// Build parts (woft_amd/build.py): this file is compiled once per precision code -- WOFT_ONLY_PREC in {1, 2, 3, 4} -- each part
+// exporting woft_conv_regb_launch_p<prec>; conv.hip's dispatcher of the same precision calls it.
+#if !defined(WOFT_ONLY_PREC)
+#error "conv_regb.hip is compiled in parts: -DWOFT_ONLY_PREC=1|2|3|4 (woft_amd/build.py)"
 #endif
-#define WOFT_CAT4_(a, b, c, d) a##b##c##d
-#define WOFT_CAT4(a, b, c, d) WOFT_CAT4_(a, b, c, d)
-#define WOFT_REGB_ENTRY WOFT_CAT4(woft_conv_regb_launch_p, WOFT_ONLY_PREC, _, WOFT_ONLY_PK)
+#define WOFT_CAT2_(a, b) a##b
+#define WOFT_CAT2(a, b) WOFT_CAT2_(a, b)
+#define WOFT_REGB_ENTRY WOFT_CAT2(woft_conv_regb_launch_p, WOFT_ONLY_PREC)
 
 namespace {
 
-using woft::BK;
-
-// NORM (compile time; encoder layers, round 3): p.in_norm != 0 -- the producer's InstanceNorm (+ ReLU) applied while the halo is
-// converted, with conv_halo_bf16_kernel's expression (bit-identical); the per-channel statistics of the chunk travel with its halo rows.
-// TERMS = 28 (precision code 4, "f16mx8"; round 4): an fp32-emulating product in TWO matrix-pipe passes instead of
-// bf16x3's three --  a * w ~= fp16(a) * fp16(w) + mx8(a - fp16(a)) * mx8(w) + mx8(a) * mx8(w - fp16(w)):  main term on
-// v_mfma_f32_32x32x16_f16, both cross terms on the block-scaled v_mfma_scale_f32_32x32x64_f8f6f4 (fp8 e4m3, one E8M0 scale per
-// 32-element K block; twice the bf16 rate).  K = 64 of one scaled MFMA = TWO TAPS x this chunk's 32 channels: MX block 0 = tap t,
-// block 1 = tap t + 1 (operand convention pinned by tools/micro/mx_layout_probe.hip: block b = bytes 16 b .. 16 b + 15 of both
-// lane halves, lane half hh = channels 16 hh .. + 15, block b's scale = the scale operand of lane half b).  Per halo row and chunk
-// the LDS holds the fp16 plane (as TERMS = 16) plus two fp8 planes -- mx8(a), mx8(a - fp16(a)): 32 data bytes + the block's scale
-// byte, 48-byte pitch -- written by the loader; the weights' three forms come pre-packed (wgt_frag: fp16 fragments, wgt_mx: the
-// fp8 fragments of w and of w - fp16(w) per tap pair with their scales).  Measured error 2.2-2.3 x bf16x3's (mx_split_probe).
-// PK (compile time; round 4): both input sources are SPLIT-PACKED (woft_conv_params.in_fmt): a halo row's 16 bytes already
-// are [hi[0..3] | lo[0..3]] of its four channels -- the loader copies them into the two LDS planes, no conversion.
-template <int TY, int TX, int KY, int KX, int WM, int TERMS, int NBUF, int DIST, int AD, int CU = 1, int HD = 1, bool IL = true,
-          bool NORM = false, bool PK = (WOFT_ONLY_PK != 0)>
+template <int TY, int TX, int KY, int KX, int WM, int TERMS, int NBUF, int DIST, int AD>
 __global__ __launch_bounds__(256, 2) void conv_regb_kernel(const woft_conv_params pa, const woft_conv_params pb, const int split) {
     // (two independent layers that run on the same instance of this kernel may share ONE launch -- woft_conv2d_pair: the
     //  workgroups [0, split) belong to the first layer, the rest to the second; split = gridDim.x for a single layer)
@@ -63,562 +23,15 @@ __global__ __launch_bounds__(256, 2) void conv_regb_kernel(const woft_conv_param
     const woft_conv_params p = second_layer ? pb : pa;     // (a copy: a REFERENCE selected between the two argument
                                                             //  structs does not compile -- 'illegal VGPR to SGPR copy')
     const int bid = second_layer ? (int)blockIdx.x - split : (int)blockIdx.x;
-    constexpr int NWAVES = 4;
-    constexpr int NPIX = TY * TX;
-    constexpr int BM = (NPIX + 31) / 32 * 32;
-    constexpr int WN = NWAVES / WM;
-    constexpr int BN = 32 * WN;
-    constexpr int WROWS = BM / WM;
-    constexpr int TM = WROWS / 32;
-    constexpr int NP = (TERMS == 3) ? 2 : 1;
-    constexpr bool MX = (TERMS == 28);
-    constexpr int MT = MX ? 16 : TERMS;                                   // conversion / MFMA type of the (main) term
-    constexpr int TAPS = KY * KX;
-    constexpr int NPAIR = (TAPS + 1) / 2;                                 // MX: tap pairs per chunk (an odd last tap pairs with zero weights)
-    static_assert(!MX || !NORM, "f16mx8: no norm-on-load");
-    // CU: chunks per unrolled group (the ring slot of step s = chunk * TAPS + tap must be a compile-time constant:
-    // (CU * TAPS) % NBUF == 0; multi-tap layers: CU = 1, TAPS % NBUF == 0; 1x1 layers: TAPS = 1, CU = NBUF).
-    // HD: how many chunks ahead the input tile is requested (1x1: a chunk is a single K step, too short to cover HBM latency)
-    static_assert((CU * TAPS) % NBUF == 0 && DIST >= 1 && DIST < NBUF && CU % HD == 0, "register ring: static slots");
-    static_assert(BM % (32 * WM) == 0, "bad wave layout");
-    constexpr int HX = TX + KX - 1, HY = TY + KY - 1, HROWS = HX * HY;
-    constexpr int RH = (HROWS + 31) / 32;
-    constexpr int QPITCH = 48;                                            // MX: bytes per row of an fp8 plane (32 data + scale + pad)
-    constexpr int Q_PLANE = HROWS * QPITCH / 2;                           // ... in bf16-sized elements
-    constexpr int A_PLANE = HROWS * LDB, A_ELEMS = NP * A_PLANE + (MX ? 2 * Q_PLANE : 0);   // one halo buffer (bf16 elements)
-    constexpr int STAGE_ELEMS = 2 * NWAVES * TM * woft::STAGE_FLOATS;     // epilogue staging: all TM tiles of every wave
-    constexpr int SMEM_ELEMS = (2 * A_ELEMS > STAGE_ELEMS) ? 2 * A_ELEMS : STAGE_ELEMS;
-    constexpr int STEP_ELEMS = NP * 2 * 64 * 8;                           // fragment elements of one K step of a band
-    __shared__ __attribute__((aligned(16))) __bf16 smem[SMEM_ELEMS];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
-    const int r32 = lane & 31, hh = lane >> 5;
-    const int v = tid & 7, r0 = tid >> 3;
-
+    using G = RegbGeom<TY, TX, KY, KX, WM, TERMS>;
+    __shared__ __attribute__((aligned(16))) __bf16 smem[G::SMEM_ELEMS];
     const int tyn = (p.ho + TY - 1) / TY, txn = (p.wo + TX - 1) / TX;
     int m_tile, n_tile;
-    woft::tile_of_block(bid, p.n_img * tyn * txn, p.cout_pad / BN, m_tile, n_tile);
-    const int img0 = m_tile / (tyn * txn);
-    const int trem = m_tile - img0 * (tyn * txn);
-    const int y0 = (trem / txn) * TY, x0 = (trem % txn) * TX;
-    const int n0 = n_tile * BN;
-    const int nchunk = p.cin_pad / BK;
-    const int nsteps = nchunk * TAPS;
-
-    int hpix[RH];
-    bool hok[RH];
-#pragma unroll
-    for (int j = 0; j < RH; ++j) {
-        const int ht = r0 + 32 * j;
-        const int hy = ht / HX, hx = ht - hy * HX;
-        const int iy = y0 + hy - p.pad_y, ix = x0 + hx - p.pad_x;
-        hok[j] = ht < HROWS && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w;
-        // (PK: taps outside the image read the ZERO PIXEL ROW that follows a split-packed tensor -- pixel index n_img * h * w,
-        //  see woft_conv_params.in_fmt -- so the loader needs no per-element select)
-        hpix[j] = hok[j] ? (img0 * p.h + iy) * p.w + ix : (PK ? p.n_img * p.h * p.w : 0);
-    }
-    f32x4 rh[HD][RH];                                    // ring: the input tile of chunk c waits in rh[c % HD]
-    f32x4 nmu[HD], nrs[HD];                              // NORM: mean / rstd of the chunk's channels 4 v .. 4 v + 3
-    auto load_halo = [&](int chunk, auto slot_tag) {
-        constexpr int hs = decltype(slot_tag)::value;
-        const int c0 = chunk * BK;
-        const bool second = (p.in1 != nullptr) && (c0 >= p.c_split);
-        // (wave-uniform base + 32-bit lane offset: the scalar-base addressing form -- with the lane's 4 v folded into the base the
-        //  six addresses of a chunk cost ~34 vector instructions of 64-bit arithmetic, and those add to the MFMAs' SIMD time)
-        const float* src = second ? p.in1 + (c0 - p.c_split) : p.in0 + c0;
-        const int cs = second ? p.cs1 : p.cs0;
-#pragma unroll
-        for (int j = 0; j < RH; ++j) rh[hs][j] = *(const f32x4*)(src + (uint32_t)(hpix[j] * cs + 4 * v));
-        if constexpr (NORM) {
-            nmu[hs] = *(const f32x4*)(p.in_mean + c0 + 4 * v);
-            nrs[hs] = *(const f32x4*)(p.in_rstd + c0 + 4 * v);
-        }
-    };
-    auto store_halo_row = [&](__bf16* As, auto slot_tag, auto j_tag) {      // one of this thread's RH halo rows -> LDS
-        constexpr int hs = decltype(slot_tag)::value, j = decltype(j_tag)::value;
-        const int ht = r0 + 32 * j;
-        if (RH * 32 > HROWS && ht >= HROWS) return;
-        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-        f32x4 x = rh[hs][j];
-        if constexpr (NORM) {                            // (zero padding applies to the NORMALISED map: select afterwards)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float y = (x[e] - nmu[hs][e]) * nrs[hs][e];
-                if (p.in_norm == 2) y = fmaxf(y, 0.f);
-                x[e] = y;
-            }
-        }
-#ifdef WOFT_EPI_MXP
-        if constexpr (PK && MX) {
-            // MXP input (mxp.h): the row's 128 bytes are [fp16 x 32 | fp8(a) x 32 | fp8(a - fp16(a)) x 32] -- lanes v = 0 .. 3 carry the
-            // fp16 plane's 16-byte pieces, 4 / 5 the first fp8 plane's, 6 / 7 the second's: one LDS write each, no conversion; the
-            // block's scale is re-derived from the fp16 magnitudes (the producer's rule) and written by lane 0.
-            typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-            char* qpa = (char*)(As + A_PLANE) + ht * QPITCH;
-            char* fp = (char*)(As + ht * LDB);
-            char* dst = v < 4 ? fp + 16 * v : (v < 6 ? qpa + 16 * (v - 4) : qpa + 2 * Q_PLANE + 16 * (v - 6));
-            *(f32x4*)dst = x;
-            const u32x4_t w = __builtin_bit_cast(u32x4_t, x) & 0x7fff7fffu;
-            uint32_t m = max(max(w[0] & 0xffffu, w[0] >> 16), max(w[1] & 0xffffu, w[1] >> 16));
-            m = max(m, max(max(w[2] & 0xffffu, w[2] >> 16), max(w[3] & 0xffffu, w[3] >> 16)));
-            m = dpp_max8_u32(v < 4 ? m : 0u);
-            if (v == 0) {
-                const uint32_t sa = (m >> 10) + 105u;
-                qpa[32] = (char)sa;
-                (qpa + 2 * Q_PLANE)[32] = (char)(sa - 11u);
-            }
-            return;
-        }
-#endif
-        if constexpr (PK) {                              // (the zero row supplied the padding: a plain copy)
-            static_assert(!NORM, "split-packed inputs are final activations");
-            *(bf16x4*)(As + ht * LDB + 4 * v) = packed_hi(x);
-            if (NP == 2) *(bf16x4*)(As + A_PLANE + ht * LDB + 4 * v) = packed_lo(x);
-            return;
-        }
-        const f32x4 val = hok[j] ? x : zero;
-        if constexpr (MX) {
-            // fp16 plane + the two block-scaled fp8 planes of this row's 32 channels (the row's 8 loader lanes = one MX block)
-            const bf16x4 h16 = cvt16<16>(val);
-            *(bf16x4*)(As + ht * LDB + 4 * v) = h16;
-            const f32x4 la = val - __builtin_convertvector(__builtin_bit_cast(f16x4, h16), f32x4);
-            float ma = fmaxf(fmaxf(fabsf(val[0]), fabsf(val[1])), fmaxf(fabsf(val[2]), fabsf(val[3])));
-            // block maximum over the row's eight loader lanes (an aligned group of 8): three DPP steps on the vector ALU -- half-row
-            // mirror (i <-> 7 - i), then the quad swaps xor 1 and xor 2.  (The first version used __shfl_xor = ds_bpermute: three
-            // dependent LDS round trips per row, and every lgkmcnt wait also drained the fragment prefetches behind them.)
-            auto dpp_max = [](float x, auto ctrl_tag) {
-                constexpr int ctrl = decltype(ctrl_tag)::value;
-                const int xi = __builtin_bit_cast(int, x);
-                const int yi = __builtin_amdgcn_update_dpp(xi, xi, ctrl, 0xf, 0xf, false);
-                return fmaxf(x, __builtin_bit_cast(float, yi));
-            };
-            ma = dpp_max(ma, std::integral_constant<int, 0x141>{});     // row_half_mirror
-            ma = dpp_max(ma, std::integral_constant<int, 0xB1>{});      // quad_perm [1,0,3,2]
-            ma = dpp_max(ma, std::integral_constant<int, 0x4E>{});      // quad_perm [2,3,0,1]
-            // E8M0 scale 2^(s - 127) with the block maximum scaled into [128, 256) (e4m3's largest: 448): s = biased exponent - 7.
-            // The remainder a - fp16(a) is at most 2^-11 of its element, so ITS block needs no maximum of its own: scale s - 11
-            // keeps it below 256 too, and e4m3's fourteen octaves leave room for blocks whose remainders happen to be smaller.
-            int sa = (int)((__builtin_bit_cast(uint32_t, ma) >> 23) & 0xffu) - 7;
-            sa = sa < 11 ? 11 : sa;
-            const int sl = sa - 11;
-            const float ia = __builtin_bit_cast(float, (uint32_t)(254 - sa) << 23), il = __builtin_bit_cast(float, (uint32_t)(254 - sl) << 23);
-            int qa = 0, ql = 0;
-            qa = __builtin_amdgcn_cvt_pk_fp8_f32(val[0] * ia, val[1] * ia, qa, false);
-            qa = __builtin_amdgcn_cvt_pk_fp8_f32(val[2] * ia, val[3] * ia, qa, true);
-            ql = __builtin_amdgcn_cvt_pk_fp8_f32(la[0] * il, la[1] * il, ql, false);
-            ql = __builtin_amdgcn_cvt_pk_fp8_f32(la[2] * il, la[3] * il, ql, true);
-            char* qpa = (char*)(As + A_PLANE) + ht * QPITCH;
-            char* qpl = qpa + 2 * Q_PLANE;
-            *(int*)(qpa + 4 * v) = qa;
-            *(int*)(qpl + 4 * v) = ql;
-            if (v == 0) { qpa[32] = (char)sa; qpl[32] = (char)sl; }
-            return;
-        }
-        const bf16x4 hi = cvt16<TERMS>(val);
-        *(bf16x4*)(As + ht * LDB + 4 * v) = hi;
-        if (NP == 2) {
-            const f32x4 rem = val - widen_bf16x4(hi);
-            *(bf16x4*)(As + A_PLANE + ht * LDB + 4 * v) = __builtin_convertvector(rem, bf16x4);
-        }
-    };
-    auto store_halo = [&](__bf16* As, auto slot_tag) {
-        [&]<int... J>(std::integer_sequence<int, J...>) {
-            (store_halo_row(As, slot_tag, std::integral_constant<int, J>{}), ...);
-        }(std::make_integer_sequence<int, RH>{});
-    };
-
-    // this wave's weight stream: band (n0 / 32 + wn), steps in (chunk, tap) order, STEP_ELEMS per step
-    const __bf16* wstream = (const __bf16*)p.wgt_frag + (int64_t)(n0 / 32 + wn) * nsteps * STEP_ELEMS + lane * 8;
-    bf16x8 bq[NBUF][NP][2];
-    auto fetch_b = [&](int step, auto slot_tag) {
-        constexpr int slot = decltype(slot_tag)::value;
-        const int s = step < nsteps ? step : nsteps - 1;                // (past the end: a harmless repeat)
-        const __bf16* src = wstream + (int64_t)s * STEP_ELEMS;
-#pragma unroll
-        for (int pl = 0; pl < NP; ++pl)
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) bq[slot][pl][s2] = *(const bf16x8*)(src + (pl * 2 + s2) * 512);
-    };
-
-    f32x16 acc[TM];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-
-    int a_off[TM];                   // element offset of this lane's A row inside a halo buffer (tap (0,0), k half hh)
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        bool valid;
-        const int pl = halo_row_pixel<TY, TX>(wm * WROWS + i * 32 + r32, valid);
-        a_off[i] = ((pl / TX) * HX + (pl % TX)) * LDB + hh * 8;
-    }
-
-    // MX: byte offset of this lane's row inside an fp8 plane (tap (0, 0)): data of its channel half at + 16 hh, scale byte at + 32
-    int q_off[TM];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        bool valid;
-        const int pl = halo_row_pixel<TY, TX>(wm * WROWS + i * 32 + r32, valid);
-        q_off[i] = ((pl / TX) * HX + (pl % TX)) * QPITCH;
-    }
-    // MX: this wave's fp8 weight stream -- per (chunk, tap pair, term): 64 lanes x 32 data bytes, then 64 scale dwords
-    typedef int i32x8 __attribute__((ext_vector_type(8)));
-    typedef int i32x4 __attribute__((ext_vector_type(4)));
-    constexpr int MXQ = 64 * 32 + 64 * 4;                                  // bytes per (pair, term)
-    const char* wmx = MX ? (const char*)p.wgt_mx + (int64_t)(n0 / 32 + wn) * nchunk * NPAIR * 2 * MXQ : nullptr;
-    i32x8 wq[1][2];                                                        // [one register set][term: w (meets l_a), l_w (meets a)]
-    int wsc[1][2];
-    auto fetch_mx = [&](int pair_idx, auto slot_tag) {                     // pair_idx = chunk * NPAIR + pair (clamped at the end)
-        constexpr int slot = decltype(slot_tag)::value;
-        const int last = nchunk * NPAIR - 1;
-        const char* src = wmx + (int64_t)(pair_idx < last ? pair_idx : last) * (2 * MXQ);
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const i32x4 lo = *(const i32x4*)(src + t * MXQ + lane * 32), hi = *(const i32x4*)(src + t * MXQ + lane * 32 + 16);
-            wq[slot][t] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            wsc[slot][t] = *(const int*)(src + t * MXQ + 64 * 32 + lane * 4);
-        }
-    };
-
+    woft::tile_of_block(bid, p.n_img * tyn * txn, p.cout_pad / G::BN, m_tile, n_tile);
     // developer probe (tools/regb_probe.py): s_memtime stamps of wave 0 -> in_rstd (unused by this kernel otherwise)
-    unsigned long long* stamps = (p.in_mean == (const float*)1 && wave == 0 && lane == 0)
+    unsigned long long* stamps = (p.in_mean == (const float*)1 && threadIdx.x == 0)
                                      ? (unsigned long long*)p.in_rstd + (size_t)bid * 32 : nullptr;
-    if (stamps) { stamps[0] = __builtin_amdgcn_s_memtime(); stamps[30] = __builtin_amdgcn_s_memrealtime(); }
-    // ---- prologue: halo of chunk 0, the first DIST steps of the weight stream ---------------------------------
-    [&]<int... C>(std::integer_sequence<int, C...>) {
-        ((C < nchunk ? load_halo(C, std::integral_constant<int, C % HD>{}) : (void)0), ...);
-    }(std::make_integer_sequence<int, HD>{});
-    [&]<int... S>(std::integer_sequence<int, S...>) {
-        (fetch_b(S, std::integral_constant<int, S % NBUF>{}), ...);
-    }(std::make_integer_sequence<int, DIST>{});
-    if constexpr (MX) fetch_mx(0, std::integral_constant<int, 0>{});
-    store_halo(smem, std::integral_constant<int, 0>{});
-    __syncthreads();
-
-    // One 32-channel chunk = TAPS K steps, fully unrolled into "pairs": (tap, k half, two row tiles) = 4 (2 in plain
-    // bf16) A-fragment reads + 6 (2) MFMAs, issued term-major so that consecutive MFMAs never chain on one accumulator.
-    // The fragments of pair q + AD are requested BEFORE the MFMAs of pair q (ring of AD + 1 register sets) and
-    // sched_barriers keep it that way: left to itself the compiler sinks every ds_read next to its use and follows it
-    // with s_waitcnt lgkmcnt -- each pair then waits out the full LDS latency (PMC of that version: matrix pipe 55 %
-    // busy while LDS, L1 and L2 were all under 30 % busy).
-    constexpr int PT = TM, NQ = TAPS * PT, AR = AD + 1;                  // pairs per tap / per chunk
-    static_assert(TM % 2 == 0, "row tiles are processed in pairs");
-    static_assert(!IL || NQ >= RH, "interleaved halo conversion: one thread-row per pair");
-    auto run_chunk = [&](int chunk, auto more_tag, auto phase_tag) {
-        constexpr bool more = decltype(more_tag)::value;
-        constexpr int phase = decltype(phase_tag)::value;                // chunk % CU
-        const __bf16* As = smem + (chunk & 1) * A_ELEMS;
-        bf16x8 aq[AR][2][NP];
-        auto load_a = [&](auto q_tag) {
-            constexpr int q = decltype(q_tag)::value;
-            constexpr int tap = q / PT, r = q % PT, s2 = r / (TM / 2), i0 = 2 * (r % (TM / 2));
-            constexpr int ky = tap / KX, kx = tap - ky * KX;
-#pragma unroll
-            for (int d = 0; d < 2; ++d)
-#pragma unroll
-                for (int pl = 0; pl < NP; ++pl)
-                    aq[q % AR][d][pl] = *(const bf16x8*)(As + a_off[i0 + d] + pl * A_PLANE + (ky * HX + kx) * LDB + s2 * 16);
-        };
-        [&]<int... Q>(std::integer_sequence<int, Q...>) { (load_a(std::integral_constant<int, Q>{}), ...); }
-        (std::make_integer_sequence<int, (AD < NQ ? AD : NQ)>{});
-        __builtin_amdgcn_sched_barrier(0);
-        [&]<int... Q>(std::integer_sequence<int, Q...>) {
-            ([&] {
-                constexpr int q = Q;
-                constexpr int tap = q / PT, r = q % PT, s2 = r / (TM / 2), i0 = 2 * (r % (TM / 2));
-                constexpr int slot = (phase * TAPS + tap) % NBUF, as = q % AR;
-                if constexpr (r == 0) {
-                    // weights of step (chunk, tap) + DIST into the slot that step (chunk, tap) - (NBUF - DIST) vacated
-                    fetch_b(chunk * TAPS + tap + DIST, std::integral_constant<int, (phase * TAPS + tap + DIST) % NBUF>{});
-                    // input tile of chunk + HD into the ring slot chunk's own tile left at the end of the previous chunk
-                    if (tap == 0 && chunk + HD < nchunk) load_halo(chunk + HD, std::integral_constant<int, phase % HD>{});
-                }
-                if constexpr (q + AD < NQ) load_a(std::integral_constant<int, q + AD>{});
-                __builtin_amdgcn_sched_barrier(0);
-                // IL: the next chunk's halo (requested at the first tap of this chunk) is converted and written to the other
-                // buffer ONE thread-row per pair over the last RH pairs of the chunk, its ~20 vector / LDS instructions
-                // placed in the issue gaps between this pair's MFMAs (sched_group_barrier: 1 MFMA, then up to 4 others)
-                // instead of as one block after the last MFMA, where the matrix pipe idled for the whole conversion
-                constexpr bool il_row = IL && more && q >= NQ - RH;
-                if constexpr (il_row)
-                    store_halo_row(smem + ((chunk + 1) & 1) * A_ELEMS, std::integral_constant<int, (phase + 1) % HD>{},
-                                   std::integral_constant<int, q - (NQ - RH)>{});
-                if (NP == 2) {
-                    acc[i0] = mma16<TERMS>(aq[as][0][NP - 1], bq[slot][0][s2], acc[i0]);
-                    acc[i0 + 1] = mma16<TERMS>(aq[as][1][NP - 1], bq[slot][0][s2], acc[i0 + 1]);
-                    acc[i0] = mma16<TERMS>(aq[as][0][0], bq[slot][NP - 1][s2], acc[i0]);
-                    acc[i0 + 1] = mma16<TERMS>(aq[as][1][0], bq[slot][NP - 1][s2], acc[i0 + 1]);
-                }
-                acc[i0] = mma16<TERMS>(aq[as][0][0], bq[slot][0][s2], acc[i0]);
-                acc[i0 + 1] = mma16<TERMS>(aq[as][1][0], bq[slot][0][s2], acc[i0 + 1]);
-                if constexpr (il_row) {
-#pragma unroll
-                    for (int g = 0; g < (NP == 2 ? 6 : 2); ++g) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
-                        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);      // up to three VALU
-                        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // up to one LDS write
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                // next chunk's halo -> the other buffer (free since the barrier that ended the previous chunk); late
-                // in the chunk so that its loads had the whole chunk to land
-                if constexpr (q == NQ - 1 && !IL) {
-                    if (more) store_halo(smem + ((chunk + 1) & 1) * A_ELEMS, std::integral_constant<int, (phase + 1) % HD>{});
-                }
-            }(), ...);
-        }(std::make_integer_sequence<int, NQ>{});
-        if (more) __syncthreads();
-        if (stamps && chunk < 12) stamps[1 + chunk] = __builtin_amdgcn_s_memtime();
-    };
-    // ---- f16mx8: one chunk = TAPS fp16 steps (2 MFMAs per row tile) + NPAIR tap pairs of two scaled fp8 MFMAs per row tile.
-    //      Register diet (the first version spilled 170-900 bytes per lane): the main term's A fragments are two half sets --
-    //      k half 1 of tap t is requested before the MFMAs of its k half 0, k half 0 of tap t + 1 before the MFMAs of k half 1 --;
-    //      the fp8 fragments go row tile by row tile, one tile ahead; the fp8 weights of pair p + 1 are requested right after pair
-    //      p's MFMAs consumed the single register set (two taps of lead).
-#ifndef MX_FENCE
-#define MX_FENCE __builtin_amdgcn_sched_barrier(0)
-#endif
-    auto run_chunk_mx = [&](int chunk, auto more_tag) {
-        constexpr bool more = decltype(more_tag)::value;
-        static_assert(CU == 1 && HD == 1, "f16mx8: multi-tap layers");
-        const __bf16* As = smem + (chunk & 1) * A_ELEMS;
-        const char* Qa = (const char*)(As + A_PLANE);
-        const char* Ql = Qa + 2 * Q_PLANE;
-        // Two pipelines.  DEEP (two row tiles per wave: the 64-column and the 4 x 16-pixel layouts): ALL fragments of tap t + 1 -- and,
-        // at a pair's last tap, the pair's fp8 fragments and scales -- are requested before the MFMAs of tap t (two register sets by
-        // tap parity).  Four row tiles per wave (8 x 16 pixels x 128 columns) do not have the registers: the main term's fragments go
-        // as two half sets (k half 1 of tap t before the MFMAs of its k half 0, k half 0 of tap t + 1 before those of k half 1), the
-        // fp8 fragments row tile by row tile.
-        constexpr bool DEEP = TM <= 2;
-        constexpr bool AM2 = DEEP && TAPS <= 5;                            // (3x3: the two-set form spills -- half sets there too)
-        constexpr int NAM = AM2 ? 2 : 1;
-        bf16x8 am[NAM][2][TM];                                             // [tap parity][k half][row tile]
-        auto load_am = [&](auto tap_tag, auto s2_tag) {
-            constexpr int tap = decltype(tap_tag)::value, s2 = decltype(s2_tag)::value;
-            constexpr int ky = tap / KX, kx = tap - ky * KX;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) am[AM2 ? (tap & 1) : 0][s2][i] = *(const bf16x8*)(As + a_off[i] + (ky * HX + kx) * LDB + s2 * 16);
-        };
-        i32x8 qa[DEEP ? TM : 1], ql[DEEP ? TM : 1];
-        int sqa[DEEP ? TM : 1], sql[DEEP ? TM : 1];
-        auto load_q = [&](auto pr_tag, auto i_tag) {
-            constexpr int pr = decltype(pr_tag)::value, i = decltype(i_tag)::value, sb = DEEP ? i : 0;
-            constexpr int t0 = 2 * pr, t1 = (2 * pr + 1 < TAPS) ? 2 * pr + 1 : 2 * pr;                    // (odd tail: zero weights)
-            constexpr int o0 = ((t0 / KX) * HX + (t0 % KX)) * QPITCH, o1 = ((t1 / KX) * HX + (t1 % KX)) * QPITCH;
-            const char* ra = Qa + q_off[i] + 16 * hh;
-            const char* rl = Ql + q_off[i] + 16 * hh;
-            const i32x4 a0 = *(const i32x4*)(ra + o0), a1 = *(const i32x4*)(ra + o1);
-            const i32x4 l0 = *(const i32x4*)(rl + o0), l1 = *(const i32x4*)(rl + o1);
-            qa[sb] = i32x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-            ql[sb] = i32x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
-            const int so = q_off[i] + (hh ? o1 : o0) + 32;                 // lane half b supplies block b's scale
-            sqa[sb] = *(const unsigned char*)(Qa + so);
-            sql[sb] = *(const unsigned char*)(Ql + so);
-        };
-        load_am(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
-        if constexpr (AM2) load_am(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
-        [&]<int... T>(std::integer_sequence<int, T...>) {
-            ([&] {
-                constexpr int tap = T, ab = AM2 ? (tap & 1) : 0;
-                constexpr int slot = tap % NBUF;                           // (CU == 1, TAPS % NBUF == 0: static ring slots)
-                constexpr bool pair_end = (tap & 1) == 1 || tap == TAPS - 1;
-                constexpr int pr = tap / 2;
-                fetch_b(chunk * TAPS + tap + DIST, std::integral_constant<int, (tap + DIST) % NBUF>{});
-                if (tap == 0 && chunk + 1 < nchunk) load_halo(chunk + 1, std::integral_constant<int, 0>{});
-                if constexpr (AM2) {
-                    if constexpr (tap + 1 < TAPS) {
-                        load_am(std::integral_constant<int, tap + 1>{}, std::integral_constant<int, 0>{});
-                        load_am(std::integral_constant<int, tap + 1>{}, std::integral_constant<int, 1>{});
-                    }
-                } else {
-                    load_am(std::integral_constant<int, tap>{}, std::integral_constant<int, 1>{});
-                }
-                if constexpr (DEEP) {
-                    // the pair's fp8 fragments a tap ahead (at the pair's first tap) where the registers allow it: the 1x5 / 5x1 instances
-                    // (41.7 -> 37.7 us on the GRU's q conv); the 3x3 instance spills with the longer live range (85 -> 125 us)
-                    constexpr bool QEARLY = TAPS <= 5 && TY == 4;     // (the 8 x 16-pixel 1x5 / 5x1 instances spill with it)
-                    if constexpr (QEARLY ? (tap & 1) == 0 : pair_end)
-                        [&]<int... I>(std::integer_sequence<int, I...>) {
-                            (load_q(std::integral_constant<int, pr>{}, std::integral_constant<int, I>{}), ...);
-                        }(std::make_integer_sequence<int, TM>{});
-                }
-                MX_FENCE;
-                // DEEP: the next chunk's halo (requested at tap 0) is converted and written to the other buffer ONE thread-row per half
-                // tap over the last RH half taps, its ~80 vector / cross-lane / LDS instructions in the issue shadow of this half
-                // tap's MFMAs -- as one block after the last MFMA it cost ~3 k of a 9.4 k-cycle chunk (stamps, first version)
-                constexpr int NHS = 2 * TAPS;                              // half-tap slots per chunk
-                constexpr bool ILX = DEEP && NHS >= RH;
-                constexpr int rowa = 2 * tap - (NHS - RH), rowb = rowa + 1;
-                if constexpr (ILX && more && rowa >= 0 && rowa < RH)
-                    store_halo_row(smem + ((chunk + 1) & 1) * A_ELEMS, std::integral_constant<int, 0>{}, std::integral_constant<int, (rowa >= 0 && rowa < RH) ? rowa : 0>{});
-#pragma unroll
-                for (int i = 0; i < TM; ++i) acc[i] = mma16<16>(am[ab][0][i], bq[slot][0][0], acc[i]);
-                if constexpr (ILX && more && rowa >= 0 && rowa < RH) {
-#pragma unroll
-                    for (int g = 0; g < TM; ++g) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
-                        __builtin_amdgcn_sched_group_barrier(0x002, 24, 0);     // then a share of the row's vector work
-                        __builtin_amdgcn_sched_group_barrier(0x080, 4, 0);      // and of its cross-lane / LDS instructions
-                    }
-                    MX_FENCE;
-                }
-                if constexpr (ILX && more && rowb >= 0 && rowb < RH)
-                    store_halo_row(smem + ((chunk + 1) & 1) * A_ELEMS, std::integral_constant<int, 0>{}, std::integral_constant<int, (rowb >= 0 && rowb < RH) ? rowb : 0>{});
-                if constexpr (!AM2) {
-                    MX_FENCE;
-                    if constexpr (tap + 1 < TAPS) load_am(std::integral_constant<int, tap + 1>{}, std::integral_constant<int, 0>{});
-                    MX_FENCE;
-                }
-#pragma unroll
-                for (int i = 0; i < TM; ++i) acc[i] = mma16<16>(am[ab][1][i], bq[slot][0][1], acc[i]);
-                if constexpr (pair_end) {
-                    if constexpr (DEEP) {
-                        // term-major: consecutive MFMAs never chain on one accumulator (a dependent scaled MFMA waits out the whole
-                        // 16-pass latency of its predecessor: the tile-major first version gained nothing over bf16x3)
-#pragma unroll
-                        for (int i = 0; i < TM; ++i)
-                            acc[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ql[i], wq[0][0], acc[i], 0, 0, 0, sql[i], 0, wsc[0][0]);
-#pragma unroll
-                        for (int i = 0; i < TM; ++i)
-                            acc[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(qa[i], wq[0][1], acc[i], 0, 0, 0, sqa[i], 0, wsc[0][1]);
-                    } else {
-                        [&]<int... I>(std::integer_sequence<int, I...>) {
-                            ([&] {
-                                constexpr int i = I;
-                                load_q(std::integral_constant<int, pr>{}, std::integral_constant<int, i>{});
-                                acc[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ql[0], wq[0][0], acc[i], 0, 0, 0, sql[0], 0, wsc[0][0]);
-                                acc[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(qa[0], wq[0][1], acc[i], 0, 0, 0, sqa[0], 0, wsc[0][1]);
-                            }(), ...);
-                        }(std::make_integer_sequence<int, TM>{});
-                    }
-                    // the NEXT pair's fp8 weights into the register set these MFMAs just read
-                    fetch_mx(chunk * NPAIR + pr + 1, std::integral_constant<int, 0>{});
-                }
-                MX_FENCE;
-            }(), ...);
-        }(std::make_integer_sequence<int, TAPS>{});
-        // next chunk's halo -> the other buffer (its loads had the whole chunk to land)
-        if (stamps && chunk < 12) stamps[16 + chunk] = __builtin_amdgcn_s_memtime();        // (probe: MFMAs of the chunk issued)
-        if (more) {
-            if constexpr (!(DEEP && 2 * TAPS >= RH)) store_halo(smem + ((chunk + 1) & 1) * A_ELEMS, std::integral_constant<int, 0>{});
-            __syncthreads();
-        }
-        if (stamps && chunk < 12) stamps[1 + chunk] = __builtin_amdgcn_s_memtime();
-    };
-    auto run_phase = [&](int chunk, auto more_tag) {     // chunk % CU selects the unrolled body with the right ring slots
-        if constexpr (MX) {
-            run_chunk_mx(chunk, more_tag);
-        } else if constexpr (CU == 1) {
-            run_chunk(chunk, more_tag, std::integral_constant<int, 0>{});
-        } else {
-            const int ph = chunk % CU;
-            [&]<int... P>(std::integer_sequence<int, P...>) {
-                ((ph == P ? run_chunk(chunk, more_tag, std::integral_constant<int, P>{}) : (void)0), ...);
-            }(std::make_integer_sequence<int, CU>{});
-        }
-    };
-    for (int chunk = 0; chunk + 1 < nchunk; ++chunk) run_phase(chunk, std::true_type{});
-    run_phase(nchunk - 1, std::false_type{});
-    __syncthreads();                                     // halo buffers are dead: reuse them as epilogue staging
-
-    const HaloRowMap<TY, TX> rowmap{img0, p.n_img, y0, x0, p.ho, p.wo};
-    if (p.epi == WOFT_EPI_FLOWHEAD) {
-        // (f16mx8: the epilogue's small second conv keeps the split-bf16 arithmetic; its W2 fragments are packed for it)
-        constexpr int ET = MX ? 3 : TERMS, ENP = (ET == 3) ? 2 : 1;
-        // Flow head, second conv folded into the first one's epilogue (update.py:10-17: conv2(relu(conv1(h))), 3 x 3, 2
-        // output channels).  A 3 x 3 conv is linear in its input pixels: delta[q] = b2 + sum_taps <W2[tap], y[q + tap]>, so
-        // this launch emits, per pixel p and tap, the 2 partial dot products s[p][tap][o] = <W2[o][:, tap], y[p]> over the
-        // channels this workgroup holds (18 values per pixel) and woft_flow_head_gather adds the 9 neighbours' shares --
-        // the 256-channel activation (33 MB at 1/8 of 1080p, the store tail of this launch and three reads of the next)
-        // is never written.  The partial products run on the matrix cores: relu(acc + bias) is transposed through the
-        // wave's LDS staging area into A fragments (lane = pixel row, k = its 32 channels), split into bf16 hi / lo as any
-        // other activation, and multiplied with the pre-split W2 fragments of the band (p.e0, [band][k half][plane][64][8],
-        // column j = tap * 2 + o, 18 of 32 used).  The 32-channel shares of the waves of one row group are totalled in a
-        // fixed order through LDS; the column tiles' shares land in separate planes of p.out ([n_tile][pixel][ldo]).
-        float* stage = (float*)smem + wave * TM * woft::STAGE_FLOATS;
-        const int ncol = n0 + wn * 32;
-        f32x4 bv[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            bv[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (p.bias != nullptr) bv[q] = *(const f32x4*)(p.bias + ncol + (q >> 1) * 16 + 8 * hh + (q & 1) * 4);
-        }
-        const __bf16* wf = (const __bf16*)p.e0 + (int64_t)(ncol / 32) * (2 * ENP * 512) + lane * 8;
-        bf16x8 w2[2][ENP];
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-            for (int pl = 0; pl < ENP; ++pl) w2[s2][pl] = *(const bf16x8*)(wf + (s2 * ENP + pl) * 512);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                stage[i * woft::STAGE_FLOATS + ((r & 3) + 8 * (r >> 2) + 4 * hh) * woft::STAGE_LD + r32] = acc[i][r];
-        __builtin_amdgcn_wave_barrier();
-        f32x16 sacc[TM];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const float* row = stage + i * woft::STAGE_FLOATS + r32 * woft::STAGE_LD + 8 * hh;
-            bf16x8 ah[2], al[2];
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    f32x4 yv = *(const f32x4*)(row + 16 * s2 + 4 * q);
-                    const f32x4 b4 = bv[2 * s2 + q];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) yv[e] = fmaxf(p.alpha * yv[e] + b4[e], 0.f);
-                    const bf16x4 hi = cvt16<ET>(yv);
-                    bf16x4 lo = hi;
-                    if constexpr (ENP == 2) lo = __builtin_convertvector(yv - widen_bf16x4(hi), bf16x4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { ah[s2][4 * q + e] = hi[e]; al[s2][4 * q + e] = lo[e]; }
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sacc[i][r] = 0.f;
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                if (ENP == 2) {
-                    sacc[i] = mma16<ET>(al[s2], w2[s2][0], sacc[i]);
-                    sacc[i] = mma16<ET>(ah[s2], w2[s2][ENP - 1], sacc[i]);
-                }
-                sacc[i] = mma16<ET>(ah[s2], w2[s2][0], sacc[i]);
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        constexpr int SLD = 20;                          // floats per pixel row of a share: 18 values + 2 (16-byte rows)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (r32 < SLD) stage[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh) * SLD + r32] = sacc[i][r];
-        __syncthreads();
-        const int64_t M = (int64_t)p.n_img * p.ho * p.wo;
-        float* dst = p.out + (int64_t)n_tile * M * p.ldo;
-        for (int idx = tid; idx < BM * (SLD / 4); idx += 256) {
-            const int row = idx / (SLD / 4), c4 = (idx - row * (SLD / 4)) * 4;
-            const int wmr = row / WROWS, lr = row - wmr * WROWS;
-            f32x4 t = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int w_ = 0; w_ < WN; ++w_)
-                t += *(const f32x4*)((const float*)smem + (wmr * WN + w_) * TM * woft::STAGE_FLOATS + lr * SLD + c4);
-            const int64_t m = rowmap(row);
-            if (m >= 0) *(f32x4*)(dst + m * p.ldo + c4) = t;
-        }
-        return;
-    }
-    f32x16 acc2[TM][1];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) acc2[i][0] = acc[i];
-    if (stamps) stamps[14] = __builtin_amdgcn_s_memtime();
-    woft::conv_epilogue_t<TM, 1, WROWS, 32, TM>(p, acc2, (float*)smem + wave * TM * woft::STAGE_FLOATS, rowmap, n0, wm, wn,
-                                                lane, m_tile, stamps ? stamps + 16 : nullptr);
-    if (stamps) { stamps[15] = __builtin_amdgcn_s_memtime(); stamps[31] = __builtin_amdgcn_s_memrealtime(); }
+    regb_tile<TY, TX, KY, KX, WM, TERMS, NBUF, DIST, AD>(p, m_tile, n_tile, smem, stamps);
 }
 
 template <int WM, int TY = 8>
@@ -633,40 +46,18 @@ int launch_regb(const woft_conv_params& p, const woft_conv_params* second, hipSt
     dim3 grid((unsigned)(blocks(p) + (second ? blocks(pb) : 0)));
 #define REGB(KY, KX, T, NB, D) \
     woft_launch(0, conv_regb_kernel<TY, TX, KY, KX, WM, T, NB, D, 2>, grid, dim3(256), (size_t)g_regb_dyn_lds, s, p, pb, split)
-#if WOFT_ONLY_PK == 0
-#define REGB_NORM_INSTANCE(T) \
-            if (p.taps_y == 3 && p.taps_x == 3 && second == nullptr)                                        \
-                woft_launch(0, conv_regb_kernel<TY, TX, 3, 3, WM, T, 3, 2, 2, 1, 1, true, true>, grid, dim3(256), (size_t)g_regb_dyn_lds, s, p, pb, split); \
-            else return WOFT_EINVAL;
-#else
-#define REGB_NORM_INSTANCE(T) return WOFT_EINVAL;
-#endif
 #define REGB_TAPS(T)                                                     \
-    if (p.in_norm != 0) {                 /* encoder residual blocks: 3x3, 8x16 x 64 tiles, single layer */ \
-        if constexpr (WM == 2 && TY == 8) {                                                                 \
-            REGB_NORM_INSTANCE(T)                                                                           \
-        } else return WOFT_EINVAL;                                                                          \
-    } else if (p.taps_y == 3 && p.taps_x == 3) REGB(3, 3, T, 3, 2);      \
+    if (p.taps_y == 3 && p.taps_x == 3) REGB(3, 3, T, 3, 2);             \
     else if (p.taps_y == 1 && p.taps_x == 5) REGB(1, 5, T, 5, 3);        \
     else if (p.taps_y == 5 && p.taps_x == 1) REGB(5, 1, T, 5, 3);        \
-    else if (p.taps_y == 1 && p.taps_x == 1) {    /* 1x1: three chunks per unrolled group, input tile three chunks ahead; \
-                                                     64-column tiles only (the 128-column layout does not fit 256 registers) */ \
-        if constexpr (WM == 2 && TY == 8)                                                                                       \
-            woft_launch(0, conv_regb_kernel<TY, TX, 1, 1, WM, T, 3, 2, 1, 3, 3, false>, grid, dim3(256), (size_t)g_regb_dyn_lds, s, p, pb, split); \
-        else return WOFT_EINVAL;                                                                                                \
-    } else return WOFT_EINVAL
+    else return WOFT_EINVAL
     if (p.precision != WOFT_ONLY_PREC) return WOFT_EINVAL;
 #if WOFT_ONLY_PREC == 1
     REGB_TAPS(3);
 #elif WOFT_ONLY_PREC == 3
     REGB_TAPS(16);
 #elif WOFT_ONLY_PREC == 4
-    // f16mx8: the multi-tap instances only (no norm-on-load, no 1x1)
-    if (p.in_norm != 0 || p.wgt_mx == nullptr || pb.wgt_mx == nullptr) return WOFT_EINVAL;
-    for (const woft_conv_params* q : {&p, &pb})      // MXP outputs (out_fmt with this precision): whole 32-channel blocks
-        if (((q->out_fmt & 1) != 0 && (q->co_off % 32 != 0 || q->ldo % 32 != 0)) ||
-            ((q->out_fmt & 2) != 0 && (q->ldo1 % 32 != 0 || q->split % 32 != 0)))
-            return WOFT_EINVAL;
+    if (p.wgt_mx == nullptr || pb.wgt_mx == nullptr) return WOFT_EINVAL;
     if (p.taps_y == 3 && p.taps_x == 3) REGB(3, 3, 28, 3, 2);
     else if (p.taps_y == 1 && p.taps_x == 5) REGB(1, 5, 28, 5, 3);
     else if (p.taps_y == 5 && p.taps_x == 1) REGB(5, 1, 28, 5, 3);
@@ -685,32 +76,22 @@ int launch_regb(const woft_conv_params& p, const woft_conv_params* second, hipSt
 // bands of 64 rows -- the per-wave work of the 8 x 16 x 64 layout with the weights fetched once per workgroup), after its
 // argument checks.
 int WOFT_REGB_ENTRY(const woft_conv_params& p, const woft_conv_params* second, void* stream) {
-    // input format of this part: both sources split-packed (WOFT_ONLY_PK = 1) or both fp32
-    for (const woft_conv_params* q : {&p, second}) {
-        if (q == nullptr) continue;
-        const int want = WOFT_ONLY_PK ? ((q->in1 != nullptr) ? 3 : 1) : 0;
-        if ((q->in_fmt & 3) != want || (WOFT_ONLY_PK && q->in_norm != 0)) return WOFT_EINVAL;
-    }
     if (second != nullptr) {            // one launch for two layers: the same kernel instance, no probe
         const woft_conv_params& b = *second;
         if (b.halo != p.halo || b.tile_n != p.tile_n || b.taps_y != p.taps_y || b.taps_x != p.taps_x || b.precision != p.precision ||
             b.wgt_frag == nullptr || b.in_norm != 0 || b.in_mean != nullptr || p.in_mean != nullptr || b.wh0_lookup != nullptr ||
-            b.epi == WOFT_EPI_WH_MEAN || b.cout_pad % b.tile_n != 0 || (p.taps_y * p.taps_x == 1))
+            b.epi == WOFT_EPI_WH_MEAN || b.cout_pad % b.tile_n != 0)
             return WOFT_EINVAL;
         if (b.epi == WOFT_EPI_FLOWHEAD && (b.e0 == nullptr || b.ldo < 20 || b.ldo % 4 != 0 || b.co_off != 0 || b.cout % 32 != 0)) return WOFT_EINVAL;
     }
     if (p.halo == 12) {
         if (p.wgt_frag == nullptr || p.in_norm != 0 || (p.in_mean != nullptr && p.in_mean != (const float*)1) || p.wh0_lookup != nullptr ||
-            p.epi == WOFT_EPI_WH_MEAN || p.epi == WOFT_EPI_FLOWHEAD || p.tile_n != 128 || p.cout_pad % 128 != 0 || p.taps_y * p.taps_x == 1) return WOFT_EINVAL;
+            p.epi == WOFT_EPI_WH_MEAN || p.epi == WOFT_EPI_FLOWHEAD || p.tile_n != 128 || p.cout_pad % 128 != 0) return WOFT_EINVAL;
         return launch_regb<1, 4>(p, second, (hipStream_t)stream);
     }
     if (p.wgt_frag == nullptr || p.wh0_lookup != nullptr || p.epi == WOFT_EPI_WH_MEAN) return WOFT_EINVAL;
-    if (p.in_norm != 0) {               // InstanceNorm applied on load: the 3x3 / 64-column instance only
-        if (p.in_mean == nullptr || p.in_mean == (const float*)1 || p.in_rstd == nullptr || p.in1 != nullptr || p.tile_n != 64 ||
-            p.taps_y != 3 || p.taps_x != 3 || second != nullptr || p.epi == WOFT_EPI_FLOWHEAD)
-            return WOFT_EINVAL;
-    } else if (p.in_mean != nullptr && p.in_mean != (const float*)1) return WOFT_EINVAL;
-    if (p.stat_sum != nullptr && p.tile_n != 64) return WOFT_EINVAL;    // (statistics rows: two row halves per tile = the 2 x 2 wave layout)
+    if (p.in_norm != 0 || p.stat_sum != nullptr) return WOFT_EINVAL;    // (InstanceNorm plumbing: the LDS-halo kernel, conv.hip)
+    if (p.in_mean != nullptr && p.in_mean != (const float*)1) return WOFT_EINVAL;
     if (p.epi == WOFT_EPI_FLOWHEAD && (p.e0 == nullptr || p.ldo < 20 || p.ldo % 4 != 0 || p.co_off != 0 || p.cout % 32 != 0)) return WOFT_EINVAL;
     if (p.tile_n == 128 && p.cout_pad % 128 == 0) return launch_regb<1>(p, second, (hipStream_t)stream);
     if (p.tile_n == 64 && p.cout_pad % 64 == 0) return launch_regb<2>(p, second, (hipStream_t)stream);

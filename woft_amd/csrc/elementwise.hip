@@ -1,20 +1,8 @@
 // Streaming (HBM-bound) helpers: input normalisation, InstanceNorm finalize/apply, 2x2 pooling.
 #include "common.h"
 #include "halo_map.h"
-#include "mxp.h"
 
 namespace {
-
-// ---- fp32 activation rows -> split-packed rows (woft_conv_params.in_fmt): group of 4 channels -> [hi[0..3] | lo[0..3]] ----
-template <int TERMS>
-__global__ void pack_split_kernel(const float* __restrict__ x, int64_t rows, int32_t c4, int32_t ldx, float* __restrict__ out,
-                                  int32_t ldo) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rows * c4) return;
-    const int64_t r = i / c4;
-    const int g = (int)(i - r * c4);
-    *(f32x4*)(out + r * ldo + 4 * g) = pack_split<TERMS>(*(const f32x4*)(x + r * ldx + 4 * g));
-}
 
 // ---- uint8 BGR HWC -> normalised RGB NHWC4 with replicate padding ------------------------------
 __global__ void preprocess_kernel(const uint8_t* __restrict__ img, int h, int w, float* __restrict__ out,
@@ -264,7 +252,7 @@ __global__ __launch_bounds__(256) void feature_pyramid_kernel(const PyrArgs a) {
 
 }  // namespace
 
-extern "C" int woft_abi_version(void) { return 10000 * 0 + 100 * 1 + 0; }
+extern "C" int woft_abi_version(void) { return 10000 * 0 + 100 * 2 + 0; }
 
 extern "C" int woft_preprocess_bgr_u8(const uint8_t* img, int32_t h, int32_t w, float* out, int32_t hp, int32_t wp,
                                       int32_t pad_top, int32_t pad_left, void* stream) {
@@ -337,40 +325,5 @@ extern "C" int woft_feature_pyramid(const float* in, int32_t h, int32_t w, int32
     const dim3 grid((unsigned)(((h + 7) / 8) * ((w + 7) / 8)));
     if (terms == 3) hipLaunchKernelGGL(feature_pyramid_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(feature_pyramid_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a);
-    return woft_launch_status();
-}
-
-// MXP (precision 4, mxp.h): one thread per four channels, the eight threads of a 32-channel block adjacent
-__global__ void pack_mxp_kernel(const float* __restrict__ x, int64_t rows, int32_t c4, int32_t ldx, float* __restrict__ out, int32_t ldo) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rows * c4) return;                       // (c4 % 8 == 0, 256 threads per block: whole 8-lane groups leave together)
-    const int64_t r = i / c4;
-    const int g = (int)(i - r * c4);
-    const MxpWords w = mxp_pack(*(const f32x4*)(x + r * ldx + 4 * g));
-    char* blk = (char*)(out + r * ldo + 32 * (g >> 3));
-    const int j = g & 7;
-    *(uint32_t*)(blk + 8 * j) = w.h0;
-    *(uint32_t*)(blk + 8 * j + 4) = w.h1;
-    *(uint32_t*)(blk + 64 + 4 * j) = w.qa;
-    *(uint32_t*)(blk + 96 + 4 * j) = w.ql;
-}
-
-extern "C" int woft_pack_split(const float* x, int64_t rows, int32_t channels, int32_t ldx, int32_t precision, float* out,
-                               int32_t ldo, void* stream) {
-    if (!x || !out || rows <= 0 || channels <= 0 || channels % 4 != 0 || ldx % 4 != 0 || ldo % 4 != 0 || ldx < channels ||
-        ldo < channels || precision < 1 || precision > 4)
-        return WOFT_EINVAL;
-    if (precision == 4) {                             // MXP: whole 32-channel blocks, not in place
-        if (channels % 32 != 0 || ldx % 32 != 0 || ldo % 32 != 0 || x == out) return WOFT_EINVAL;
-        hipLaunchKernelGGL(pack_mxp_kernel, dim3((unsigned)ceil_div64(rows * (channels / 4), 256)), dim3(256), 0, (hipStream_t)stream, x, rows,
-                           channels / 4, ldx, out, ldo);
-        return woft_launch_status();
-    }
-    const int64_t n = rows * (channels / 4);
-    const dim3 grid((unsigned)ceil_div64(n, 256));
-    hipStream_t s = (hipStream_t)stream;
-    if (precision == 1) hipLaunchKernelGGL(pack_split_kernel<3>, grid, dim3(256), 0, s, x, rows, channels / 4, ldx, out, ldo);
-    else if (precision == 3) hipLaunchKernelGGL(pack_split_kernel<16>, grid, dim3(256), 0, s, x, rows, channels / 4, ldx, out, ldo);
-    else hipLaunchKernelGGL(pack_split_kernel<1>, grid, dim3(256), 0, s, x, rows, channels / 4, ldx, out, ldo);
     return woft_launch_status();
 }

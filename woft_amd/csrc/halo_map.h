@@ -36,41 +36,6 @@ __device__ __forceinline__ f32x4 widen_bf16x4(const bf16x4 h) {
     r[3] = __builtin_bit_cast(float, w[1] & 0xffff0000u);
     return r;
 }
-// ---- split-packed activations (woft_conv_params.in_fmt / out_fmt) --------------------------------
-// The 16 bytes of a 4-channel group: [hi[0..3] | lo[0..3]], hi = cvt16<TERMS>(x), lo = bf16(x - hi) (TERMS == 3), else zero --
-// the very expressions the fp32-input loaders apply, evaluated once by the producer.
-template <int TERMS>
-__device__ __forceinline__ f32x4 pack_split(const f32x4 x) {
-    const bf16x4 hi = cvt16<TERMS>(x);
-    bf16x4 lo = __builtin_bit_cast(bf16x4, (unsigned long long)0);
-    if constexpr (TERMS == 3) lo = __builtin_convertvector(x - widen_bf16x4(hi), bf16x4);
-    typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
-    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-    const u32x2_t h = __builtin_bit_cast(u32x2_t, hi), l = __builtin_bit_cast(u32x2_t, lo);
-    const u32x4_t w = {h[0], h[1], l[0], l[1]};
-    return __builtin_bit_cast(f32x4, w);
-}
-// run-time form for the shared epilogue: prec = woft_conv_params.precision (1 bf16x3, 2 bf16, 3 fp16)
-__device__ __forceinline__ f32x4 pack_split_rt(const f32x4 x, const int prec) {
-    return prec == 1 ? pack_split<3>(x) : prec == 3 ? pack_split<16>(x) : pack_split<1>(x);
-}
-// (element-wise on 32-bit words: `__builtin_bit_cast(u64x2, w)[1]` -- indexing the bit-cast temporary -- is miscompiled by this
-//  toolchain to element 0, seen in the ISA: both LDS planes received the hi words)
-__device__ __forceinline__ bf16x4 packed_hi(const f32x4 w) {
-    typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
-    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-    const u32x4_t u = __builtin_bit_cast(u32x4_t, w);
-    const u32x2_t r = {u[0], u[1]};
-    return __builtin_bit_cast(bf16x4, r);
-}
-__device__ __forceinline__ bf16x4 packed_lo(const f32x4 w) {
-    typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
-    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-    const u32x4_t u = __builtin_bit_cast(u32x4_t, w);
-    const u32x2_t r = {u[2], u[3]};
-    return __builtin_bit_cast(bf16x4, r);
-}
-
 template <int TERMS>
 __device__ __forceinline__ f32x16 mma16(const bf16x8 a, const bf16x8 b, const f32x16 c) {
     if constexpr (TERMS == 16)

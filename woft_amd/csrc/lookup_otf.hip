@@ -20,23 +20,10 @@
 #include "common.h"
 #include "dma.h"
 
-// build-time switches of two round-3 experiments (compile this file with -DOTF_IL=0/1 -DOTF_SAMPLE_UNROLL=n).  Measured at
-// 1080p feature size (tools/bench_lookup_otf.py, one GPU call): round-2 kernel 85.4 us; centre read before the A fragments +
-// no spilled LDS addresses 82.0 us (per-level set-up 2.8 k -> 0.6 k cycles); the same with OTF_IL = 1: 88.3 us -- the
-// pieces of group g + 2 then leave up to a group later and the stream's lead shrinks; sampling unroll 3 vs 21: +-0
-#ifndef OTF_IL
-#define OTF_IL 0                 // 1: DMA pieces issued one per k sub-step instead of four in a row after the barrier
-#endif
-#ifndef OTF_PIPE
-#define OTF_PIPE 0               // 1: the window drop of chunk c - 1 is spread over the MFMA sub-steps of chunk c (see the chunk loop):
-#endif                           //    bit-identical (tested), 81.3 vs 81.9 us alone and +-0 in a frame (A/B in one call) -- the drop was not
-                                 //    the chunk's exposed cost (round-2 ablation: 51 of 89 us remain without MFMAs, stream and drops); off
-#ifndef OTF_PROBE
-#define OTF_PROBE 0              // 1: compile the per-K-step-group phase probe in (ablate & 32, tools/bench_lookup_otf.py OTF_ABL=32)
-#endif
-#ifndef OTF_SAMPLE_UNROLL
-#define OTF_SAMPLE_UNROLL 3      // unroll factor of the sampling loop (21: fully unrolled)
-#endif
+// Measured and NOT kept (rounds 2-3, tools/bench_lookup_otf.py; the code is in the git history): DMA pieces issued one per k
+// sub-step instead of four in a row after the barrier (88.3 vs 82.0 us); the window drop of chunk c - 1 spread under the MFMAs of
+// chunk c (81.3 vs 81.9 us, +-0 in a frame); a fully unrolled sampling loop (+-0, spills at 256 registers).
+#define OTF_SAMPLE_UNROLL 3      // unroll factor of the sampling loop
 
 namespace {
 
@@ -72,7 +59,6 @@ __global__ __launch_bounds__(TW * 32, 2) void corr_lookup_otf_kernel(const woft_
     __shared__ int2 s_w0[NPX];                          // window origin (x, y) of every source pixel at the current level
     __shared__ float s_fx[NPX], s_fy[NPX];
     __shared__ float2 s_cc[NPX];                         // lookup centre of every source pixel (level 0 units)
-    __shared__ float s_dump[NT];                         // where a lane's accumulator element goes when no window wants it (OTF_PIPE)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -184,15 +170,6 @@ __global__ __launch_bounds__(TW * 32, 2) void corr_lookup_otf_kernel(const woft_
     int n_stamp = 0;
     auto stamp = [&]() { if (stamps && n_stamp < 24) stamps[n_stamp++] = (uint32_t)__builtin_amdgcn_s_memtime(); };
     stamp();
-    // second probe (ablate & 32): the phases of every K-step group of ONE chunk (level 0, second chunk) -- kept in LDS (a global
-    // store would count in vmcnt and disturb the DMA waits it is timing), written out after the last level
-    __shared__ uint32_t s_probe[24];
-    // (round-3 reading, `-DOTF_PROBE=1`, cycles incl. ~100-180 per stamp: per group wait 184, barrier 132-150, DMA issue 444-760,
-    //  fragment reads + MFMAs 620-776; after the fourth group the window drop 2 100 -- 9.2 k per probed chunk)
-    const bool probe = OTF_PROBE && (p.ablate & 32) && tid == 0 && p.ldo >= 4 * N2 + 24;
-    int n_probe = 0;
-    bool probe_on = false;
-    auto gstamp = [&]() { if (OTF_PROBE && probe_on && n_probe < 24) s_probe[n_probe++] = (uint32_t)__builtin_amdgcn_s_memtime(); };
     const int mypix = tid >> 2, part = tid & 3;         // sampling: 4 threads per source pixel
     const int gy = py0 + (mypix >> TSH), gx = px0 + (mypix & (TW - 1));
     const bool pvalid = gy < p.hf && gx < p.wf;
@@ -298,58 +275,27 @@ __global__ __launch_bounds__(TW * 32, 2) void corr_lookup_otf_kernel(const woft_
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         int c0 = 0;
-        // OTF_PIPE (build-time experiment, measured neutral): hypothesis -- the two workgroups of a CU run in phase, so a chunk
-        // costs its MFMAs (both waves of a SIMD serialised on the matrix pipe) PLUS its window drop, nothing overlapping.
-        // The drop of chunk c - 1 (accumulator copy `accp`) is therefore issued one accumulator
-        // element per MFMA sub-step of chunk c -- a wave's vector and LDS instructions issue while its own MFMA runs, the
-        // next (dependent) MFMA waits for the pipe anyway.  Same cells, same values: bit-identical.
-        constexpr int NSTEPS = (NK / GS) * (GS * NSUB);   // MFMA sub-steps per chunk (16; 8 for the small model's split rows)
-        constexpr int RPS = 16 / NSTEPS;                  // accumulator elements dropped per sub-step
-        static_assert(RPS >= 1 && RPS * NSTEPS == 16, "drop schedule: 16 accumulator rows over the sub-steps of a chunk");
-        f32x16 accp;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) accp[r] = 0.f;
-        int txp = 0, typ = 0;
-        bool okp = false;                                // (first chunk of a level: nothing to drop yet)
-        auto row_of = [&](int r) { return wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh; };
-        int2 w0n = s_w0[row_of(0)];                      // window origin of the next element to drop, one element ahead
-        auto drop_elem = [&](auto r_tag) {
-            constexpr int r = decltype(r_tag)::value;
-            const int2 w0c = w0n;
-            w0n = s_w0[row_of((r + 1) & 15)];            // (read BEFORE this element's write: LDS reads are not moved above LDS writes)
-            const int cx = txp - w0c.x, cy = typ - w0c.y;
-            // (an UNCONDITIONAL store through a selected address -- the window cell, or this lane's own dump word: a
-            //  conditional store is control flow, which ends the scheduling region and the whole drop sinks behind the MFMAs)
-            const bool hit = okp && (unsigned)cx < (unsigned)WS && (unsigned)cy < (unsigned)WS;
-            float* dst = hit ? Wn + (row_of(r) * WLD + cy * WS + cx) : s_dump + tid;
-            *dst = accp[r] * p.alpha;
-        };
         stamp();
         for (int s0 = 0; s0 < S; s0 += NK) {             // one 64-column chunk per iteration, K steps unrolled
             [&]<int... KGS>(std::integer_sequence<int, KGS...>) {
             ([&] {
-                constexpr int KG = KGS, kg = KGS;        // (compile time: the drop schedule below names accumulator elements)
+                constexpr int kg = KGS;
                 const int g = s0 / GS + kg;
-                if (OTF_PROBE && kg == 0) probe_on = probe && l == 0 && s0 == NK;
-                gstamp();
                 // this group's pieces have landed; those of the following (up to DEPTH - 1) groups may still fly
                 const int rem = G - 1 - g;
                 if (rem >= DEPTH - 1) dma_wait<(DEPTH - 1) * GS * QPW>();
                 else dma_wait<0>();
-                gstamp();
                 __syncthreads();                         // ... for every wave; and group g - 1 is fully consumed
-                gstamp();
                 // the GS * QPW pieces of group g + DEPTH go into the stages of group g - 1, all of them right after the barrier
-                // (OTF_IL = 1, one per k sub-step between the fragment reads and the MFMAs, measured 6 us slower: see above)
+                // (one per k sub-step between the fragment reads and the MFMAs measured 6 us slower: see above)
                 const bool feed = g + DEPTH < G;
-                if (feed && (!OTF_IL || (p.ablate & 2))) {
+                if (feed) {
 #pragma unroll
                     for (int e = 0; e < GS; ++e) issue((g + DEPTH) * GS + e);
                 }
                 // the GS steps of the group as one list of k sub-steps; the B fragments of sub-step u + 1 are requested
                 // before the MFMAs of sub-step u (two register sets) -- left alone the compiler reads, waits out the LDS
                 // latency and only then issues the three MFMAs, every sub-step
-                gstamp();
                 constexpr int NU = GS * NSUB;
                 bf16x8 bq[2][NPL];
                 auto load_b = [&](auto u_tag) {
@@ -372,11 +318,6 @@ __global__ __launch_bounds__(TW * 32, 2) void corr_lookup_otf_kernel(const woft_
                             const int ks = kg * GS + e;
                             if constexpr (u + 1 < NU) load_b(std::integral_constant<int, u + 1>{});
                             __builtin_amdgcn_sched_barrier(0);
-                            constexpr int NPC = GS * QPW;          // pieces per group, spread evenly over the NU sub-steps
-                            if constexpr (u % (NU / NPC) == 0) {
-                                constexpr int pc = u / (NU / NPC);
-                                if (OTF_IL && feed) issue_piece((g + DEPTH) * GS + pc / QPW, pc % QPW);
-                            }
                             const bf16x8 bh = bq[u & 1][0];
                             if (TERMS == 0) {
                                 const f32x4 a0 = __builtin_bit_cast(f32x4, afr[ks][s2][0]), a1 = __builtin_bit_cast(f32x4, afr[ks][s2][NPL - 1]);
@@ -394,39 +335,15 @@ __global__ __launch_bounds__(TW * 32, 2) void corr_lookup_otf_kernel(const woft_
                             } else {
                                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks][s2][0], bh, acc, 0, 0, 0);
                             }
-                            if (OTF_PIPE) {              // element(s) kg * NU + u of the PREVIOUS chunk's drop, under these MFMAs
-                                [&]<int... E>(std::integer_sequence<int, E...>) {
-                                    (drop_elem(std::integral_constant<int, (KG * NU + u) * RPS + E>{}), ...);
-                                }(std::make_integer_sequence<int, RPS>{});
-                                if (TERMS == 3) {        // one MFMA, then a third of the drop's vector work, three times
-                                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                                    __builtin_amdgcn_sched_group_barrier(0x102, 4 * RPS, 0);
-                                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                                    __builtin_amdgcn_sched_group_barrier(0x002, 4 * RPS, 0);
-                                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                                }
-                            }
                             __builtin_amdgcn_sched_barrier(0);
                         }(), ...);
                     }(std::make_integer_sequence<int, NU>{});
                 }
-                gstamp();
             }(), ...);
             }(std::make_integer_sequence<int, NK / GS>{});
             // ---- chunk complete: every lane drops its 16 correlations (one box position, 16 source pixels) into
             //      the windows that contain that position (zero outside the map = never written) ----
-            if (OTF_PIPE) {                              // ... during the NEXT chunk's MFMAs (after the loop for the last one)
-                const int pos = c0 + wn * 32 + r32;
-                const int by = pos / bw, bx = pos - by * bw;
-                txp = bx0 + bx;
-                typ = by0 + by;
-                okp = pos < N && !(p.ablate & 4);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    accp[r] = acc[r];
-                    acc[r] = 0.f;
-                }
-            } else {
+            {
                 const int pos = c0 + wn * 32 + r32;
                 const int by = pos / bw, bx = pos - by * bw;
                 const int tx = bx0 + bx, ty = by0 + by;  // target pixel of this column
@@ -446,18 +363,6 @@ __global__ __launch_bounds__(TW * 32, 2) void corr_lookup_otf_kernel(const woft_
                 }
             }
             c0 += 64;
-            gstamp();
-            probe_on = false;
-        }
-        if (OTF_PIPE && okp) {                           // the last chunk's drop (the all-reads-first form of the un-pipelined path)
-            int2 w0[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) w0[r] = s_w0[row_of(r)];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int cx = txp - w0[r].x, cy = typ - w0[r].y;
-                if (cx >= 0 && cx < WS && cy >= 0 && cy < WS) Wn[row_of(r) * WLD + cy * WS + cx] = accp[r] * p.alpha;
-            }
         }
         stamp();
         __syncthreads();
@@ -482,10 +387,6 @@ __global__ __launch_bounds__(TW * 32, 2) void corr_lookup_otf_kernel(const woft_
         }
         stamp();
         __syncthreads();
-    }
-    if (probe) {
-        uint32_t* o = (uint32_t*)(p.out + ((int64_t)py0 * p.wf + px0) * p.ldo + 4 * N2);
-        for (int i = 0; i < 24; ++i) o[i] = i < n_probe ? s_probe[i] : 0u;
     }
 }
 

@@ -25,38 +25,22 @@ from . import _lib, ops
 from .ops import Act, new_act
 
 EPI = _lib
-# the motion encoder's flow branch on a second HIP stream, beside the lookup and the correlation branch (off: one stream)
 # InstanceNorm encoders: conv1's output and the downsample branch stay raw for their consumers to normalise (0: materialised)
 DEFER_NORM = os.environ.get("WOFT_DEFER_NORM", "1") != "0"
-SIDE_STREAM = os.environ.get("WOFT_SIDE_STREAM", "0") != "0"
 # flow head: the 3x3 -> 2-channel conv folded into the first conv's epilogue + a per-pixel gather (0: two convs, the
 # second on the vector ALUs in exact fp32 -- woft_flow_head_update)
 FUSE_FLOWHEAD = os.environ.get("WOFT_FUSE_FLOWHEAD", "1") != "0"
 # motion encoder: the correlation branch (convc1 -> convc2) and the flow branch (convf1 -> convf2) are independent until
 # `conv` joins them (update.py:89-97): first layers in one launch, second layers in one launch (woft_conv2d_pair)
 PAIR_BRANCHES = os.environ.get("WOFT_PAIR", "1") != "0"
+# The seven register-streamed conv layers of a refinement iteration (convc2 | convf2, convm, z|r and q of both GRU half steps, the flow
+# head's conv) as ONE persistent launch: resident workgroups pull (layer, tile) work items from a queue and hand tiles to each other
+# through per-tile ready counters (csrc/update_pk.hip).  "0": one launch per layer (round 3's 9 launches)
+UPDATE_PK = os.environ.get("WOFT_UPDATE_PK", "0")
 PYRAMID_ONE_LAUNCH = os.environ.get("WOFT_PYRAMID", "1") != "0"    # target pyramid (pool + split of all levels) in one launch
 # the flow-head gather of iteration k runs inside the lookup launch of iteration k + 1 (volume-free lookup; the last
 # iteration's as its own launch): one launch fewer per iteration, same operations in the same order (0: always its own launch)
 FOLD_GATHER = os.environ.get("WOFT_FOLD_GATHER", "1") != "0"
-# SepConvGRU half step z|r -> q in one launch (woft_gru_halfstep: r*h recomputed on the q conv's halo and kept in LDS, z in
-# registers; one workgroup per 8 x 16 tile and per CU, so it is taken only where the tiles fill whole rounds of the 256 CUs)
-GRU_FUSE = os.environ.get("WOFT_GRU_FUSE", "0")          # "1": always, "auto": where the tiles fill whole rounds of the CUs
-# Split-packed activations in the update block (round 4; full model, split-bf16 / fp16 precisions): every activation that only
-# convolutions read (motion-encoder layers, r*h, the motion features; the GRU state additionally as a packed copy) is written by
-# its producer's epilogue in MFMA operand form -- [hi | lo] per 4-channel group, woft_conv_params.out_fmt -- and the consumers'
-# loaders copy instead of converting (in_fmt).  Same hi / lo values reach the matrix cores: bit-identical flows (tested).
-# OPT-IN (WOFT_PACKED=1): it removes 80 % of the vector instructions of the conv main loops (134 -> 26 per 108 MFMAs, ISA) and
-# changes NO launch time -- per-layer times equal within noise, frames/s 0 ... -1.5 % (the epilogues' conversions, the state's second
-# store) in three A/B runs: the main loops are bound by the matrix pipe that the two resident waves of a SIMD share, not by vector
-# issue.
-PACKED_ACTS = os.environ.get("WOFT_PACKED", "0") != "0"
-# ... and in precision "f16mx8": MXP (csrc/mxp.h: fp16 | fp8 | fp8 images of 32-channel blocks) between the layers that both run on the
-# register-streamed kernel's f16mx8 instances -- there the loader's conversion is ~60 vector instructions and ~25 registers per float4
-# in a main loop that is NOT matrix-pipe bound.  convc1 / convf1 (per-tap kernel) keep fp32 outputs.  (WOFT_PACKED_MX)
-# OPT-IN like the bf16x3 form, and for the same reason: measured -1 % frames/s (iteration 0.542 -> 0.560 ms: the three stores per lane of
-# the producing epilogues cost more than the copy-only loaders save; the conversion was not what held the f16mx8 main loops back either)
-PACKED_MX = os.environ.get("WOFT_PACKED_MX", "0") != "0"
 
 
 def _ru(x, m):
@@ -236,7 +220,6 @@ class _Plan:
         self.source_tag = None
         self.lookup_events = None
         self.wh_events = None      # bench hook: list collecting (start, end) HIP events per lookup launch
-        self._side, self._fork_ev, self._join_ev = torch.cuda.Stream(), torch.cuda.Event(), torch.cuda.Event()
         self.conv_events = None    # bench hook: {tag: [(start, end)]} for the tagged conv launches of the iteration program
         sp = eng.spec
         hf, wf = hp // 8, wp // 8
@@ -313,14 +296,6 @@ class _Plan:
         self.rh = new_act(1, hf, wf, sp.hdim, zero=True)
         self.hA = new_act(1, hf, wf, sp.hdim, zero=True)
         self.hB = new_act(1, hf, wf, sp.hdim, zero=True)
-        # split-packed update block (see PACKED_ACTS): packed copies of the GRU states; c1 / cf / fl1 / rh / the motion
-        # channels of xbuf simply hold the packed form.  Decided per plan: every layer that would read a packed tensor must
-        # select a kernel that takes one (the register-streamed or the per-tap kernel)
-        self.packed = bool((PACKED_MX if self.prec == "f16mx8" else PACKED_ACTS) and self.prec != "fp32" and not sp.small
-                           and ops.USE_REGB and ops.USE_HALO)
-        self.net0p = self.hAp = self.hBp = None
-        if self.packed:
-            self.net0p, self.hAp, self.hBp = (new_act(1, hf, wf, sp.hdim, zero=True) for _ in range(3))
         self.fh = new_act(1, hf, wf, 128 if sp.small else 256, zero=True)
         self.fh_part = None        # flow head folded into one conv launch: per-pixel partial products of its second conv
         self.delta = new_act(1, hf, wf, 2, cs=4, zero=True)
@@ -329,21 +304,13 @@ class _Plan:
                                                      self.corr.t, sp.radius, 3 if x3 else (0 if self.prec == "fp32" else 1))
         else:
             self.lookup = ops.make_lookup_params(self.vol, self.dims, self.coords, self.corr.t, sp.radius)
-        try:
-            self.prog_iter_first = self._iter_program(first=True)
-            self.prog_iter = self._iter_program(first=False)
-        except ValueError:                  # (a layer of this size selects a kernel without packed inputs: fp32 activations)
-            if not self.packed:
-                raise
-            self.packed = False
-            self.fh_part = None
-            self.prog_iter_first = self._iter_program(first=True)
-            self.prog_iter = self._iter_program(first=False)
+        self.prog_iter_first = self._iter_program(first=True)
+        self.prog_iter = self._iter_program(first=False)
         self.prog_mask = []
         if not sp.small:
             self.mk = new_act(1, hf, wf, 256, zero=True)
             self.mask = new_act(1, hf, wf, 576, zero=True)
-            self.prog_mask = [cp(self.hBp if self.packed else self.hB, eng.mk1, self.mk, epi=EPI.EPI_RELU, in_fmt=int(self.packed)),
+            self.prog_mask = [cp(self.hB, eng.mk1, self.mk, epi=EPI.EPI_RELU),
                               cp(self.mk, eng.mk2, self.mask)]
             # last iteration: the flow head's conv and the mask head's first conv both read the final GRU state and are
             # independent (update.py:132-135) -> one launch when they select the same kernel instance (woft_conv2d_pair)
@@ -552,9 +519,6 @@ class _Plan:
         e, cp, sp = self.eng, self._cp, self.eng.spec
         hd = sp.hdim
         h_in = self.net0 if first else self.hB
-        pk = int(self.packed)               # split-packed activations between the update block's layers (PACKED_ACTS)
-        pk1 = 0 if self.prec == "f16mx8" else pk   # ... of the per-tap kernel's layers (convc1, convf1): fp32 in f16mx8 (no MXP epilogue there)
-        packed_of = {id(self.net0): self.net0p, id(self.hA): self.hAp, id(self.hB): self.hBp}
         prog = [("lookup", self.lookup)]
         if sp.small:            # SmallMotionEncoder update.py:71-77: cor(96) | flo(32) -> 80, cat flow
             prog += [("conv", cp(self.corr, e.convc1, self.cf, co_off=0, epi=EPI.EPI_RELU)),
@@ -562,13 +526,11 @@ class _Plan:
                      ("conv", cp(self.fl1, e.convf2, self.cf, co_off=96, epi=EPI.EPI_RELU)),
                      ("conv", cp(self.cf, e.convm, self.xbuf, co_off=sp.cdim, epi=EPI.EPI_RELU))]
         else:                   # BasicMotionEncoder update.py:89-97: cor(192) | flo(64) -> 126, cat flow
-            flo = [("conv", cp(self.flow4, e.convf1, self.fl1, epi=EPI.EPI_RELU, out_fmt=pk1), "convf1"),
-                   ("conv", cp(self.fl1, e.convf2, self.cf, co_off=192, epi=EPI.EPI_RELU, in_fmt=pk1, out_fmt=pk), "convf2")]
-            cor = [("conv", cp(self.corr, e.convc1, self.c1, epi=EPI.EPI_RELU, out_fmt=pk1), "convc1"),
-                   ("conv", cp(self.c1, e.convc2, self.cf, co_off=0, epi=EPI.EPI_RELU, in_fmt=pk1, out_fmt=pk), "convc2")]
-            if SIDE_STREAM:     # the flow branch (reads flow4, writes fl1 and cf[:, 192:]) beside lookup + correlation branch
-                prog = [("fork", flo)] + prog + cor + [("join", None)]
-            elif PAIR_BRANCHES:
+            flo = [("conv", cp(self.flow4, e.convf1, self.fl1, epi=EPI.EPI_RELU), "convf1"),
+                   ("conv", cp(self.fl1, e.convf2, self.cf, co_off=192, epi=EPI.EPI_RELU), "convf2")]
+            cor = [("conv", cp(self.corr, e.convc1, self.c1, epi=EPI.EPI_RELU), "convc1"),
+                   ("conv", cp(self.c1, e.convc2, self.cf, co_off=0, epi=EPI.EPI_RELU), "convc2")]
+            if PAIR_BRANCHES:
                 for c_, f_ in zip(cor, flo):             # (larger layer first: its workgroups are dispatched first)
                     if ops.pair_ok(c_[1], f_[1]):
                         prog.append(("conv2", (c_[1], f_[1]), c_[2] + "+" + f_[2]))
@@ -576,10 +538,7 @@ class _Plan:
                         prog += [c_, f_]
             else:
                 prog += cor + flo
-            # (packed: the ragged last group [out 124, out 125, flow x, flow y] -- update.py:96-97 cat([out, flow]) -- is stored
-            #  whole by this launch, its tail read from flow4; the flow writers' own fp32 copies in xbuf are overwritten)
-            prog.append(("conv", cp(self.cf, e.convm, self.xbuf, co_off=sp.cdim, epi=EPI.EPI_RELU, in_fmt=pk, out_fmt=pk,
-                                    e0=self.flow4 if pk else None), "convm"))
+            prog.append(("conv", cp(self.cf, e.convm, self.xbuf, co_off=sp.cdim, epi=EPI.EPI_RELU), "convm"))
         # GRU half steps: z|r conv (sigmoid, r*h fused), q conv (tanh + state blend fused)
         states = [h_in, self.hA, self.hB] if len(e.zr) == 2 else [h_in, self.hB]
         if len(e.zr) == 1 and not first:
@@ -588,18 +547,11 @@ class _Plan:
             hi, ho = states[k], states[k + 1]
             if self.gate_bias is not None:      # [h | motion] only; the inp term is the per-pixel bias (see RaftEngine)
                 gz, gq = self.gate_bias[k]
-                hip_, hop_ = (packed_of[id(hi)], packed_of[id(ho)]) if pk else (hi, None)
-                pzr = cp(hip_, e.zr_dyn[k], self.zbuf, x2=self.xbuf, x2_off=sp.cdim, c_split=hd,
-                         epi=EPI.EPI_GRU_ZR, split=hd, e0=hi, out1=self.rh, bias_map=gz, in_fmt=3 * pk, out_fmt=2 * pk)
+                pzr = cp(hi, e.zr_dyn[k], self.zbuf, x2=self.xbuf, x2_off=sp.cdim, c_split=hd,
+                         epi=EPI.EPI_GRU_ZR, split=hd, e0=hi, out1=self.rh, bias_map=gz)
                 pq = cp(self.rh, e.q_dyn[k], ho, x2=self.xbuf, x2_off=sp.cdim, c_split=hd,
-                        epi=EPI.EPI_GRU_Q, e0=hi, e1=self.zbuf, bias_map=gq, in_fmt=3 * pk, out_fmt=2 * pk, out1=hop_)
-                tiles = math.ceil(self.hf / 8) * math.ceil(self.wf / 16)
-                n_cu = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
-                full_rounds = tiles % n_cu == 0 or tiles % n_cu >= (7 * n_cu) // 8   # (one workgroup per CU: a last round that fills)
-                if (GRU_FUSE == "1" or (GRU_FUSE == "auto" and full_rounds)) and ops.gru_ok(pzr, pq):
-                    prog.append(("gru", (pzr, pq), f"gru{k}"))
-                else:
-                    prog += [("conv", pzr, f"gru_zr{k}"), ("conv", pq, f"gru_q{k}")]
+                        epi=EPI.EPI_GRU_Q, e0=hi, e1=self.zbuf, bias_map=gq)
+                prog += [("conv", pzr, f"gru_zr{k}"), ("conv", pq, f"gru_q{k}")]
                 continue
             prog += [("conv", cp(hi, zr, self.zbuf, x2=self.xbuf, c_split=hd, epi=EPI.EPI_GRU_ZR, split=hd, e0=hi,
                                  out1=self.rh)),
@@ -610,12 +562,11 @@ class _Plan:
         if e.fh2_frag is not None and e.fh2.cout == 2:
             if self.fh_part is None:
                 self.fh_part = torch.zeros(4 * self.P, 20, dtype=torch.float32, device="cuda")
-            fused = ops.flowhead_params(self.hBp if pk else self.hB, e.fh1, self.fh_part, e.fh2_frag, precision=self.prec,
-                                        in_fmt=pk)
+            fused = ops.flowhead_params(self.hB, e.fh1, self.fh_part, e.fh2_frag, precision=self.prec)
         if fused is not None:                            # conv1 with conv2's partial products in its epilogue + the gather
             prog += [("conv", fused, "fh1"), ("fh_gather", (fused._n_planes, e.fh2.bias[:2].contiguous()))]
             return prog
-        prog.append(("conv", cp(self.hBp if pk else self.hB, e.fh1, self.fh, epi=EPI.EPI_RELU, in_fmt=pk), "fh1"))
+        prog.append(("conv", cp(self.hB, e.fh1, self.fh, epi=EPI.EPI_RELU), "fh1"))
         if ops.narrow_ok(self.fh, e.fh2):                # second conv + coords1 += delta in one launch
             prog.append(("fh_update", (self.fh, e.fh2, self.delta)))
         else:
@@ -626,9 +577,7 @@ class _Plan:
     def run(self, prog):
         for ent in prog:
             kind, a = ent[0], ent[1]
-            if kind == "gru":
-                ops.run_gru_halfstep(*a)
-            elif kind == "conv2":
+            if kind == "conv2":
                 ev = self.conv_events
                 if ev is not None and len(ent) > 2 and ent[2] in ev:
                     s, t = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -654,14 +603,6 @@ class _Plan:
             elif kind == "apply":
                 raw, out, mode, res, ms, res_ms, res_mode = a
                 ops.inorm_apply(raw, ms[0], ms[1], out, mode, res=res, res_stats=res_ms, res_mode=res_mode)
-            elif kind == "fork":
-                self._fork_ev.record()
-                self._side.wait_event(self._fork_ev)
-                with torch.cuda.stream(self._side):
-                    self.run(a)
-                    self._join_ev.record()
-            elif kind == "join":
-                torch.cuda.current_stream().wait_event(self._join_ev)
             elif kind == "pyramid":
                 ops.feature_pyramid(a)
             elif kind == "pool":
@@ -722,8 +663,6 @@ class _Plan:
         if self.gate_bias is not None:
             self.inp_c.t.copy_(self.xbuf.t[:, :self.eng.spec.cdim])
             self.run(self.prog_gate_bias)
-        if self.packed:                     # the first iteration's convs read the initial GRU state in packed form
-            ops.pack_split(self.net0.t, self.net0p.t, self.prec)
 
     def flow(self, iters, crop, h, w, flow_up=None, dst=None, wout=None, do_sigmoid=False, trace=None, defer_wh=False):
         """Target features -> volume -> `iters` refinements -> full-resolution outputs.

@@ -7,6 +7,7 @@ import numpy as np
 import torch
 
 from . import ops
+from .probe import recorder
 
 
 class _Probe:
@@ -83,6 +84,9 @@ def _fit_callable(points1, points2, weights, reweighting_fn, n_iter):
 def find_homography_nonhomogeneous_QR(points1, points2, weights=None):
     """Weighted inhomogeneous DLT, h33 = 1 (least_squares_H.py:142-210).
     points (B,N,2), weights (B,N) -> (B,3,3) mapping points1 -> points2."""
+    rec = recorder()
+    if rec is not None:                  # (woft_amd.probe: the tracker is finding out what a config's estimator does)
+        return rec.fit("lsq", points1, points2, weights)
     _check(points1, points2)
     return _fit(points1, points2, weights, 0, 0.0, 0)
 
@@ -92,6 +96,9 @@ def find_homography_IRLSq_QR(points1, points2, weights=None, reweighting_fn=IRLS
     sqrt(reweighting_fn(A x - b)) from the weighted algebraic residual.  Losses built from IRLSq_L1 / IRLSq_Huber
     (what the reference's configs use, configs/..._wIRLSq.py:24-31) run in ONE launch; any other callable is
     driven pass by pass on device tensors (_fit_callable)."""
+    rec = recorder()
+    if rec is not None:
+        return rec.fit("irls", points1, points2, weights, reweighting_fn, n_iter)
     _check(points1, points2)
     if not points1.is_cuda:
         raise AssertionError("correspondences should be on GPU")
@@ -110,6 +117,9 @@ def find_homography_IRLSq_QR(points1, points2, weights=None, reweighting_fn=IRLS
 def torch_proj_errors(GT_H, pts_A, pts_B):
     """L2 distance between H * pts_A and pts_B (least_squares_H.py:474-489).
     GT_H (B,3,3); pts (B,2,N) -> (B,N)."""
+    rec = recorder()
+    if rec is not None:
+        return rec.proj(GT_H, pts_A, pts_B)
     ones = torch.ones_like(pts_A[:, :1])
     proj = torch.matmul(GT_H, torch.cat([pts_A, ones], dim=1))
     z = proj[:, 2:3]

@@ -44,32 +44,21 @@ class Act:
         return self.t[:, :self.c].reshape(self.n, self.h, self.w, self.c).permute(0, 3, 1, 2).contiguous()
 
 
-def _rows_with_zero_row(n_pix, cs, zero):
-    """(n_pix, cs) fp32 view of a buffer with ONE more pixel row, which is zero and never written: the LDS-halo loader of the
-    register-streamed conv kernel points the out-of-image taps of a split-packed input there (woft_conv_params.in_fmt) instead
-    of selecting zeros per element."""
-    buf = (torch.zeros if zero else torch.empty)(n_pix + 1, cs, dtype=torch.float32, device=DEV)
-    if not zero:
-        buf[n_pix].zero_()
-    return buf[:n_pix]
-
-
-def has_zero_row(t):
-    """True when the tensor's storage extends one pixel row past its last row (what _rows_with_zero_row allocates)."""
-    return t.untyped_storage().nbytes() >= 4 * (t.storage_offset() + (t.shape[0] + 1) * t.stride(0))
+def _rows(n_pix, cs, zero):
+    return (torch.zeros if zero else torch.empty)(n_pix, cs, dtype=torch.float32, device=DEV)
 
 
 def act_from_nchw(x, cs=None):
     n, c, h, w = x.shape
     cs = cs or _round_up(c, 4)
-    t = _rows_with_zero_row(n * h * w, cs, True)
+    t = _rows(n * h * w, cs, True)
     t[:, :c] = x.to(DEV).permute(0, 2, 3, 1).reshape(n * h * w, c)
     return Act(t, n, h, w, c)
 
 
 def new_act(n, h, w, c, cs=None, zero=False):
     cs = cs or _round_up(c, 4)
-    return Act(_rows_with_zero_row(n * h * w, cs, zero), n, h, w, c)
+    return Act(_rows(n * h * w, cs, zero), n, h, w, c)
 
 
 # ------------------------------------------------------------------------------------------
@@ -225,13 +214,9 @@ MX_LAYERS = os.environ.get("WOFT_MX_LAYERS", "auto")
 SLOW_GATES = os.environ.get("WOFT_SLOW_GATES", "0") != "0"     # developer A/B: libm sigmoid / tanh in the conv epilogues
 USE_HALO = os.environ.get("WOFT_HALO", "1") != "0"
 USE_REGB = os.environ.get("WOFT_REGB", "1") != "0"
-USE_REGB1 = os.environ.get("WOFT_REGB1", "0") != "0"      # (measured: 45 vs 37 us on convc1 -- the 64 x 64 gather tiles win)
 REGB_TY4 = os.environ.get("WOFT_REGB_TY4", "1") != "0"
-# InstanceNorm layers (statistics out / normalise on load) on conv_regb.hip instead of the LDS-halo kernel: bit-identical (tested),
-# measured +-0 in a frame (138-143 vs 135-142 us per half-resolution layer): opt-in
-REGB_NORM = os.environ.get("WOFT_REGB_NORM", "0") != "0"
 USE_STEM = os.environ.get("WOFT_STEM", "1") != "0"        # 7x7 / stride-2 first layer on conv_stem.hip (0: gather kernel)
-HALO_TILES = {1: (8, 16, 1), 2: (9, 9, 1), 4: (4, 16, 1), 6: (6, 16, 1), 7: (8, 16, 1), 8: (8, 16, 1), 12: (4, 16, 1)}     # (TY, TX, images per workgroup)
+HALO_TILES = {1: (8, 16, 1), 2: (9, 9, 1), 4: (4, 16, 1), 7: (8, 16, 1), 8: (8, 16, 1), 12: (4, 16, 1)}     # (TY, TX, images per workgroup)
 HALO_MIN_BLOCKS = int(os.environ.get("WOFT_HALO_MIN_BLOCKS", "400"))
 WH_HALO = int(os.environ.get("WOFT_WH_HALO", "2"))
 
@@ -253,15 +238,12 @@ def pick_tiles(m, cout_pad):
 # ------------------------------------------------------------------------------------------
 def conv_params(x, pc, out, co_off=0, epi=_lib.EPI_LINEAR, x2=None, c_split=0, e0=None, e1=None, out1=None,
                 split=0, alpha=1.0, stats=None, ho=None, wo=None, tiles=None, cout=None, precision=0, halo=None,
-                in_norm=0, in_stats=None, bias_map=None, x2_off=0, wh0=None, in_fmt=0, out_fmt=0):
+                in_norm=0, in_stats=None, bias_map=None, x2_off=0, wh0=None):
     """Build (and keep alive) a woft_conv_params for `out[:, co_off:co_off+cout] = epi(conv(x))`.
     in_norm = 1 / 2 with in_stats = (mean, rstd): x is a RAW conv output, InstanceNorm (2: + ReLU) applied while
     loading -- LDS-halo kernel only (check p.halo on the result; the caller falls back to woft_inorm_apply).
     wh0 = (lookup Act, mean, fragments (pack_wh0_frags), bias, index | None): the weight head's first conv is
-    evaluated inside this launch from the lookup windows and x is not read (whole-window kernel only: p.halo == 2).
-    in_fmt / out_fmt: split-packed activations (woft_conv_params.in_fmt / out_fmt: bit 0 = x / out, bit 1 = x2 / out1 hold the
-    MFMA operand form [hi | lo] of every 4-channel group instead of fp32 values).  Inputs: the per-tap kernel and the
-    register-streamed kernel only -- ValueError when this layer selects another one."""
+    evaluated inside this launch from the lookup windows and x is not read (whole-window kernel only: p.halo == 2)."""
     if ho is None or wo is None:
         ho, wo = pc.out_hw(x.h, x.w)
     p = ConvParams()
@@ -344,20 +326,6 @@ def conv_params(x, pc, out, co_off=0, epi=_lib.EPI_LINEAR, x2=None, c_split=0, e
     if USE_REGB and auto_halo and halo in (1, 4) and tiles is None and stats is None and not in_norm and p.precision != 0:
         p.tile_n = tn = (p.tile_n if halo == 1 else 64)
         halo = 8
-    # ... and (round 3) the fnet encoder's 3x3 layers: partial statistics by the shared epilogue, the producer's InstanceNorm
-    # (+ ReLU) applied while the halo is converted (NORM instance: 8x16 pixels x 64 columns) -- bit-identical to the LDS-halo kernel
-    if USE_REGB and REGB_NORM and auto_halo and halo in (1, 4) and tiles is None and (stats is not None or in_norm) \
-            and p.precision != 0 and (pc.taps_y, pc.taps_x) == (3, 3) and x2 is None and pc.cout_pad % 64 == 0:
-        p.tile_n = tn = 64
-        halo = 8
-    # 1x1 stride-1 layers (motion encoder convc1, mask head, encoder outputs) CAN run on the same kernel with the "taps"
-    # dimension collapsed -- three chunks per unrolled group, 64-column tiles (halo=8 explicitly, or WOFT_REGB1=1); bit-identical
-    # but 10-20 % slower than the gather kernel's 64 x 64 tiles on these short-K layers, so it is not the default
-    if USE_REGB1 and auto_halo and halo == 0 and tiles is None and stats is None and not in_norm and p.precision != 0 \
-            and not pc.flat and pc.stride == 1 and (pc.taps_y, pc.taps_x) == (1, 1) and (ho, wo) == (x.h, x.w) \
-            and x.h >= 8 and x.w >= 16 and x2 is None:
-        p.tile_n = tn = 64
-        halo = 8
     # the GRU q convs (1x5 / 5x1, 128 columns) on 4x16-pixel x 128-column tiles instead of 8x16 x 64: same workgroup count and
     # per-wave work (64 rows x 32 columns), but the four waves are four column bands -- the weight fragments are fetched once
     # per workgroup instead of by both row halves.  Alone -6...8 % per layer at 1/8 of 1080p; inside a frame +-0 at 1080p
@@ -389,8 +357,8 @@ def conv_params(x, pc, out, co_off=0, epi=_lib.EPI_LINEAR, x2=None, c_split=0, e
         elif (pc.taps_y, pc.taps_x) != (3, 3) and os.environ.get("WOFT_MX_ZR", "12") == "64":
             p.tile_n = 64
     if halo in (8, 12):                 # weights streamed to registers in MFMA-fragment order (conv_regb.hip)
-        assert p.precision != 0 and not pc.flat and pc.stride == 1 and (not in_norm or (pc.taps_y, pc.taps_x) == (3, 3))
-        assert (pc.taps_y, pc.taps_x) in ((3, 3), (1, 5), (5, 1), (1, 1)) and (ho, wo) == (x.h, x.w)
+        assert p.precision != 0 and not pc.flat and pc.stride == 1 and not in_norm
+        assert (pc.taps_y, pc.taps_x) in ((3, 3), (1, 5), (5, 1)) and (ho, wo) == (x.h, x.w)
         frag = pc.frag(2 if p.precision == 1 else 1, f16=p.precision in (3, 4))
         p.wgt_frag = ptr(frag)
         if p.precision == 4:
@@ -400,25 +368,12 @@ def conv_params(x, pc, out, co_off=0, epi=_lib.EPI_LINEAR, x2=None, c_split=0, e
         if halo == 12:
             assert pc.cout_pad % 128 == 0 and pc.taps_y * pc.taps_x > 1
             p.tile_n = 128
-        if pc.taps_y * pc.taps_x == 1:
-            p.tile_n = 64
         if p.tile_n == 128 and pc.cout_pad % 128 != 0:
             p.tile_n = 64
         p.cout_pad = pc.cout_pad if stats is not None else _round_up(p.cout, p.tile_n)
-    p.in_fmt, p.out_fmt = int(in_fmt), int(out_fmt)
-    if (p.in_fmt or p.out_fmt) and PRECISION.get(precision, precision) == 4 and p.precision != 4:
-        # f16mx8's packed form is MXP (csrc/mxp.h): written and read by the register-streamed kernel's f16mx8 instances only
-        raise ValueError("MXP activations: this layer does not run in f16mx8")
-    if p.in_fmt and (p.precision == 0 or halo not in (0, 8, 12) or pc.flat or in_norm):
-        raise ValueError(f"split-packed input: not supported by the kernel this layer selects (halo {halo})")
-    if p.in_fmt and halo in (8, 12) and p.in_fmt != (3 if x2 is not None else 1):
-        raise ValueError("split-packed input: both sources or neither on the register-streamed kernel")
-    if p.in_fmt and halo in (8, 12) and not (has_zero_row(x.t) and (x2 is None or has_zero_row(x2.t))):
-        raise ValueError("split-packed input of the register-streamed kernel: the tensor must be followed by one zero pixel row "
-                         "(ops.new_act / act_from_nchw allocate it)")
     p.bias_map, p.ld_bias_map = (ptr(bias_map.t), bias_map.cs) if bias_map is not None else (None, 0)
     p.in_norm, p.in_mean, p.in_rstd = 0, None, None
-    if in_norm and halo in (1, 4, 8) and (pc.taps_y, pc.taps_x) == (3, 3):   # (instantiated for the 3x3 pixel tiles)
+    if in_norm and halo in (1, 4) and (pc.taps_y, pc.taps_x) == (3, 3):   # (instantiated for the 3x3 pixel tiles)
         p.in_norm, p.in_mean, p.in_rstd = int(in_norm), ptr(in_stats[0]), ptr(in_stats[1])
     p._m_tiles = math.ceil(m / tm)
     if halo in HALO_TILES:
@@ -498,30 +453,7 @@ def pair_ok(a, b):
         return False
     if a.halo == 0:
         return True
-    if bool(a.in_fmt) != bool(b.in_fmt):                     # (the input format is a compile-time property of the instance)
-        return False
     return a.halo in (8, 12) and (a.taps_y, a.taps_x) == (b.taps_y, b.taps_x) and a.taps_y * a.taps_x > 1
-
-
-def gru_ok(zr, q):
-    """True when woft_gru_halfstep takes this z|r conv / q conv pair (one SepConvGRU half step in one launch)."""
-    return (zr.precision in (1, 2, 3) and q.precision == zr.precision and (zr.taps_y, zr.taps_x) in ((1, 5), (5, 1))
-            and (q.taps_y, q.taps_x) == (zr.taps_y, zr.taps_x) and zr.n_img == 1 and zr.cin_pad == 256 == q.cin_pad
-            and zr.c_split == 128 == q.c_split and zr.cout == 256 and q.cout == 128 and bool(zr.wgt_frag) and bool(q.wgt_frag)
-            and bool(zr.bias_map) and bool(q.bias_map) and bool(zr.in1) and zr.in1 == q.in1 and zr.e0 == zr.in0 == q.e0
-            and not (zr.in_fmt or zr.out_fmt or q.in_fmt or q.out_fmt))
-
-
-def pack_split(x, out, precision, channels=None):
-    """fp32 activation rows x (tensor [rows][ld]) -> split-packed rows (woft_pack_split); in place when out is x."""
-    c = channels or x.shape[1]
-    assert PRECISION.get(precision, precision) != 4 or x.data_ptr() != out.data_ptr(), "MXP packing is not in place"
-    check(_lib.load().woft_pack_split(ptr(x), x.shape[0], c, x.stride(0), PRECISION.get(precision, precision), ptr(out),
-                                      out.stride(0), stream_ptr()), "woft_pack_split")
-
-
-def run_gru_halfstep(zr, q):
-    check(_lib.load().woft_gru_halfstep(C.byref(zr), C.byref(q), stream_ptr()), "woft_gru_halfstep")
 
 
 def run_conv_pair(a, b):
@@ -671,14 +603,14 @@ def corr_volume(f1, f2_rows, n_q, out, alpha, precision=0, f2_hi=None, f2_lo=Non
 
 
 def tiled_dims(h, w, tw=4):
-    """(tile rows, tile cols, elements per plane) of an h x w map in the volume layout of 4-row x tw-column tiles."""
+    """(tile rows, tile cols, elements per plane) of an h x w map in the volume layout of 4 x 4 tiles."""
     ht, wt = (h + 3) // 4, (w + tw - 1) // tw
     return ht, wt, ht * wt * 4 * tw
 
 
-def tile_rows(x, out, tw=4):
-    """x: Act (1, h, w, c) -> out rows in (4 x tw)-tile order (first ht*wt*4*tw rows of `out`)."""
-    check(_lib.load().woft_tile_rows(ptr(x.t), x.h, x.w, x.cs, tw, ptr(out), stream_ptr()), "woft_tile_rows")
+def tile_rows(x, out):
+    """x: Act (1, h, w, c) -> out rows in 4x4-tile order (first ht*wt*16 rows of `out`)."""
+    check(_lib.load().woft_tile_rows(ptr(x.t), x.h, x.w, x.cs, ptr(out), stream_ptr()), "woft_tile_rows")
 
 
 def tile_planes(planes, tw=4):
@@ -697,15 +629,14 @@ def untile_planes(vol, h, w, tw=4):
     return vol[:, :n].reshape(P, ht, wt, 4, tw).permute(0, 1, 3, 2, 4).reshape(P, ht * 4, wt * tw)[:, :h, :w]
 
 
-def make_lookup_params(vols, dims, coords, out, radius, tw=4):
-    """vols[l]: (P, plane_l) tiled volumes (4 x tw tiles), all float32 or all bfloat16; dims[l] = (H_l, W_l)."""
+def make_lookup_params(vols, dims, coords, out, radius):
+    """vols[l]: (P, plane_l) tiled volumes (4 x 4 tiles), all float32 or all bfloat16; dims[l] = (H_l, W_l)."""
     p = LookupParams()
     assert len({v.dtype for v in vols}) == 1 and vols[0].dtype in (torch.float32, torch.bfloat16)
     p.vol_bf16 = int(vols[0].dtype == torch.bfloat16)
-    p.tile_w = tw
     for l, v in enumerate(vols):
         p.vol[l] = ptr(v)
-        p.ht[l], p.wt[l], n = tiled_dims(*dims[l], tw)
+        p.ht[l], p.wt[l], n = tiled_dims(*dims[l])
         assert v.shape[1] >= n
         p.plane[l] = v.shape[1]
     p.levels, p.radius = len(vols), radius

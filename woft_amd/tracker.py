@@ -120,27 +120,30 @@ class YAOFTrackerSingleControl:
 
     # ---- which solver back end ------------------------------------------------------------------
     def _fused_specs(self):
-        """Parameters of the device back end when the config's estimator / subsampler / re-detection callables are
-        the tagged ones of woft_amd.presets, else None (callable back end)."""
+        """Parameters of the device back end -- dict(reweight, huber_k, n_irls, thr, min_frac, n_draw, sobol_u) -- when the
+        config's estimator / subsampler / re-detection callables are the weighted LSq / IRLS estimators, the Sobol-n draw and
+        the inlier-fraction test: tagged by woft_amd.presets, or found to BEHAVE as those (woft_amd.probe: reference-format
+        configs define them inline, configs/..._wLSq.py:14-53); else None (callable back end: the config's own functions run)."""
         C = self.C
-        if os.environ.get("WOFT_FUSED", "1") == "0":
-            return None
-        est = getattr(C.H_estimator, "woft_spec", None)
-        red = getattr(C.redet_success_fn, "woft_spec", None)
-        sub = getattr(C.subsampler_fn, "woft_spec", None) if C.subsampler_fn else ("none", 0)
-        if est is None or red is None or sub is None or red[0] != "inliers":
+        self.solver_decision = "callable back end"
+        v = C.device_solver
+        if os.environ.get("WOFT_FUSED", "1") == "0" or (not isinstance(v, type(C)) and v is not None and not v):
+            self.solver_decision += " (device back end switched off)"
             return None
         if C.post_hoc_weights_postprocessing_fn or C.flow_numpy_out:
             return None
         if not hasattr(self.flower, "pin_source") or self.flower.C.raft_type != "weighted":
             return None
-        n_draw = int(sub[1]) if sub[0] == "sobol" else 0
-        if n_draw > 1024:
+        from .probe import solver_spec
+        spec, how = solver_spec(C.H_estimator, C.subsampler_fn or None, C.redet_success_fn, device=self.device)
+        self.solver_decision = ("device back end" if spec is not None else "callable back end") + f" ({how})"
+        logger.info(f"tracker solver: {self.solver_decision}")
+        if spec is None:
             return None
         from .presets import sobol_points
-        return dict(reweight=int(est[1]), huber_k=float(est[2]), n_irls=int(est[3]), thr=float(red[1]),
-                    min_frac=float(red[2]), n_draw=n_draw,
-                    sobol_u=torch.from_numpy(sobol_points(n_draw).astype(np.float32)).cuda() if n_draw else None)
+        n_draw = spec["n_draw"]
+        spec["sobol_u"] = torch.from_numpy(sobol_points(n_draw).astype(np.float32)).cuda() if n_draw else None
+        return spec
 
     def _fused_buffers(self, n_grid):
         if getattr(self, "_fb_key", None) != n_grid:
@@ -362,7 +365,7 @@ class YAOFTrackerSingleControl:
         ih = host.view(torch.int32)
         if int(ih[10]) == 1:
             raise AssertionError(torch.Size([1, int(ih[12]), 2]))    # least_squares_H.py:162 (fewer than 4 points)
-        return _Fit(H=host[0:9].numpy().astype(np.float64).reshape(3, 3), success=bool(float(host[9]) > F["min_frac"]))   # (astype: a copy)
+        return _Fit(H=host[0:9].numpy().astype(np.float64).reshape(3, 3), success=bool(np.float32(host[9]) > np.float32(F["min_frac"])))   # (astype: a copy; the verdict in float32, as torch compares a float32 mean with a Python float)
 
     def _solve_callables(self, src_xy, dst_xy, w, grid, frame_hw, src_mask_u8, dst_valid_u8, bounds, judge):
         C = self.C
