@@ -64,9 +64,9 @@ class FakeCuda(torch.Tensor):
     is_cuda = property(lambda s: True)
 
 
-def ref_args(small, weighted=True):
+def ref_args(small, weighted=True, weight_head_structure=None):
     return SimpleNamespace(small=small, mixed_precision=False, alternate_corr=False,
-                           weight_head_structure=[(128, 3)] * 3, mask_estimation=False)
+                           weight_head_structure=weight_head_structure or [(128, 3)] * 3, mask_estimation=False)
 
 
 def pair(H, W, seed, shift=(3, -2)):
@@ -176,6 +176,25 @@ def gen_flow():
     coords[:, 0, 3] = (W2 + 3.0, H2 + 2.0)             # fully beyond the border at level 0
     out = cbk(torch.from_numpy(coords)[None])
     np.savez_compressed(GOLD / "lookup_handmade.npz", vol0=vol0, coords=coords, out=out.numpy(), radius=4)
+
+
+HEAD_STRUCTURES = {"mixed": [(32, 3), (48, 5), 24], "one_1x1": [(64, 1)], "wide_7": [(16, 7), (160, 3)]}
+
+
+@torch.no_grad()
+def gen_heads():
+    """Weight heads other than the shipped [(128, 3)] * 3 (class_params.weight_head_structure, weighted_raft.py:318-345):
+    the reference network built with each structure, 3 iterations at 128 x 160 -> flow and weight logits."""
+    from raft_core.weighted_raft import WeightedRAFT
+    a, b = pair(128, 160, seed=21, shift=(2, 3))
+    out = dict(img1=a, img2=b, seed=17, iters=3, names=np.array(sorted(HEAD_STRUCTURES)))
+    for name, st in HEAD_STRUCTURES.items():
+        sd = synth.make_state_dict(seed=17, weight_head_structure=st)
+        net = WeightedRAFT(ref_args(False, weight_head_structure=st)).eval()
+        net.load_state_dict(sd, strict=True)
+        flow_low, flow_up, vol, w_low, w_up = net(to_t(a), to_t(b), iters=3, test_mode=True)
+        out[f"{name}_flow_up"], out[f"{name}_w_low"], out[f"{name}_w_up"] = flow_up.numpy(), w_low.numpy(), w_up.numpy()
+    np.savez_compressed(GOLD / "weight_heads_128x160_it3.npz", **out)
 
 
 @torch.no_grad()
@@ -499,6 +518,8 @@ def main():
     only = os.environ.get("GOLDEN_ONLY")
     if only in (None, "flow"):
         gen_flow()
+    if only in (None, "heads"):
+        gen_heads()
     if only in (None, "wrapper"):
         gen_wrapper()
     if only in (None, "hfit"):

@@ -239,11 +239,14 @@ def weight_head(sd, lookup, vol0, radius, hf, wf):
     x = samp.permute(0, 4, 5, 3, 1, 2).reshape(b * hf * wf, L, n, n)
     m = mean.reshape(b * hf * wf, 1, 1, 1).expand(-1, 1, n, n)
     x = torch.cat([x, m], dim=1)
+    # any weight_head_structure (weighted_raft.py:318-345): convs net.0, net.2, ... with padding k // 2 and a ReLU each, then
+    # the closing 1x1 conv (the shipped configs: three 3x3 layers of 128 channels)
     p = "weight_head.net"
-    x = F.relu(_conv(sd, p + ".0", x, 1, 1))
-    x = F.relu(_conv(sd, p + ".2", x, 1, 1))
-    x = F.relu(_conv(sd, p + ".4", x, 1, 1))
-    x = _conv(sd, p + ".6", x)
+    idx = sorted(int(k.split(".")[2]) for k in sd if k.startswith(p + ".") and k.endswith(".weight"))
+    for i in idx[:-1]:
+        k = sd[f"{p}.{i}.weight"].shape[-1]
+        x = F.relu(_conv(sd, f"{p}.{i}", x, 1, k // 2))
+    x = _conv(sd, f"{p}.{idx[-1]}", x)
     return x.view(b, hf, wf, n * n).mean(dim=-1)[:, None]
 
 

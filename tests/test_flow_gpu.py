@@ -587,3 +587,31 @@ def test_fast_gate_functions_drift_is_bounded(monkeypatch, golden_dir):
     m, mx = _epe(flows[0], flows[1])
     print(f"fast vs library gate functions, 32 iterations: EPE mean {m:.2e} max {mx:.2e}")
     assert 0 < mx < 1e-4, (m, mx)
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("precision", ["bf16x3", "fp32"])
+def test_weight_heads_other_than_the_shipped_one(golden_dir, precision):
+    """class_params.weight_head_structure other than [(128, 3)] * 3 (weighted_raft.py:318-345; round-4 review: a hard refusal):
+    the engine follows the state-dict's layers -- here 3x3 / 5x5 / 7x7 / 1x1 kernels, 16 to 160 channels, plain-int entries --
+    layer by layer; flow and weights against the REFERENCE built with each structure."""
+    from oracle.gen_golden import HEAD_STRUCTURES
+    g = np.load(golden_dir / "weight_heads_128x160_it3.npz")
+    for name, st in HEAD_STRUCTURES.items():
+        sd = synth.make_state_dict(seed=int(g["seed"]), weight_head_structure=st)
+        fc = _flow_config(sd, int(g["iters"]), precision=precision)
+        fc.class_params.weight_head_structure = st
+        flower = fc.of_class(fc)
+        assert not flower.engine.wh_std
+        flow, w = flower.compute_flow(g["img1"], g["img2"], mode="flow", do_sigmoid=False)
+        torch.cuda.synchronize()
+        m, mx = _epe(flow, torch.from_numpy(g[f"{name}_flow_up"])[0])
+        dw = float((torch.sigmoid(w.cpu()) - torch.sigmoid(torch.from_numpy(g[f"{name}_w_up"])[0])).abs().max())
+        dl = float((w.cpu() - torch.from_numpy(g[f"{name}_w_up"])[0]).abs().max())
+        print(f"{name} {precision}: EPE {m:.2e} / {mx:.2e}; sigmoid(w) {dw:.2e}; logits {dl:.2e}")
+        assert m < 1e-3 and mx < 1e-2 and dw < 1e-4 and dl < 2e-3, (name, m, mx, dw, dl)
+        # through the tracker-facing surface too: a pinned source with a weight region falls back to the full map
+        flower.pin_source(g["img1"])
+        flower.pin_weight_region(np.ones(g["img1"].shape[:2], dtype=bool))
+        _, _, wt = flower.compute_flow(g["img1"], g["img2"], mode="TC", do_sigmoid=False, weight_region=True, defer_weights=500)
+        assert wt is not None and float((wt.reshape(-1).cpu() - w.reshape(-1).cpu()).abs().max()) == 0.0

@@ -264,3 +264,19 @@ def test_metric_resolution_1080p(golden_dir):
     assert np.abs(out["flow_up"].double().mean(-1).numpy() - g["flow_up_rowmean"]).max() < 1e-4
     assert np.abs(out["weights_up"][..., ::s, ::s].numpy() - g["w_up_s"]).max() < 3e-4
     assert np.abs(out["weights_up"].double().mean(-1).numpy() - g["w_up_rowmean"]).max() < 1e-4
+
+
+@torch.no_grad()
+def test_weight_heads_other_than_the_shipped_one(golden_dir):
+    """class_params.weight_head_structure (weighted_raft.py:318-345): the oracle's head follows the state-dict's layers --
+    (channels, kernel) tuples with any odd kernel, plain channel counts (3x3) -- against the reference built with each structure."""
+    g = np.load(golden_dir / "weight_heads_128x160_it3.npz")
+    from oracle.gen_golden import HEAD_STRUCTURES
+    assert sorted(HEAD_STRUCTURES) == list(g["names"])
+    for name, st in HEAD_STRUCTURES.items():
+        sd = synth.make_state_dict(seed=int(g["seed"]), weight_head_structure=st)
+        out = raft_ref.raft_forward(sd, _t(g["img1"]), _t(g["img2"]), int(g["iters"]))
+        m, mx = _epe(out["flow_up"], g[f"{name}_flow_up"])
+        assert m < 1e-4 and mx < 1e-3, (name, m, mx)
+        assert np.abs(out["weights_low"].numpy() - g[f"{name}_w_low"]).max() < 1e-4, name
+        assert np.abs(out["weights_up"].numpy() - g[f"{name}_w_up"]).max() < 1e-4, name

@@ -574,3 +574,73 @@ def test_graph_replay_keeps_the_deferred_weight_head():
             assert any(g is not None for g in plan._graphs.values()), "nothing was replayed"
     for a, b in zip(outs[False], outs[True]):
         assert np.array_equal(a, b)
+
+
+def test_reference_form_config_takes_the_device_solver_with_identical_results(monkeypatch):
+    """A config written like the reference's default (inline, untagged estimator / subsampler / re-detection callables:
+    tests/configs/inline_wlsq.py; configs/..._wLSq.py:14-53) is recognised by woft_amd.probe and runs the device back end --
+    with the homographies, lost flags and metas the SAME config produces on the callable back end (WOFT_FUSED=0), and those of
+    the shipped presets config."""
+    from pytracking.utils.config import load_config
+    H, W, iters, nframes = 128, 160, 4, 5
+    sd = synth.make_state_dict(seed=7)
+    template = synth.make_template(H, W, seq_id=3)
+    frames = [synth.make_frame(template, t) for t in range(1, nframes + 1)]
+    mask = synth.make_init_mask(H, W)
+
+    def run(path, fused, **kw):
+        monkeypatch.setenv("WOFT_FUSED", "1" if fused else "0")
+        conf = load_config(path)
+        conf.flow_config.model, conf.flow_config.iters = sd, iters
+        for k, v in kw.items():
+            setattr(conf.flow_config, k, v)
+        trk = conf.tracker_class(conf)
+        trk.init(template, mask)
+        return trk, [trk.track(f) for f in frames]
+
+    inline = ROOT / "tests" / "configs" / "inline_wlsq.py"
+    t_dev, r_dev = run(inline, True, precision="bf16x3")
+    t_call, r_call = run(inline, False, precision="bf16x3")
+    t_pre, r_pre = run(ROOT / "pytracking" / "configs" / "WOFT.py", True)
+    assert t_dev._fused is not None and "probed" in t_dev.solver_decision and t_dev.solver_decision.count("probed") == 3
+    assert t_dev._fused["n_draw"] == 500 and t_dev._fused["thr"] == 5.0 and t_dev._fused["min_frac"] == 0.2
+    assert t_call._fused is None and t_pre._fused is not None and "tagged" in t_pre.solver_decision
+    for (Ha, ma), (Hb, mb), (Hc, mc) in zip(r_dev, r_call, r_pre):
+        assert np.array_equal(Ha, Hc) and ma.lost == mc.lost == mb.lost and ma.N_lost == mb.N_lost
+        assert _corners_err(Ha, Hb, H, W) < 1e-2           # (callable back end: torch's QR-free path on the same kernels, fp32 H)
+    # no `precision` key (an unmodified reference flow config): the reference's arithmetic class, still the device solver
+    t_fp32, r_fp32 = run(inline, True)
+    assert t_fp32.flower.precision == "fp32" and t_fp32._fused is not None
+    for (Ha, _), (Hb, _) in zip(r_fp32, r_dev):
+        assert _corners_err(Ha, Hb, H, W) < 0.05
+
+
+def test_host_frames_keep_the_previous_frame_intact():
+    """_FrameUploader's lifetime contract: the device frame a host-frame track() call keeps as prev_img survives the NEXT call
+    (two alternating buffers) -- the local stage of a lost frame reads it -- and is reused by the call after that; frames and
+    results equal those of device-resident frames."""
+    from pytracking.utils.config import load_config
+    H, W, iters = 128, 160, 3
+    sd = synth.make_state_dict(seed=7)
+    template = synth.make_template(H, W, seq_id=3)
+    frames = [synth.make_frame(template, t) for t in range(1, 5)]
+    mask = synth.make_init_mask(H, W)
+
+    def tracker():
+        conf = load_config(ROOT / "pytracking" / "configs" / "WOFT.py")
+        conf.flow_config.model, conf.flow_config.iters = sd, iters
+        conf.redet_success_fn = lambda *a: False            # every frame lost: the local stage reads frame t - 1
+        t = conf.tracker_class(conf)
+        t.init(template, mask)
+        return t
+    a, b = tracker(), tracker()
+    kept = []
+    for f in frames:
+        Ha, ma = a.track(f)                                  # numpy frame per call
+        Hb, mb = b.track(torch.from_numpy(f).cuda())         # device frame
+        assert np.array_equal(Ha, Hb) and ma.lost and mb.lost
+        kept.append((a.prev_img, f))
+        assert torch.equal(a.prev_img.cpu(), torch.from_numpy(f))
+        if len(kept) >= 2:                                   # the frame before is still intact after this call
+            assert torch.equal(kept[-2][0].cpu(), torch.from_numpy(kept[-2][1]))
+    assert kept[0][0].data_ptr() == kept[2][0].data_ptr() != kept[1][0].data_ptr()

@@ -120,6 +120,9 @@ typedef __attribute__((address_space(1))) f32x4 g_f32x4;
 typedef __attribute__((address_space(1))) float g_f32;
 struct GPtr {
     uint64_t a;
+#ifdef WOFT_STORE_WT
+    bool plain = false;    // developer ablation (woft_conv_params.out_w == -12347): ordinary stores -- NOT a valid hand-off, timing only
+#endif
     __device__ __forceinline__ bool null() const { return a == 0; }
     __device__ __forceinline__ f32x4 ld4(int64_t off) const { return *(const g_f32x4*)(a + 4 * (uint64_t)off); }
 #ifdef WOFT_STORE_WT
@@ -129,11 +132,13 @@ struct GPtr {
     // offsets: the launcher checks that every output is smaller than 2 GiB.
     __device__ __forceinline__ void st4(int64_t off, f32x4 v) const {
         typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+        if (plain) { *(g_f32x4*)(a + 4 * (uint64_t)off) = v; return; }
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v),
                                                __builtin_amdgcn_make_buffer_rsrc((void*)a, 0, 0x7fffffff, 0x00020000),
                                                (int)(4 * off), 0, 16);
     }
     __device__ __forceinline__ void st1(int64_t off, float v) const {
+        if (plain) { *(g_f32*)(a + 4 * (uint64_t)off) = v; return; }
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v),
                                               __builtin_amdgcn_make_buffer_rsrc((void*)a, 0, 0x7fffffff, 0x00020000),
                                               (int)(4 * off), 0, 16);
@@ -317,8 +322,8 @@ __device__ __forceinline__ void epi_dispatch(const EpiRegs& a, const float* stag
 
 // ST = accumulator tiles transposed into the wave's LDS staging area at once (the caller provides ST * STAGE_FLOATS floats
 // per wave): all of a wave's tiles when the LDS allows, one at a time otherwise.
-template <int TM, int TN, int WROWS, int WCOLS, int ST = 1, typename RowMap>
-__device__ __forceinline__ void conv_epilogue_t(const woft_conv_params& p, f32x16 (&acc)[TM][TN], float* stage,
+template <int TM, int TN, int WROWS, int WCOLS, int ST = 1, typename RowMap, class PT = woft_conv_params>
+__device__ __forceinline__ void conv_epilogue_t(const PT& p, f32x16 (&acc)[TM][TN], float* stage,
                                                 const RowMap& rowmap, int n0, int wm, int wn, int lane, int m_tile,
                                                 unsigned long long* dbg = nullptr) {
     constexpr int NT = TM * TN;
@@ -333,6 +338,9 @@ __device__ __forceinline__ void conv_epilogue_t(const woft_conv_params& p, f32x1
     a.ld_bias_map = keep_sgpr(p.ld_bias_map); a.co_off = keep_sgpr(p.co_off); a.cout = keep_sgpr(p.cout);
     a.split = keep_sgpr(p.split); a.epi = keep_sgpr(p.epi); a.alpha = keep_sgpr(p.alpha);
     a.no_store = p.out_w == -12345;                            // (micro-benchmark ablation, tools/bench_conv.py)
+#ifdef WOFT_STORE_WT
+    a.out.plain = a.out1.plain = p.out_w == -12347;
+#endif
     a.fast = p.precision != 0 && p.out_w != -12346;            // (-12346: developer ablation, library gate functions)
     const GPtr stat_sum = keep_gptr(p.stat_sum), stat_sq = keep_gptr(p.stat_sq);
     const int cout_pad = keep_sgpr(p.cout_pad);

@@ -70,8 +70,11 @@ struct RegbGeom {
 // smem: RegbGeom<...>::SMEM_ELEMS bf16 elements, 16-byte aligned; all 256 threads of the workgroup call together.
 // The caller guarantees that the tile's inputs are visible to this CU and may reuse smem after the call returns (the body ends
 // with the epilogue's last store ISSUED, not completed).
-template <int TY, int TX, int KY, int KX, int WM, int TERMS, int NBUF, int DIST, int AD, bool IL = true>
-__device__ __forceinline__ void regb_tile(const woft_conv_params& p, const int m_tile, const int n_tile, __bf16* smem,
+// ParamsT: woft_conv_params -- or the same struct behind a constant-address-space reference (update_pk.hip: the layer table lives in
+// device memory; only address space 4 makes its fields SCALAR loads -- through a plain pointer the compiler reads them with
+// vector loads, base addresses end up in VGPRs and the epilogue's "+s" operands fail with 'illegal VGPR to SGPR copy').
+template <int TY, int TX, int KY, int KX, int WM, int TERMS, int NBUF, int DIST, int AD, bool IL = true, class ParamsT = woft_conv_params>
+__device__ __forceinline__ void regb_tile(const ParamsT& p, const int m_tile, const int n_tile, __bf16* smem,
                                           unsigned long long* stamps) {
     using G = RegbGeom<TY, TX, KY, KX, WM, TERMS>;
     constexpr int WN = G::WN, BN = G::BN, WROWS = G::WROWS, TM = G::TM, NP = G::NP, TAPS = G::TAPS;
@@ -526,8 +529,11 @@ __device__ __forceinline__ void regb_tile(const woft_conv_params& p, const int m
         __syncthreads();
         const int64_t M = (int64_t)p.n_img * p.ho * p.wo;
         const uint64_t dbase = (uint64_t)(uintptr_t)(p.out + (int64_t)n_tile * M * p.ldo);   // wave-uniform; said explicitly (an
-        const woft::GPtr dst{((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(dbase >> 32)) << 32) |   // "+s" asm
-                             (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)dbase)};   // operand here: 'illegal VGPR to SGPR copy')
+        woft::GPtr dst{((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(dbase >> 32)) << 32) |   // "+s" asm
+                       (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)dbase)};   // operand here: 'illegal VGPR to SGPR copy')
+#ifdef WOFT_STORE_WT
+        dst.plain = p.out_w == -12347;
+#endif
         for (int idx = tid; idx < G::BM * (SLD / 4); idx += 256) {
             const int row = idx / (SLD / 4), c4 = (idx - row * (SLD / 4)) * 4;
             const int wmr = row / WROWS, lr = row - wmr * WROWS;

@@ -1,4 +1,6 @@
 // Streaming (HBM-bound) helpers: input normalisation, InstanceNorm finalize/apply, 2x2 pooling.
+#include <string.h>
+
 #include "common.h"
 #include "halo_map.h"
 
@@ -300,10 +302,23 @@ extern "C" int woft_avgpool2_nhwc(const float* in, int32_t h, int32_t w, int32_t
 }
 
 // sizeof() of the ABI structs, so the Python ctypes mirror can verify its layout at load time.
+extern "C" int woft_upload_u8(const void* src, void* pinned, void* dev, int64_t bytes, int32_t n_chunks, void* stream) {
+    if (!src || !pinned || !dev || bytes <= 0 || n_chunks < 1 || n_chunks > 64) return WOFT_EINVAL;
+    const int64_t per = ((bytes + n_chunks - 1) / n_chunks + 4095) / 4096 * 4096;          // whole pages per piece
+    for (int64_t off = 0; off < bytes; off += per) {
+        const int64_t n = bytes - off < per ? bytes - off : per;
+        memcpy((char*)pinned + off, (const char*)src + off, (size_t)n);
+        if (hipMemcpyAsync((char*)dev + off, (const char*)pinned + off, (size_t)n, hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess)
+            return WOFT_ELAUNCH;
+    }
+    return WOFT_OK;
+}
+
 extern "C" int woft_sizeof(int which) {
     if (which == 0) return (int)sizeof(woft_conv_params);
     if (which == 1) return (int)sizeof(woft_lookup_params);
     if (which == 2) return (int)sizeof(woft_lookup_otf_params);
+    if (which == 3) return (int)sizeof(woft_pk_layer);
     return -1;
 }
 

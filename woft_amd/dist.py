@@ -90,7 +90,7 @@ def device_index():
 def gather_floats(values, device=None):
     """Every rank contributes a fixed-length list of floats; -> (world, n) float64 tensor on every rank."""
     t = torch.tensor([float(v) for v in values], dtype=torch.float64)
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():            # (an initialised group of ONE rank still goes through its collective)
         return t[None]
     if device is None:
         device = "cuda" if dist.get_backend() == "nccl" else "cpu"
@@ -114,7 +114,7 @@ def pack_track(results):
 def gather_tracks(results, device=None):
     """All ranks contribute their sequence's track; every rank gets the (world, T, RECORD) tensor."""
     rec = pack_track(results)
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return rec[None]
     if device is None:
         device = "cuda" if dist.get_backend() == "nccl" else "cpu"
@@ -125,7 +125,7 @@ def gather_tracks(results, device=None):
 
 
 def max_over_ranks(value, device=None):
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return float(value)
     if device is None:
         device = "cuda" if dist.get_backend() == "nccl" else "cpu"
@@ -135,5 +135,5 @@ def max_over_ranks(value, device=None):
 
 
 def barrier():
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized():
         dist.barrier()

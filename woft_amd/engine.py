@@ -183,21 +183,37 @@ class RaftEngine:
         self.q_inp = [ops.pack_conv(w_, b_, padding=pd, cin_layout=ctx) for w_, b_, pd in q_w]
         if weighted:
             w = "weight_head.net."
-            # the head's kernels are laid out for weight_head_structure [(128, 3)] * 3 (weighted_raft.py:318-345 with
-            # optical_flow/configs/v2_SNOB_large_g05_RAFT.py:16): 3x3 convs 5 -> 128 -> 128 -> 128, then 1x1 -> 1
-            want = {"0": (128, 5, 3, 3), "2": (128, 128, 3, 3), "4": (128, 128, 3, 3), "6": (1, 128, 1, 1)}
-            have = {k.split(".")[2]: tuple(v.shape) for k, v in sd.items() if k.startswith(w) and k.endswith(".weight")}
-            if have != want:
-                raise NotImplementedError(f"weight head layers {have}: the HIP path implements weight_head_structure "
-                                          f"[(128, 3)] * 3 = {want}")
-            self.wh0 = ops.pack_conv(sd[w + "0.weight"], sd[w + "0.bias"], flat_cs=8)
-            self.wh2 = ops.pack_conv(sd[w + "2.weight"], sd[w + "2.bias"])
-            self.wh4 = ops.pack_conv(sd[w + "4.weight"], sd[w + "4.bias"])
-            # first conv as MFMA fragments for the fused two-layer launch (split-bf16 precisions, 9x9 windows)
-            self.wh0_frag = (ops.pack_wh0_frags(sd[w + "0.weight"], 2 if self.prec_wh == "bf16x3" else 1)
-                             if precision != "fp32" and self.spec.nwin == 9 else None)
-            self.wh6_w = sd[w + "6.weight"].reshape(-1).contiguous().cuda()
-            self.wh6_b = float(sd[w + "6.bias"].item())
+            # class_params.weight_head_structure (weighted_raft.py:318-345) = the state-dict's layers net.0, net.2, ..., a ReLU after
+            # each, then the closing 1x1 conv.  The shipped configs' [(128, 3)] * 3 (optical_flow/configs/v2_SNOB_large_g05_RAFT.py:16)
+            # has its own kernels (first layer fused into the second's launch, mean fused into the third's epilogue, evaluated on
+            # a subset of the windows); any other structure runs layer by layer on every window (wh_std = False).
+            idx = sorted(int(k.split(".")[2]) for k in sd if k.startswith(w) and k.endswith(".weight"))
+            shapes = [tuple(sd[f"{w}{i}.weight"].shape) for i in idx]
+            if len(idx) < 2 or shapes[-1][0] != 1 or shapes[-1][2:] != (1, 1) or shapes[0][1] != sp.levels + 1 \
+                    or any(a[0] != b[1] for a, b in zip(shapes, shapes[1:])) or any(sh[2] != sh[3] or sh[2] % 2 == 0 for sh in shapes):
+                raise ValueError(f"weight head layers {shapes}: not a WeightHead (weighted_raft.py:318-345)")
+            self.wh_std = shapes == [(128, 5, 3, 3), (128, 128, 3, 3), (128, 128, 3, 3), (1, 128, 1, 1)]
+            last = idx[-1]
+            if self.wh_std:
+                self.wh0 = ops.pack_conv(sd[w + "0.weight"], sd[w + "0.bias"], flat_cs=8)
+                self.wh2 = ops.pack_conv(sd[w + "2.weight"], sd[w + "2.bias"])
+                self.wh4 = ops.pack_conv(sd[w + "4.weight"], sd[w + "4.bias"])
+                # first conv as MFMA fragments for the fused two-layer launch (split-bf16 precisions, 9x9 windows)
+                self.wh0_frag = (ops.pack_wh0_frags(sd[w + "0.weight"], 2 if self.prec_wh == "bf16x3" else 1)
+                                 if precision != "fp32" and self.spec.nwin == 9 else None)
+            else:
+                # generic head: the first layer reads the 5-channel patches -- "flat" packing (8 floats per window position)
+                # while kernel * 8 <= 32, else 32-channel rows; the other layers are ordinary convs on (windows, n, n, C)
+                k0 = shapes[0][2]
+                self.wh_flat0 = k0 * 8 <= 32
+                self.wh_layers = [ops.pack_conv(sd[f"{w}{idx[0]}.weight"], sd[f"{w}{idx[0]}.bias"], flat_cs=8 if self.wh_flat0 else 0)]
+                self.wh_layers += [ops.pack_conv(sd[f"{w}{i}.weight"], sd[f"{w}{i}.bias"]) for i in idx[1:-1]]
+                self.wh0_frag = None
+            self.wh6_c = shapes[-1][1]
+            self.wh6_w = torch.zeros(_ru(self.wh6_c, 4))
+            self.wh6_w[:self.wh6_c] = sd[f"{w}{last}.weight"].reshape(-1)
+            self.wh6_w = self.wh6_w.contiguous().cuda()
+            self.wh6_b = float(sd[f"{w}{last}.bias"].item())
         self._plans = {}
 
     def plan(self, hp, wp, slot=0):
@@ -296,6 +312,7 @@ class _Plan:
         self.rh = new_act(1, hf, wf, sp.hdim, zero=True)
         self.hA = new_act(1, hf, wf, sp.hdim, zero=True)
         self.hB = new_act(1, hf, wf, sp.hdim, zero=True)
+        self._pk = {}              # persistent update-block launch: {(first, parity, last): program} (UPDATE_PK)
         self.fh = new_act(1, hf, wf, 128 if sp.small else 256, zero=True)
         self.fh_part = None        # flow head folded into one conv launch: per-pixel partial products of its second conv
         self.delta = new_act(1, hf, wf, 2, cs=4, zero=True)
@@ -323,25 +340,45 @@ class _Plan:
         if eng.weighted:
             n = sp.nwin
             self.x8 = new_act(P, n, n, 5, cs=8, zero=True)
-            self.a2 = new_act(P, n, n, 128)
             self.wmean = z(P)
             self.wlow = z(P)
             self.cs_ws = torch.zeros(256, sp.fdim, dtype=torch.float64, device=dev)
             self.cs_tot = torch.zeros(sp.fdim, dtype=torch.float64, device=dev)
-            # first conv (5 -> 128): scalar-operand VALU kernel straight from the lookup buffer for the 7x7 / 9x9
-            # windows (woft_wh_conv0), the generic conv on the packed x8 patches otherwise
-            self.wh0_direct = n in (7, 9)
-            self.wh0_fused = (eng.wh0_frag is not None and os.environ.get("WOFT_WH0_FUSED", "1") != "0"
-                              and cp(self.a2, eng.wh2, self.a2, epi=EPI.EPI_RELU, precision=self.prec_wh).halo == 2)
-            # (with the first layer AND the tail fused into the two 128->128 launches only ONE activation exists)
-            self.a1 = self.a2 if self.wh0_fused else new_act(P, n, n, 128)
-            self.wh0_t = eng.wh0.wgt[:128].t().contiguous()          # [ky*32 + kx*8 + ci][co]
             self.wh6_b = torch.tensor([eng.wh6_b], dtype=torch.float32, device=dev)
-            self.prog_wh, self.wh_fused = self._wh_program(P, None)
-            # the head restricted to a subset of the source pixels (set_weight_region): programs per region
             self.wh_region = None                        # None = every source pixel
             self._wh_regions = {}
             self._wh_dyn = {}                            # per region: (dynamic window list, its programs, scratch)
+            if eng.wh_std:
+                self.a2 = new_act(P, n, n, 128)
+                # first conv (5 -> 128): scalar-operand VALU kernel straight from the lookup buffer for the 7x7 / 9x9
+                # windows (woft_wh_conv0), the generic conv on the packed x8 patches otherwise
+                self.wh0_direct = n in (7, 9)
+                self.wh0_fused = (eng.wh0_frag is not None and os.environ.get("WOFT_WH0_FUSED", "1") != "0"
+                                  and cp(self.a2, eng.wh2, self.a2, epi=EPI.EPI_RELU, precision=self.prec_wh).halo == 2)
+                # (with the first layer AND the tail fused into the two 128->128 launches only ONE activation exists)
+                self.a1 = self.a2 if self.wh0_fused else new_act(P, n, n, 128)
+                self.wh0_t = eng.wh0.wgt[:128].t().contiguous()          # [ky*32 + kx*8 + ci][co]
+                self.prog_wh, self.wh_fused = self._wh_program(P, None)
+                # the head restricted to a subset of the source pixels (set_weight_region): programs per region
+            else:
+                # any other weight_head_structure: layer by layer on every window, the closing 1x1 conv + window mean by
+                # woft_wh_reduce (no window subsets, no fused layers: a correct path, not a tuned one)
+                self.wh0_direct = self.wh0_fused = self.wh_fused = False
+                cpw = lambda *a, **kw: self._cp(*a, precision=self.prec_wh, **kw)
+                x = self.x8
+                if not eng.wh_flat0:                     # first kernel wider than 3: 32-channel rows instead of the flat 8
+                    self.x32 = new_act(P, n, n, 5, cs=32, zero=True)
+                    x = self.x32
+                cmax = max(_ru(pc.cout, 4) for pc in eng.wh_layers)
+                # (zeroed once: a layer writes its cout channels only, and the next layer's K chunks read whole 32-channel groups
+                #  against zero weights -- what a wider earlier layer left behind is finite, never NaN)
+                bufs = [new_act(P, n, n, cmax, cs=_ru(cmax, 32), zero=True), new_act(P, n, n, cmax, cs=_ru(cmax, 32), zero=True)]
+                self.prog_wh = []
+                for i, pc in enumerate(eng.wh_layers):
+                    out = Act(bufs[i % 2].t, P, n, n, pc.cout)
+                    self.prog_wh.append(cpw(x, pc, out, epi=EPI.EPI_RELU))
+                    x = out
+                self.wh_last = x
 
     def _fold_gather_programs(self):
         """Variants of the iteration programs in which the flow-head gather that ends iteration k is done by the lookup
@@ -357,7 +394,7 @@ class _Plan:
         lk.fh_flow4, lk.fh_flow_cat = _lib.ptr(self.flow4.t), flow_cat.data_ptr()
         lk.fh_planes, lk.fh_ld, lk.fh_ld_delta, lk.fh_ld_cat = n_planes, self.fh_part.shape[1], self.delta.cs, self.xbuf.cs
         lk._keep = (self.lookup._keep, bias2, self.fh_part)
-        out = {"gather": [self.prog_iter[-1]]}
+        out = {"gather": [self.prog_iter[-1]], "lookup": lk}
         for p in progs:
             head = p[0] if p is self.prog_iter_first else ("lookup", lk)
             out[id(p)] = [head] + p[1:-1]
@@ -573,11 +610,67 @@ class _Plan:
             prog += [("conv", cp(self.fh, e.fh2, self.delta)), ("coords", None)]
         return prog
 
+    # ---- the same iteration with its seven register-streamed conv layers in ONE persistent launch (UPDATE_PK) ----
+    def _pk_program(self, first, par, last):
+        """Launch list of one refinement iteration: lookup (+ the previous iteration's flow-head gather), convc1 | convf1 on the
+        per-tap kernel, then ONE woft_update_pk launch for convf2, convc2, convm, z|r / q of both half steps and the flow head's
+        conv (+ the mask head's first conv when `last`).  Same layers, same structs as _iter_program -- except that nothing is
+        written twice inside the launch (its tile counters order readers after writers only): the two half steps have their own
+        z / r*h tensors and the GRU state alternates between two buffers (par = iteration parity; the first iteration reads net0).
+        -> None when the persistent kernel does not take this plan (then the per-layer launches run)."""
+        key = (bool(first), int(par), bool(last))
+        if key in self._pk:
+            return self._pk[key]
+        e, cp, sp = self.eng, self._cp, self.eng.spec
+        prog = None
+        ok = (not sp.small and self.prec != "fp32" and self._fold is not None and self.gate_bias is not None and len(e.zr) == 2
+              and self.fh_part is not None and ops.USE_REGB and ops.USE_HALO)
+        if ok:
+            if not hasattr(self, "hB1"):
+                self.hB1, self.zbuf2, self.rh2 = (new_act(1, self.hf, self.wf, sp.hdim, zero=True) for _ in range(3))
+            hd = sp.hdim
+            hS = (self.hB, self.hB1)
+            h_in, h_out = (self.net0 if first else hS[1 - par]), hS[par]
+            L = [cp(self.fl1, e.convf2, self.cf, co_off=192, epi=EPI.EPI_RELU),
+                 cp(self.c1, e.convc2, self.cf, co_off=0, epi=EPI.EPI_RELU),
+                 cp(self.cf, e.convm, self.xbuf, co_off=sp.cdim, epi=EPI.EPI_RELU)]
+            states, zr_bufs = [h_in, self.hA, h_out], [(self.zbuf, self.rh), (self.zbuf2, self.rh2)]
+            for k in range(2):
+                hi, ho, (gz, gq), (zb, rb) = states[k], states[k + 1], self.gate_bias[k], zr_bufs[k]
+                L.append(cp(hi, e.zr_dyn[k], zb, x2=self.xbuf, x2_off=sp.cdim, c_split=hd, epi=EPI.EPI_GRU_ZR, split=hd, e0=hi,
+                            out1=rb, bias_map=gz))
+                L.append(cp(rb, e.q_dyn[k], ho, x2=self.xbuf, x2_off=sp.cdim, c_split=hd, epi=EPI.EPI_GRU_Q, e0=hi, e1=zb,
+                            bias_map=gq))
+            L.append(ops.flowhead_params(h_out, e.fh1, self.fh_part, e.fh2_frag, precision=self.prec))
+            if last:
+                L.append(cp(h_out, e.mk1, self.mk, epi=EPI.EPI_RELU))
+            try:
+                table = ops.PkTable(L, options=int(os.environ.get("WOFT_PK_OPTIONS", "0"))) if all(q is not None for q in L) else None
+            except _lib.WoftHipError:
+                table = None
+            if table is not None:
+                head = [ent for ent in self.prog_iter if ent[0] in ("conv", "conv2") and len(ent) > 2
+                        and ent[2] in ("convc1+convf1", "convc1", "convf1")]
+                lookup = ("lookup", self.lookup) if first else ("lookup", self._fold["lookup"])
+                prog = [lookup] + head + [("pk", table, "pk")]
+        self._pk[key] = prog
+        return prog
+
     # ---- execution ------------------------------------------------------------------------
     def run(self, prog):
         for ent in prog:
             kind, a = ent[0], ent[1]
-            if kind == "conv2":
+            if kind == "pk":
+                ev = self.conv_events
+                if ev is not None and "pk" in ev:
+                    s, t = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    s.record()
+                    a.run()
+                    t.record()
+                    ev["pk"].append((s, t, a))
+                else:
+                    a.run()
+            elif kind == "conv2":
                 ev = self.conv_events
                 if ev is not None and len(ent) > 2 and ent[2] in ev:
                     s, t = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -677,7 +770,13 @@ class _Plan:
         ops.coords_init(self.coords, self.hf, self.wf, self.flow4.t, self.xbuf.t[:, off:], self.xbuf.cs)
         last = getattr(self, "prog_iter_last", None) if iters > 1 else None
         fold = self._fold if trace is None else None        # (a trace reads the coordinates after every iteration)
+        # persistent update-block launch: every iteration's program exists, else the per-layer launches
+        pk = UPDATE_PK != "0" and trace is None and all(
+            self._pk_program(it == 0, it % 2, it == iters - 1) is not None for it in sorted({0, 1, 2, iters - 1}) if it < iters)
         for it in range(iters):
+            if pk:
+                self.run(self._pk_program(it == 0, it % 2, it == iters - 1))
+                continue
             prog = self.prog_iter_first if it == 0 else (last if (last is not None and it == iters - 1) else self.prog_iter)
             if fold is not None:
                 prog = fold[id(prog)]
@@ -686,7 +785,7 @@ class _Plan:
                 trace(self, it)
         if fold is not None:
             self.run(fold["gather"])
-        for p in (self.prog_mask[1:] if last is not None else self.prog_mask):
+        for p in (self.prog_mask[1:] if (last is not None or pk) else self.prog_mask):
             ops.run_conv(p)
         wlow = None
         if defer_wh:
@@ -731,6 +830,13 @@ class _Plan:
         ops.convex_upsample(self.coords, self.wlow, self.mask.t, self.hf, self.wf, crop, h, w, flow_up=flow_up, dst=dst,
                             wout=wout, do_sigmoid=do_sigmoid)
 
+    def _wh6_padded(self, cs):
+        """The closing 1x1 conv's weights padded with zeros to the activation's channel stride (woft_wh_reduce walks whole rows)."""
+        if getattr(self, "_wh6_pad", None) is None or self._wh6_pad.numel() != cs:
+            self._wh6_pad = torch.zeros(cs, dtype=torch.float32, device="cuda")
+            self._wh6_pad[:self.eng.wh6_c] = self.eng.wh6_w[:self.eng.wh6_c]
+        return self._wh6_pad
+
     def _weight_head(self, prog_wh, index, n_needed=None, need=None):
         """Final lookup + the weight head (weighted_raft.py:266-272, 347-384) on all source pixels (index None) or on the
         windows listed in `index` -> self.wlow."""
@@ -749,6 +855,8 @@ class _Plan:
                                     _lib.ptr(self.cs_tot), 1.0 / (math.sqrt(float(sp.fdim)) * self.P), self.P, n,
                                     _lib.ptr(self.wmean), None if self.wh0_direct else _lib.ptr(self.x8.t),
                                     _lib.stream_ptr()), "woft_wh_pack")
+        if not e.wh_std and not e.wh_flat0:
+            self.x32.t[:, :8].copy_(self.x8.t)                   # (generic head, first kernel wider than 3)
         n_win = int(index.numel()) if index is not None else self.P
         if index is not None:
             self.wlow.zero_()                                    # pixels outside the region
@@ -768,5 +876,6 @@ class _Plan:
             else:
                 ops.run_conv(p)
         if not self.wh_fused:
-            _lib.check(lib.woft_wh_reduce(_lib.ptr(self.a1.t), 128, n * n, _lib.ptr(e.wh6_w), e.wh6_b, self.P,
+            last = self.a1 if e.wh_std else self.wh_last
+            _lib.check(lib.woft_wh_reduce(_lib.ptr(last.t), last.cs, n * n, _lib.ptr(self._wh6_padded(last.cs)), e.wh6_b, self.P,
                                           _lib.ptr(self.wlow), _lib.stream_ptr()), "woft_wh_reduce")

@@ -224,9 +224,10 @@ class RAFTWrapper:
         self.last_flow_shape = {"batch": 1, "delta": 2, "H": oh, "W": ow}
         if numpy_out:
             return host(o["src"]), host(o["dst"]), (host(weights) if weights is not None else None)
-        # (the int64 source grid is a constant of the resolution -- 33 MB at 1080p: handed out SHARED, never cloned;
-        #  a caller that wants to write into it must copy it first)
-        return o["src"], own(o["dst"]), (own(weights) if weights is not None else None)
+        # (the int64 source grid is a constant of the resolution -- 33 MB at 1080p: the provider's own tensor under borrow=True
+        #  (the tracker only indexes it); any other caller gets a tensor it may edit in place, as the reference's callers may --
+        #  round-4 advisor finding: a shared grid that a caller offsets or sorts would corrupt every later call at this size)
+        return own(o["src"]), own(o["dst"]), (own(weights) if weights is not None else None)
 
     def compute_flow(self, src_img, dst_img, mode="TC", vis=False, src_img_identifier=None,
                      numpy_out=False, do_sigmoid=False, borrow=False, defer_weights=False, weight_region=False):

@@ -97,8 +97,10 @@ def _small_encoder(g, p, out_dim, norm):
     g.conv(p + ".conv2", out_dim, 96, 1, 1)
 
 
-def make_state_dict(seed=0, small=False, weighted=True, head_gain=1.0):
+def make_state_dict(seed=0, small=False, weighted=True, head_gain=1.0, weight_head_structure=None):
     """Synthetic checkpoint with the reference's key set.
+    weight_head_structure: the flow config's `class_params.weight_head_structure` (weighted_raft.py:318-345: a list of
+    (channels, kernel) tuples or plain channel counts = 3x3 layers); default [(128, 3)] * 3, the shipped configs' head.
 
     small=False, weighted=True  -> WeightedRAFT full (weighted_raft.py:62-72)
     small=True,  weighted=False -> plain RAFT-small  (raft.py:49-56)
@@ -133,11 +135,15 @@ def make_state_dict(seed=0, small=False, weighted=True, head_gain=1.0):
         g.conv(u + ".mask.0", 256, 128, 3, 3, "default")
         g.conv(u + ".mask.2", 576, 256, 1, 1, "default")
     if weighted:
-        # weight_head_structure [(128,3)]*3 (optical_flow/configs/v2_SNOB_large_g05_RAFT.py:16)
-        g.conv("weight_head.net.0", 128, 5, 3, 3, "default")
-        g.conv("weight_head.net.2", 128, 128, 3, 3, "default")
-        g.conv("weight_head.net.4", 128, 128, 3, 3, "default")
-        g.conv("weight_head.net.6", 1, 128, 1, 1, "default")
+        # weight_head_structure [(128,3)]*3 (optical_flow/configs/v2_SNOB_large_g05_RAFT.py:16) unless told otherwise;
+        # layer i is net.(2 i) (a ReLU between two convs), the closing 1x1 conv follows (weighted_raft.py:323-341)
+        cur = 5
+        structure = weight_head_structure if weight_head_structure is not None else [(128, 3)] * 3
+        for i, data in enumerate(structure):
+            c, k = data if isinstance(data, (list, tuple)) else (data, 3)
+            g.conv(f"weight_head.net.{2 * i}", c, cur, k, k, "default")
+            cur = c
+        g.conv(f"weight_head.net.{2 * len(structure)}", 1, cur, 1, 1, "default")
     return g.sd
 
 

@@ -75,10 +75,14 @@ def _device_u8(img, copy=False):
 
 class _FrameUploader:
     """Host frames (numpy, as WOFT_demo.py:61-78 / TRK:113-120 hand them to track()) -> device, without the pageable-copy
-    path of `tensor.cuda()`: the frame is copied into one of two PINNED staging buffers and sent with an asynchronous
-    H2D copy on the stream the frame's kernels are enqueued on; the two device buffers alternate, so the frame that becomes
-    `prev_img` stays valid while the next one arrives (the local stage reads frame t-1, TRK:181-184).  6.2 MB per 1080p
-    frame: ~0.25 ms of host memcpy + ~0.15 ms of PCIe time, against 2-3 ms for the pageable copy (bench `host_frames`)."""
+    path of `tensor.cuda()` (2-3 ms per 1080p frame): the frame goes through one of two PINNED staging buffers in pieces --
+    woft_upload_u8: piece k's asynchronous H2D copy runs under the host memcpy of piece k + 1 -- on the stream the frame's
+    kernels are enqueued on; the two device buffers alternate, so the frame that becomes `prev_img` stays valid while the next
+    one arrives (the local stage reads frame t-1, TRK:181-184).
+    LIFETIME of what track() keeps: `tracker.prev_img` (and anything else holding the returned device frame) is valid until
+    the SECOND next host-frame track() call, which reuses its buffer; a caller that wants a frame for longer clones it.  A change
+    of frame shape allocates new buffers (the old prev_img stays valid, as its own tensor)."""
+    CHUNKS = int(os.environ.get("WOFT_UPLOAD_CHUNKS", "8"))
 
     def __init__(self):
         self.key, self.stage, self.dev, self.done, self.i = None, None, None, None, 0
@@ -95,8 +99,13 @@ class _FrameUploader:
             self.key, self.i = key, 0
         i = self.i = self.i ^ 1
         self.done[i].synchronize()                   # (the copy that last read this staging buffer: two frames ago)
-        np.copyto(self.stage[i].numpy(), a)          # handles non-contiguous views (e.g. a BGR<->RGB flipped array)
-        self.dev[i].copy_(self.stage[i], non_blocking=True)
+        if a.flags.c_contiguous and a.nbytes >= (1 << 20):
+            from . import _lib
+            _lib.check(_lib.load().woft_upload_u8(a.ctypes.data, self.stage[i].data_ptr(), self.dev[i].data_ptr(), a.nbytes,
+                                                  self.CHUNKS, _lib.stream_ptr()), "woft_upload_u8")
+        else:                                        # (non-contiguous views, e.g. a BGR<->RGB flipped array; small frames)
+            np.copyto(self.stage[i].numpy(), a)
+            self.dev[i].copy_(self.stage[i], non_blocking=True)
         self.done[i].record()
         return self.dev[i]
 
