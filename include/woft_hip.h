@@ -173,7 +173,9 @@ int woft_upload_u8(const void* src, void* pinned, void* dev, int64_t bytes, int3
  * counters: write-through output stores -> counter increment; the consumer polls its producers' counters, then one
  * agent-scope acquire) -- no launch ramp, tail or write-back between layers, and the two workgroups of a CU drift out of
  * phase (one's epilogue beside the other's main loop).  Every tile is computed by the code of woft_conv2d's halo 8 / 12
- * kernel (same products, same order): results are bit-identical to the seven launches.
+ * kernel (same products, same order): results are bit-identical to the seven launches.  Precision 1 (bf16x3) layers only.
+ * MEASURED SLOWER than the launches it replaces (0.53-0.61 vs 0.41 ms per iteration at 1/8 of 1080p; DESIGN.md section 4, round
+ * 5, tools/pk_timeline.py): kept as an opt-in path (WOFT_UPDATE_PK=1) and as the instrument of that measurement.
  *
  * The caller describes the layers in launch order in a table of woft_pk_layer (built on the host, copied to the device
  * once per resolution); `state` is a zero-initialised device buffer of woft_update_pk_state_bytes() that the kernel
@@ -203,7 +205,8 @@ int64_t woft_update_pk_state_bytes(const woft_pk_layer* table, int32_t n);
 /* One launch.  table_dev: the prepared table copied to the device; table_host: the same table (host), read for the grid
  * geometry only.  state[2] != 0 after the launch: a workgroup gave up waiting (give-up code = 1 + its work item; never
  * expected -- the kernel cannot deadlock while its resident workgroups run; results are then invalid and `state` must be
- * zeroed by the caller).  options: bit 0 = no acquire fence after the dependency wait (A/B knob; see DESIGN). */
+ * zeroed by the caller).  options (developer A/B knobs): bit 0 = no acquire fence after the dependency wait; bit 2 = every second
+ * workgroup starts ~20 us late.  state[4..5] = device address of a [items][4] uint64 timeline buffer or 0 (tools/pk_timeline.py). */
 int woft_update_pk(const woft_pk_layer* table_dev, const woft_pk_layer* table_host, int32_t n, uint32_t* state, int32_t options,
                    void* stream);
 /* fp32 array (n % 4 == 0) -> bf16 planes hi = bf16(x), lo = bf16(x - hi) (lo may be NULL): the

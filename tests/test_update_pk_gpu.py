@@ -72,7 +72,7 @@ def _chain(ops, h, w, precision):
     return L, (x0, x1, h0), (cat, mot, z[0], rh[0], hA, z[1], rh[1], hB, fin)
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "bf16", "fp16"])
+@pytest.mark.parametrize("precision", ["bf16x3"])      # (the kernel is instantiated for the shipped arithmetic only)
 @pytest.mark.parametrize("h,w", [(135, 240), (17, 25), (40, 64), (9, 16), (8, 33)])
 def test_persistent_launch_equals_layer_launches(ops, h, w, precision):
     L, ins, outs = _chain(ops, h, w, precision)
@@ -142,10 +142,12 @@ def test_table_checks(ops):
         ops.PkTable([a, ops.conv_params(y, p1, z, precision="bf16x3")])        # 1x1: the per-tap kernel's layer
     with pytest.raises(ops._lib.WoftHipError):
         ops.PkTable([ops.conv_params(x, pc, y, epi=E.EPI_RELU, precision="fp32")])
+    with pytest.raises(ops._lib.WoftHipError):
+        ops.PkTable([ops.conv_params(x, pc, y, epi=E.EPI_RELU, precision="bf16")])     # (bf16x3 only)
 
 
 @torch.no_grad()
-@pytest.mark.parametrize("precision", ["bf16x3", "bf16", "fp16", "f16mx8"])
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
 @pytest.mark.parametrize("h,w,iters", [(136, 200, 5), (72, 136, 1), (264, 392, 2)])
 def test_flow_with_persistent_update_block_is_bit_identical(monkeypatch, precision, h, w, iters):
     from woft_amd import engine
@@ -163,8 +165,11 @@ def test_flow_with_persistent_update_block_is_bit_identical(monkeypatch, precisi
         plan = prov.engine.plan(h, w)
         if pk == "1":
             progs = [v for v in plan._pk.values() if v is not None]
-            assert progs and all(ent[1].status() == 0 for pr in progs for ent in pr if ent[0] == "pk")
-            assert sum(ent[0] == "pk" for ent in progs[0]) == 1 and len(progs[0]) == 3      # lookup, convc1 | convf1, the rest
+            if precision != "bf16x3":                    # no instance of the kernel: the per-layer launches ran
+                assert not progs
+            else:
+                assert progs and all(ent[1].status() == 0 for pr in progs for ent in pr if ent[0] == "pk")
+                assert sum(ent[0] == "pk" for ent in progs[0]) == 1 and len(progs[0]) == 3      # lookup, convc1 | convf1, the rest
         outs.append((flow.clone(), wts.clone(), flow2.clone(), wts2.clone()))
     for x, y in zip(*outs):
         assert torch.equal(x, y)

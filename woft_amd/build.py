@@ -21,8 +21,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math"
 # ONE core (conv.hip as a single unit: 9+ minutes), the parts run side by side.  Every part exports its own dispatcher symbol
 # (woft_conv_dispatch_p<k>, woft_conv_regb_launch_p<k>); the C ABI entry points live in part 1 of conv.hip.
 PARTS = {"conv.hip": [("p1", ["-DWOFT_ONLY_PREC=1"]), ("p2", ["-DWOFT_ONLY_PREC=2"]), ("p3", ["-DWOFT_ONLY_PREC=3"])],
-         "conv_regb.hip": [(f"p{k}", [f"-DWOFT_ONLY_PREC={k}"]) for k in (1, 2, 3, 4)],
-         "update_pk.hip": [(f"p{k}", [f"-DWOFT_ONLY_PREC={k}"]) for k in (1, 2, 3, 4)]}
+         "conv_regb.hip": [(f"p{k}", [f"-DWOFT_ONLY_PREC={k}"]) for k in (1, 2, 3, 4)]}
 
 
 def _sources():

@@ -22,23 +22,12 @@
 #define WOFT_STORE_WT 1
 #include "conv_regb_body.h"
 
-#if !defined(WOFT_ONLY_PREC)
-#error "update_pk.hip is compiled in parts: -DWOFT_ONLY_PREC=1|2|3|4 (woft_amd/build.py)"
-#endif
-#define WOFT_CAT2_(a, b) a##b
-#define WOFT_CAT2(a, b) WOFT_CAT2_(a, b)
-#define WOFT_PK_ENTRY WOFT_CAT2(woft_update_pk_launch_p, WOFT_ONLY_PREC)
+// (Instantiated for precision 1, bf16x3 -- the shipped arithmetic -- only: the kernel measured SLOWER than the per-layer launches
+//   and stays opt-in as the instrument of that measurement; one translation unit, not four.)
 
 namespace {
 
-#if WOFT_ONLY_PREC == 1 || WOFT_ONLY_PREC == 4
 constexpr int MAIN_TERMS = 3;
-#elif WOFT_ONLY_PREC == 3
-constexpr int MAIN_TERMS = 16;
-#else
-constexpr int MAIN_TERMS = 1;
-#endif
-constexpr bool WITH_MX = (WOFT_ONLY_PREC == 4);     // precision "f16mx8": the 3x3 layers may run the two-pass product (kinds 9 .. 11)
 
 constexpr int ST_HEAD = 0, ST_EXITED = 1, ST_ERR = 2, ST_CNT0 = 16;     // words of the state buffer
 constexpr unsigned SPIN_LIMIT = 400000u;                                  // polls (~1 us each) before a workgroup gives up
@@ -56,7 +45,7 @@ constexpr int smem_of() {
     m = cmax(m, RegbGeom<8, 16, 5, 1, 2, T>::SMEM_ELEMS); m = cmax(m, RegbGeom<8, 16, 5, 1, 1, T>::SMEM_ELEMS); m = cmax(m, RegbGeom<4, 16, 5, 1, 1, T>::SMEM_ELEMS);
     return m;
 }
-constexpr int PK_SMEM = cmax(smem_of<MAIN_TERMS>(), WITH_MX ? smem_of<28>() : 0);
+constexpr int PK_SMEM = smem_of<MAIN_TERMS>();
 
 typedef __attribute__((address_space(1))) uint32_t gu32;
 __device__ __forceinline__ uint32_t ld_relaxed(const uint32_t* p) {
@@ -80,6 +69,12 @@ __global__ __launch_bounds__(256, 2) void update_pk_kernel(const woft_pk_layer* 
     {
         const unsigned long long a = ((unsigned long long)state[5] << 32) | state[4];
         tl = (unsigned long long*)(uintptr_t)a;
+    }
+
+    // options bit 2 (experiment): every second workgroup starts ~20 us late, so that the two workgroups of a CU are half a tile out
+    // of phase (one's prologue / epilogue stores beside the other's main loop) instead of in lock-step from the launch on
+    if ((options & 4) && (blockIdx.x & 8)) {           // (consecutive ids sit on consecutive XCDs: bit 3 alternates within a CU pair)
+        for (int i = 0; i < 4; ++i) __builtin_amdgcn_s_sleep(127);
     }
 
     int my_next = 0;                                   // (thread 0) the item after the current one, requested a whole item ahead
@@ -171,11 +166,6 @@ __global__ __launch_bounds__(256, 2) void update_pk_kernel(const woft_pk_layer* 
             PK_CASE(6, 8, 5, 1, 2, MAIN_TERMS, 5, 3);
             PK_CASE(7, 8, 5, 1, 1, MAIN_TERMS, 5, 3);
             PK_CASE(8, 4, 5, 1, 1, MAIN_TERMS, 5, 3);
-#if WOFT_ONLY_PREC == 4
-            PK_CASE(9, 8, 3, 3, 2, 28, 3, 2);
-            PK_CASE(10, 8, 3, 3, 1, 28, 3, 2);
-            PK_CASE(11, 4, 3, 3, 1, 28, 3, 2);
-#endif
 #undef PK_CASE
             default: break;
         }
@@ -215,18 +205,13 @@ int kind_of(const woft_conv_params& c) {
     else if (c.halo == 8 && c.tile_n == 128) shape = 1;
     else if (c.halo == 12 && c.tile_n == 128) shape = 2;
     else return -1;
-    int kind = taps * 3 + shape;
-    if (c.precision == 4) {
-        if (taps != 0) return -1;                      // (the persistent kernel instantiates the two-pass product for the 3x3 layers)
-        kind = 9 + shape;
-    }
-    return kind;
+    return taps * 3 + shape;
 }
 
 }  // namespace
 
-int WOFT_PK_ENTRY(const woft_pk_layer* table_dev, const woft_pk_layer* th, int32_t n, uint32_t* state, int32_t options, int n_cu,
-                  void* stream) {
+static int pk_launch(const woft_pk_layer* table_dev, const woft_pk_layer* th, int32_t n, uint32_t* state, int32_t options, int n_cu,
+                     void* stream) {
     PkHdr hdr;
     int n_items = 0, n_cnt = 0;
     for (int l = 0; l < n; ++l) {
@@ -242,27 +227,16 @@ int WOFT_PK_ENTRY(const woft_pk_layer* table_dev, const woft_pk_layer* th, int32
     return woft_launch_status();
 }
 
-#if WOFT_ONLY_PREC == 1
-int woft_update_pk_launch_p2(const woft_pk_layer*, const woft_pk_layer*, int32_t, uint32_t*, int32_t, int, void*);
-int woft_update_pk_launch_p3(const woft_pk_layer*, const woft_pk_layer*, int32_t, uint32_t*, int32_t, int, void*);
-int woft_update_pk_launch_p4(const woft_pk_layer*, const woft_pk_layer*, int32_t, uint32_t*, int32_t, int, void*);
-
-// the arithmetic family of a table: every layer in one of the split-bf16 / fp16 precisions (1, 2, 3), or "f16mx8" (4: 3x3 layers
-// in precision 4, the others in bf16x3); 0 = not a table the persistent kernel takes
-static int pk_family(const woft_pk_layer* t, int32_t n) {
-    bool mx = false;
-    for (int l = 0; l < n; ++l) mx = mx || t[l].conv.precision == 4;
-    const int fam = mx ? 4 : t[0].conv.precision;
-    for (int l = 0; l < n; ++l) {
-        const int pr = t[l].conv.precision;
-        if (mx ? (pr != 4 && pr != 1) : pr != fam) return 0;
-    }
-    return (fam >= 1 && fam <= 4) ? fam : 0;
+// every layer in precision 1 (bf16x3)
+static bool pk_family_ok(const woft_pk_layer* t, int32_t n) {
+    for (int l = 0; l < n; ++l)
+        if (t[l].conv.precision != 1) return false;
+    return true;
 }
 
 extern "C" int woft_update_pk_prepare(woft_pk_layer* t, int32_t n) {
     if (t == nullptr || n < 1 || n > WOFT_PK_MAX_LAYERS) return WOFT_EINVAL;
-    if (pk_family(t, n) == 0) return WOFT_EINVAL;
+    if (!pk_family_ok(t, n)) return WOFT_EINVAL;
     int item = 0, cnt = 0;
     for (int l = 0; l < n; ++l) {
         woft_pk_layer& L = t[l];
@@ -271,7 +245,6 @@ extern "C" int woft_update_pk_prepare(woft_pk_layer* t, int32_t n) {
         if (c.in_norm != 0 || c.stat_sum != nullptr || c.in_mean != nullptr || c.wh0_lookup != nullptr || c.out_pitch != 0) return WOFT_EINVAL;
         if (c.ho != c.h || c.wo != c.w || c.pad_y != c.taps_y / 2 || c.pad_x != c.taps_x / 2) return WOFT_EINVAL;
         if (c.cin_pad <= 0 || c.cin_pad % 32 != 0 || (c.in1 != nullptr && (c.c_split <= 0 || c.c_split % 32 != 0 || c.c_split >= c.cin_pad))) return WOFT_EINVAL;
-        if (c.precision == 4 && c.wgt_mx == nullptr) return WOFT_EINVAL;
         const int kind = kind_of(c);
         if (kind < 0 || c.cout_pad % c.tile_n != 0 || c.cout > c.cout_pad) return WOFT_EINVAL;
         switch (c.epi) {
@@ -327,12 +300,6 @@ extern "C" int woft_update_pk(const woft_pk_layer* table_dev, const woft_pk_laye
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return WOFT_ELAUNCH;
         n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    switch (pk_family(th, n)) {
-        case 1: return woft_update_pk_launch_p1(table_dev, th, n, state, options, n_cu, stream);
-        case 2: return woft_update_pk_launch_p2(table_dev, th, n, state, options, n_cu, stream);
-        case 3: return woft_update_pk_launch_p3(table_dev, th, n, state, options, n_cu, stream);
-        case 4: return woft_update_pk_launch_p4(table_dev, th, n, state, options, n_cu, stream);
-        default: return WOFT_EINVAL;
-    }
+    if (!pk_family_ok(th, n)) return WOFT_EINVAL;
+    return pk_launch(table_dev, th, n, state, options, n_cu, stream);
 }
-#endif  // WOFT_ONLY_PREC == 1 (C ABI entry points)

@@ -35,7 +35,9 @@ FUSE_FLOWHEAD = os.environ.get("WOFT_FUSE_FLOWHEAD", "1") != "0"
 PAIR_BRANCHES = os.environ.get("WOFT_PAIR", "1") != "0"
 # The seven register-streamed conv layers of a refinement iteration (convc2 | convf2, convm, z|r and q of both GRU half steps, the flow
 # head's conv) as ONE persistent launch: resident workgroups pull (layer, tile) work items from a queue and hand tiles to each other
-# through per-tile ready counters (csrc/update_pk.hip).  "0": one launch per layer (round 3's 9 launches)
+# through per-tile ready counters (csrc/update_pk.hip; bf16x3).  Bit-identical to the per-layer launches (tested) and OPT-IN
+# (WOFT_UPDATE_PK=1): measured 0.53-0.61 ms per iteration against 0.41 ms for the seven launches (DESIGN section 4, round 5:
+# the launches' ramps and tails were never idle matrix time -- the workgroups that remain run faster --, the hand-offs are).
 UPDATE_PK = os.environ.get("WOFT_UPDATE_PK", "0")
 PYRAMID_ONE_LAUNCH = os.environ.get("WOFT_PYRAMID", "1") != "0"    # target pyramid (pool + split of all levels) in one launch
 # the flow-head gather of iteration k runs inside the lookup launch of iteration k + 1 (volume-free lookup; the last
@@ -623,7 +625,7 @@ class _Plan:
             return self._pk[key]
         e, cp, sp = self.eng, self._cp, self.eng.spec
         prog = None
-        ok = (not sp.small and self.prec != "fp32" and self._fold is not None and self.gate_bias is not None and len(e.zr) == 2
+        ok = (not sp.small and self.prec == "bf16x3" and self._fold is not None and self.gate_bias is not None and len(e.zr) == 2
               and self.fh_part is not None and ops.USE_REGB and ops.USE_HALO)
         if ok:
             if not hasattr(self, "hB1"):
@@ -631,6 +633,11 @@ class _Plan:
             hd = sp.hdim
             hS = (self.hB, self.hB1)
             h_in, h_out = (self.net0 if first else hS[1 - par]), hS[par]
+            # (developer knob WOFT_PK_TN=64: 64-column tiles for every layer -- twice the work items of the 128-column layers,
+            #  so that a tile's producers are a full round of the resident workgroups ahead of it in the queue)
+            tn = int(os.environ.get("WOFT_PK_TN", "0"))
+            if tn:
+                cp = lambda *a, **kw: self._cp(*a, halo=8, tiles=(128, tn), **kw)
             L = [cp(self.fl1, e.convf2, self.cf, co_off=192, epi=EPI.EPI_RELU),
                  cp(self.c1, e.convc2, self.cf, co_off=0, epi=EPI.EPI_RELU),
                  cp(self.cf, e.convm, self.xbuf, co_off=sp.cdim, epi=EPI.EPI_RELU)]
@@ -641,7 +648,8 @@ class _Plan:
                             out1=rb, bias_map=gz))
                 L.append(cp(rb, e.q_dyn[k], ho, x2=self.xbuf, x2_off=sp.cdim, c_split=hd, epi=EPI.EPI_GRU_Q, e0=hi, e1=zb,
                             bias_map=gq))
-            L.append(ops.flowhead_params(h_out, e.fh1, self.fh_part, e.fh2_frag, precision=self.prec))
+            L.append(ops.flowhead_params(h_out, e.fh1, self.fh_part, e.fh2_frag, precision=self.prec,
+                                         **(dict(halo=8, tiles=(128, tn)) if tn else {})))
             if last:
                 L.append(cp(h_out, e.mk1, self.mk, epi=EPI.EPI_RELU))
             try:
@@ -651,8 +659,16 @@ class _Plan:
             if table is not None:
                 head = [ent for ent in self.prog_iter if ent[0] in ("conv", "conv2") and len(ent) > 2
                         and ent[2] in ("convc1+convf1", "convc1", "convf1")]
-                lookup = ("lookup", self.lookup) if first else ("lookup", self._fold["lookup"])
-                prog = [lookup] + head + [("pk", table, "pk")]
+                # the flow-head gather of the previous iteration inside this iteration's lookup launch, on THIS table's column-tile
+                # planes (they differ from the per-layer program's when the table picked another tile width)
+                planes = L[7]._n_planes
+                lk = self._fold["lookup"]
+                if planes != lk.fh_planes:
+                    lk2 = type(lk).from_buffer_copy(lk)
+                    lk2.fh_planes, lk2._keep = planes, lk._keep
+                    lk = lk2
+                self._pk_gather = [("fh_gather", (planes, self.prog_iter[-1][1][1]))]
+                prog = [("lookup", self.lookup) if first else ("lookup", lk)] + head + [("pk", table, "pk")]
         self._pk[key] = prog
         return prog
 
@@ -783,7 +799,9 @@ class _Plan:
             self.run(prog)
             if trace is not None:
                 trace(self, it)
-        if fold is not None:
+        if pk:
+            self.run(self._pk_gather)
+        elif fold is not None:
             self.run(fold["gather"])
         for p in (self.prog_mask[1:] if (last is not None or pk) else self.prog_mask):
             ops.run_conv(p)
