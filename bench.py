@@ -181,7 +181,7 @@ def main():
         if precision is not None:                 # (None: the shipped flow config's own `precision` key decides)
             conf.flow_config.precision = precision
         conf.flow_config.graph = graph
-        precision = precision or conf.flow_config.precision or "fp32"
+        precision = precision or conf.flow_config.precision or "bf16x3"
         # (exact fp32: volume-free since round 3 -- bit-identical to the volume path, no P x P buffer; WOFT_FP32_CORR=volume: A/B)
         conf.flow_config.corr = (corr or args.corr) if precision != "fp32" else (corr or os.environ.get("WOFT_FP32_CORR", "otf"))
         trk = conf.tracker_class(conf)
@@ -562,14 +562,15 @@ def main():
         # ---- the drop-in as a reference user writes it (round-4 review): a tracker config in the REFERENCE's form -- estimator,
         # Sobol subsampler and inlier test defined inline as plain functions, no woft_amd import, no tags
         # (tests/configs/inline_wlsq.py; configs/YAOFT_single_control_repRAFT_sub500_noreliableinl_wLSq.py:14-53) -- (a) with a flow
-        # config WITHOUT a `precision` key (the reference's arithmetic class: exact fp32), (b) with precision = 'bf16x3'.  The
-        # tracker recognises the callables by their behaviour (woft_amd.probe) and runs the device solver.
+        # config WITHOUT a `precision` key (built-in default: fp32-emulating bf16x3), (b) with precision = 'bf16x3'.  The
+        # tracker recognises the callables by their behaviour (woft_amd.probe) and runs the device solver.  (a') the same with
+        # precision = 'fp32': exact products -- what round 4's default for a keyless config was.
         import importlib.util
         spec = importlib.util.spec_from_file_location("inline_wlsq", str(ROOT / "tests" / "configs" / "inline_wlsq.py"))
         mod = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(mod)
         ref_form = {}
-        for name, prec in (("no_precision_key", None), ("precision_bf16x3", "bf16x3")):
+        for name, prec in (("no_precision_key", None), ("precision_bf16x3", "bf16x3"), ("precision_fp32", "fp32")):
             conf = mod.get_config(precision=prec)
             conf.flow_config.model, conf.flow_config.iters = sd, args.iters
             trk = conf.tracker_class(conf)
@@ -715,8 +716,9 @@ def main():
     cfgd["fps_bf16x3_full_head"] = r1(g(out, "reference_work", "bf16x3_full_weight_head", "frames_per_s"))
     cfgd["fps_strict_fp32"] = r1(g(out, "strict_fp32", "frames_per_s"))
     cfgd["fps_host_frames"] = r1(g(out, "host_frames", "frames_per_s"))
-    cfgd["fps_reference_form_config_fp32"] = r1(g(out, "reference_format_config", "no_precision_key", "frames_per_s"))
+    cfgd["fps_reference_form_config_unmodified"] = r1(g(out, "reference_format_config", "no_precision_key", "frames_per_s"))
     cfgd["fps_reference_form_config_bf16x3"] = r1(g(out, "reference_format_config", "precision_bf16x3", "frames_per_s"))
+    cfgd["fps_reference_form_config_fp32"] = r1(g(out, "reference_format_config", "precision_fp32", "frames_per_s"))
     cfgd["fps_update_block_other_mode"] = r1(g(out, "alt_update_block", "frames_per_s"))
     cfgd["fps_f16mx8"] = r1(g(out, "alt_precisions", "f16mx8", "frames_per_s"))     # (opt-in: 2 matrix-pipe passes per product on the 3x3 layers)
     cfgd["epe_mean_px"] = g(out, "flow_epe_vs_cpu_oracle", "mean_px")

@@ -39,7 +39,7 @@ def get_config(precision=None):
     conf = Config()
     conf.tracker_class = YAOFTrackerSingleControl
     conf.flow_config = load_config(root / 'pytracking' / 'optical_flow' / 'configs' / 'v2_SNOB_large_g05_RAFT.py')
-    del conf.flow_config.precision             # a reference flow config has no such key: the reference's arithmetic class (fp32)
+    del conf.flow_config.precision             # a reference flow config has no such key: the provider's built-in default decides
     if precision is not None:
         conf.flow_config.precision = precision
     conf.flow_config.weights_postprocessing_fn = None

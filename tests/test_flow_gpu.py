@@ -18,7 +18,7 @@ def _t(a):
     return torch.from_numpy(a[:, :, ::-1].copy()).permute(2, 0, 1).float()[None]
 
 
-def _flow_config(sd, iters, raft_type="weighted", padding_mode="nopad", small=False, precision=None):
+def _flow_config(sd, iters, raft_type="weighted", padding_mode="nopad", small=False, precision="fp32"):
     from woft_amd.config import Config
     from woft_amd.flow_provider import RAFTWrapper
     c = Config()
@@ -256,7 +256,7 @@ def test_mixed_precision_key_selects_the_fp16_operating_point():
     """class_params.mixed_precision = True (weighted_raft.py:204,215,233: autocast around fnet, cnet, update block) ->
     fp16 convolutions there, fp32-class correlation and weight head; `precision` / WOFT_PRECISION override it."""
     sd = synth.make_state_dict(seed=3)
-    c = _flow_config(sd, 2)
+    c = _flow_config(sd, 2, precision=None)
     c.class_params.mixed_precision = True
     prov = c.of_class(c)
     e = prov.engine
@@ -268,6 +268,10 @@ def test_mixed_precision_key_selects_the_fp16_operating_point():
     c2 = _flow_config(sd, 2, precision="bf16x3")
     c2.class_params.mixed_precision = True
     assert c2.of_class(c2).precision == "bf16x3"
+    # no key at all (an unmodified reference flow config): the built-in default, fp32-emulating bf16x3 (flow_provider.py: why)
+    c3 = _flow_config(sd, 2, precision=None)
+    p3 = c3.of_class(c3)
+    assert p3.precision == "bf16x3" and "built-in default" in p3.precision_source
 
 
 @torch.no_grad()

@@ -593,7 +593,8 @@ def test_reference_form_config_takes_the_device_solver_with_identical_results(mo
         conf = load_config(path)
         conf.flow_config.model, conf.flow_config.iters = sd, iters
         for k, v in kw.items():
-            setattr(conf.flow_config, k, v)
+            if v is not None:
+                setattr(conf.flow_config, k, v)
         trk = conf.tracker_class(conf)
         trk.init(template, mask)
         return trk, [trk.track(f) for f in frames]
@@ -608,11 +609,14 @@ def test_reference_form_config_takes_the_device_solver_with_identical_results(mo
     for (Ha, ma), (Hb, mb), (Hc, mc) in zip(r_dev, r_call, r_pre):
         assert np.array_equal(Ha, Hc) and ma.lost == mc.lost == mb.lost and ma.N_lost == mb.N_lost
         assert _corners_err(Ha, Hb, H, W) < 1e-2           # (callable back end: torch's QR-free path on the same kernels, fp32 H)
-    # no `precision` key (an unmodified reference flow config): the reference's arithmetic class, still the device solver
-    t_fp32, r_fp32 = run(inline, True)
-    assert t_fp32.flower.precision == "fp32" and t_fp32._fused is not None
-    for (Ha, _), (Hb, _) in zip(r_fp32, r_dev):
-        assert _corners_err(Ha, Hb, H, W) < 0.05
+    # no `precision` key (an unmodified reference flow config): bf16x3 by the built-in default -- the very same run --, and exact
+    # fp32 products one key away
+    t_def, r_def = run(inline, True, precision=None)
+    assert t_def.flower.precision == "bf16x3" and "built-in default" in t_def.flower.precision_source and t_def._fused is not None
+    t_fp32, r_fp32 = run(inline, True, precision="fp32")
+    assert t_fp32.flower.precision == "fp32"
+    for (Ha, _), (Hb, _), (Hc, _) in zip(r_fp32, r_dev, r_def):
+        assert _corners_err(Ha, Hb, H, W) < 0.05 and np.array_equal(Hb, Hc)
 
 
 def test_host_frames_keep_the_previous_frame_intact():

@@ -62,16 +62,22 @@ class RAFTWrapper:
             state_dict.update({k: v for k, v in read(self.C.backbone_model).items() if in_backbone(k)})
         weighted = self.C.raft_type == "weighted"
         small = bool(cp.small)
-        # arithmetic of the convolutions / correlation GEMM: "fp32" (exact fp32 MFMA, the reference's
-        # precision class), "bf16x3" (split-bf16 operands, fp32 accumulation: fp32-emulating), "bf16", or "fp16".
-        # `mixed_precision=True` selects "fp16" with the reference's scoping (autocast = fp16 around fnet, cnet and the
-        # update block only, weighted_raft.py:204-219,233-234; correlation, weight head and upsampling stay fp32-class).
-        # The shipped flow config (pytracking/optical_flow/configs/v2_SNOB_large_g05_RAFT.py) sets precision = 'bf16x3' with
-        # its error budget beside it; a reference config file without the key gets the reference's own arithmetic class.
+        # arithmetic of the convolutions / correlation products: "bf16x3" (split-bf16 operands, fp32 accumulation: fp32-EMULATING,
+        # ~2^-16 relative per product; flow EPE <= 1e-4 px against the fp32 reference at 1080p, budget 1e-3 px), "fp32" (exact fp32
+        # MFMA products, 4x slower), "bf16", "f16mx8", or "fp16".  `mixed_precision=True` selects "fp16" with the reference's scoping
+        # (autocast = fp16 around fnet, cnet and the update block only, weighted_raft.py:204-219,233-234; correlation, weight head
+        # and upsampling stay fp32-class).
+        # A flow config WITHOUT the key (an unmodified reference config) gets "bf16x3" since round 5, not exact fp32: the reference
+        # pins torch 1.8.1 (README.org:33), whose defaults on the GPUs of its time are torch.backends.cudnn.allow_tf32 = True AND
+        # torch.backends.cuda.matmul.allow_tf32 = True (the PyTorch default from 1.7 to 1.11; the reference never touches either
+        # flag) -- its own convolutions and its correlation matmul multiply 10-bit-mantissa TF32 operands on an A100.  bf16x3's
+        # 16-bit products are 64x finer than that; exact fp32 stays one key away (precision = 'fp32' / WOFT_PRECISION=fp32) and is
+        # timed in every bench line.
         for src, val in (("env WOFT_PRECISION", os.environ.get("WOFT_PRECISION")),
                          ("flow config key 'precision'", self.C.precision),
                          ("class_params.mixed_precision", "fp16" if cp.mixed_precision else None),
-                         ("built-in default (no key in the flow config: the reference's fp32)", "fp32")):
+                         ("built-in default (no key in the flow config): fp32-emulating bf16x3 -- finer than the TF32 convolutions "
+                          "the reference's torch 1.8.1 runs by default on Ampere; 'fp32' = exact products", "bf16x3")):
             if val:
                 self.precision, self.precision_source = str(val), src
                 break

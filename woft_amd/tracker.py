@@ -74,15 +74,18 @@ def _device_u8(img, copy=False):
 
 
 class _FrameUploader:
-    """Host frames (numpy, as WOFT_demo.py:61-78 / TRK:113-120 hand them to track()) -> device, without the pageable-copy
-    path of `tensor.cuda()` (2-3 ms per 1080p frame): the frame goes through one of two PINNED staging buffers in pieces --
-    woft_upload_u8: piece k's asynchronous H2D copy runs under the host memcpy of piece k + 1 -- on the stream the frame's
-    kernels are enqueued on; the two device buffers alternate, so the frame that becomes `prev_img` stays valid while the next
-    one arrives (the local stage reads frame t-1, TRK:181-184).
+    """Host frames (numpy, as WOFT_demo.py:61-78 / TRK:113-120 hand them to track()) -> one of two alternating device buffers,
+    so that the frame that becomes `prev_img` stays valid while the next one arrives (the local stage reads frame t-1,
+    TRK:181-184).  Measured on the GPU box (tools/micro/upload_probe.py, 1080p BGR = 6.2 MB): the runtime's own pageable copy
+    0.131 ms -- it pipelines its staging internally and sits at the PCIe floor (6.2 MB / ~55 GB/s = 0.11 ms) --; one memcpy into a
+    pinned buffer + one asynchronous H2D copy 0.35 ms (round 4's path: the two do not overlap); the same in 4 pipelined pieces
+    (woft_upload_u8) 0.18 ms, in 8 pieces 0.38 ms (a hipMemcpyAsync call costs ~20 us).  So the frame is copied DIRECTLY
+    (`WOFT_UPLOAD=staged`: the pinned path in 4 pieces).  Nothing of a frame's GPU work can start before its pixels are there, and
+    the caller hands over frame t only after frame t-1's result: the 0.13 ms are on the critical path (1.5 % of a 1080p frame).
     LIFETIME of what track() keeps: `tracker.prev_img` (and anything else holding the returned device frame) is valid until
     the SECOND next host-frame track() call, which reuses its buffer; a caller that wants a frame for longer clones it.  A change
     of frame shape allocates new buffers (the old prev_img stays valid, as its own tensor)."""
-    CHUNKS = int(os.environ.get("WOFT_UPLOAD_CHUNKS", "8"))
+    STAGED = os.environ.get("WOFT_UPLOAD", "direct") == "staged"
 
     def __init__(self):
         self.key, self.stage, self.dev, self.done, self.i = None, None, None, None, 0
@@ -93,16 +96,20 @@ class _FrameUploader:
             raise TypeError(f"frames and masks must be uint8, got {a.dtype}")
         key = a.shape
         if key != self.key:
-            self.stage = [torch.empty(key, dtype=torch.uint8).pin_memory() for _ in range(2)]
             self.dev = [torch.empty(key, dtype=torch.uint8, device="cuda") for _ in range(2)]
-            self.done = [torch.cuda.Event(), torch.cuda.Event()]
+            if self.STAGED:
+                self.stage = [torch.empty(key, dtype=torch.uint8).pin_memory() for _ in range(2)]
+                self.done = [torch.cuda.Event(), torch.cuda.Event()]
             self.key, self.i = key, 0
         i = self.i = self.i ^ 1
+        if not self.STAGED:
+            self.dev[i].copy_(torch.from_numpy(np.ascontiguousarray(a)))       # (returns when the host pages have been read)
+            return self.dev[i]
         self.done[i].synchronize()                   # (the copy that last read this staging buffer: two frames ago)
         if a.flags.c_contiguous and a.nbytes >= (1 << 20):
             from . import _lib
-            _lib.check(_lib.load().woft_upload_u8(a.ctypes.data, self.stage[i].data_ptr(), self.dev[i].data_ptr(), a.nbytes,
-                                                  self.CHUNKS, _lib.stream_ptr()), "woft_upload_u8")
+            _lib.check(_lib.load().woft_upload_u8(a.ctypes.data, self.stage[i].data_ptr(), self.dev[i].data_ptr(), a.nbytes, 4,
+                                                  _lib.stream_ptr()), "woft_upload_u8")
         else:                                        # (non-contiguous views, e.g. a BGR<->RGB flipped array; small frames)
             np.copyto(self.stage[i].numpy(), a)
             self.dev[i].copy_(self.stage[i], non_blocking=True)
