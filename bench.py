@@ -261,7 +261,7 @@ def main():
         # bf16-storage volume of the plain-bf16 operating point
         algo_bytes = (LOOKUP_ALGO_BYTES_PER_PIXEL if storage == "fp32" else 4 * (10 * 10 * 2 + 9 * 9 * 4)) * P
         traffic, src = None, None
-        for name in (("r04_lookup_pmc.json", "r03_lookup_pmc.json", "r02_lookup_pmc.json", "r01_lookup_pmc.json") if storage == "fp32" else ()):   # (PMC passes: fp32 volume;
+        for name in (("r05_lookup_pmc.json", "r04_lookup_pmc.json", "r03_lookup_pmc.json", "r02_lookup_pmc.json", "r01_lookup_pmc.json") if storage == "fp32" else ()):   # (PMC passes: fp32 volume;
                                                         # FETCH_SIZE is uncalibrated for the bf16 volume's 8-B-per-lane loads)
             try:
                 pmc = json.loads((ROOT / "profiles" / name).read_text())
@@ -302,7 +302,7 @@ def main():
         # HBM bytes per launch of this symbol from the committed PMC passes (tools/conv_pmc.sh; 1080p, default precision only)
         traffic, tsrc = None, None
         if p0.halo == 8 and p0._m == 135 * 240 and args.precision == "bf16x3":
-            for name in ("r04_conv_pmc.json", "r03_conv_pmc.json"):
+            for name in ("r05_conv_pmc.json", "r04_conv_pmc.json", "r03_conv_pmc.json"):
                 pth = ROOT / "profiles" / name
                 if pth.exists():
                     traffic = json.loads(pth.read_text())["traffic_bytes_per_launch"]

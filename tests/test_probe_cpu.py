@@ -27,6 +27,9 @@ def test_reference_form_config_is_recognised():
     spec, how = probe.solver_spec(m.fit_homography, make_forward_compatible(m.draw_500), m.redetected)
     assert spec == dict(reweight=0, huber_k=0.0, n_irls=0, thr=5.0, min_frac=0.2, n_draw=500), (spec, how)
     assert how.count("probed") == 3
+    m = _module(ROOT / "tests" / "configs" / "inline_irls.py")          # nested re-weighting function around IRLSq_Huber(k = 2)
+    spec, how = probe.solver_spec(m.robust_fit, make_forward_compatible(m.sobol_500), m.inlier_test)
+    assert spec == dict(reweight=2, huber_k=2.0, n_irls=5, thr=5.0, min_frac=0.2, n_draw=500), (spec, how)
 
 
 def test_presets_are_taken_by_tag_and_probe_agrees():

@@ -358,23 +358,29 @@ def test_lost_frames_keep_the_template_resident_and_defer_the_local_weights():
         assert (a[3] is None) == (b[3] is None) and (a[3] is None or np.array_equal(a[3], b[3]))
 
 
-@pytest.mark.parametrize("name,cfg", [("woft", "WOFT.py"), ("lost", "WOFT.py"), ("irls", "WOFT_IRLS.py")])
+@pytest.mark.parametrize("name,cfg", [("woft", "WOFT.py"), ("lost", "WOFT.py"), ("irls", "WOFT_IRLS.py"),
+                                      ("woft", "inline_wlsq.py"), ("lost", "inline_wlsq.py"), ("irls", "inline_irls.py")])
 @pytest.mark.parametrize("backend", ["device", "callables"])
 def test_tracker_vs_reference_tracker_runs(golden_dir, monkeypatch, name, cfg, backend):
     """SURVEY 8c fixture (7): the HIP tracker against runs of the REFERENCE's own YAOFTrackerSingleControl
     (oracle/gen_golden.py: gen_tracker -- reference configs WOFT.py / ablation_08.py, functional cv2 stub): per frame
     the homography (box corners < 1 px), lost / N_lost / global_H_success and the local-branch result, incl. the frames
-    whose re-detection test was made to fail (lost -> local flow -> recovery).  Both solver back ends."""
+    whose re-detection test was made to fail (lost -> local flow -> recovery).  Both solver back ends; the shipped presets
+    configs and configs in the reference's inline form (tests/configs/inline_*.py: recognised by woft_amd.probe)."""
     from pytracking.utils.config import load_config
     from woft_amd import presets
     g = np.load(golden_dir / "tracker_ref_runs.npz")
     monkeypatch.setenv("WOFT_FUSED", "1" if backend == "device" else "0")
     sd = synth.make_state_dict(seed=int(g["seed"]))
-    conf = load_config(ROOT / "pytracking" / "configs" / cfg)
+    inline = cfg.startswith("inline")
+    conf = load_config(ROOT / ("tests/configs" if inline else "pytracking/configs") / cfg)
     conf.flow_config.model = sd
     conf.flow_config.iters = int(g["iters"])
     tracker = conf.tracker_class(conf)
     assert (tracker._fused is not None) == (backend == "device")
+    if backend == "device":
+        assert ("probed" in tracker.solver_decision) == inline
+        assert (tracker._fused["reweight"], tracker._fused["huber_k"], tracker._fused["n_irls"]) == ((2, 2.0, 5) if name == "irls" else (0, 0.0, 0))
     mask = g[f"{name}_mask"]
     H, W = mask.shape
     tracker.init(g[f"{name}_template"], mask)
