@@ -654,3 +654,28 @@ def test_host_frames_keep_the_previous_frame_intact():
         if len(kept) >= 2:                                   # the frame before is still intact after this call
             assert torch.equal(kept[-2][0].cpu(), torch.from_numpy(kept[-2][1]))
     assert kept[0][0].data_ptr() == kept[2][0].data_ptr() != kept[1][0].data_ptr()
+
+
+def test_unweighted_estimator_and_constant_verdict_on_the_device_solver(monkeypatch):
+    """The reference's "plain LSq / always re-detected" ablation in its inline form (tests/configs/inline_plain_always.py): the probe
+    finds an UNWEIGHTED fit and a constant verdict; the device back end then skips the weight head (nobody reads a weight) and must
+    give the homographies of the callable back end, which evaluates everything and calls the config's functions."""
+    from pytracking.utils.config import load_config
+    H, W, iters = 128, 160, 4
+    sd = synth.make_state_dict(seed=7)
+    template = synth.make_template(H, W, seq_id=3)
+    frames = [synth.make_frame(template, t) for t in range(1, 5)]
+    mask = synth.make_init_mask(H, W)
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setenv("WOFT_FUSED", "1" if fused else "0")
+        conf = load_config(ROOT / "tests" / "configs" / "inline_plain_always.py")
+        conf.flow_config.model, conf.flow_config.iters = sd, iters
+        trk = conf.tracker_class(conf)
+        assert (trk._fused is not None) == fused
+        if fused:
+            assert trk._fused["weighted"] is False and trk._fused["const_verdict"] is True
+        trk.init(template, mask)
+        res[fused] = [trk.track(f) for f in frames]
+    for (Ha, ma), (Hb, mb) in zip(res[True], res[False]):
+        assert _corners_err(Ha, Hb, H, W) < 1e-2 and not ma.lost and not mb.lost and ma.global_H_success and mb.global_H_success

@@ -152,8 +152,8 @@ def _match_loss(fn):
 
 
 def probe_estimator(fn, device="cpu"):
-    """-> (reweight, huber_k, n_irls) when fn(pts_A (1,N,2), pts_B, weights (1,N)) is one pass-through call of the library's
-    weighted least-squares / IRLS estimator (reweight 0 / 1 L1 / 2 Huber), else None."""
+    """-> (reweight, huber_k, n_irls, weighted) when fn(pts_A (1,N,2), pts_B, weights (1,N)) is one pass-through call of the
+    library's least-squares / IRLS estimator (reweight 0 / 1 L1 / 2 Huber; weighted = it hands the weights on), else None."""
     g = torch.Generator().manual_seed(5)
     a = torch.rand(1, 64, 2, generator=g).to(device) * 100
     b = torch.rand(1, 64, 2, generator=g).to(device) * 100
@@ -167,15 +167,16 @@ def probe_estimator(fn, device="cpu"):
         if c["kind"] not in ("lsq", "irls") or out is not c["out"]:
             return None
         same = lambda x, y: x is y or (isinstance(x, torch.Tensor) and x.shape == y.shape and x.dtype == y.dtype and torch.equal(x, y))
-        if not (same(c["a"], a) and same(c["b"], b) and c["w"] is not None and same(c["w"], w)):
+        if not (same(c["a"], a) and same(c["b"], b) and (c["w"] is None or same(c["w"], w))):
             return None
+        weighted = c["w"] is not None          # (the reference's "plainLSq" configs hand the library weights=None: an unweighted fit)
         if c["kind"] == "lsq":
-            return 0, 0.0, 0
+            return 0, 0.0, 0, weighted
         loss = _match_loss(c["fn"])
         n_iter = c["n_iter"]
         if loss is None or not isinstance(n_iter, int) or not (0 <= n_iter <= 64):
             return None
-        return loss[0], loss[1], n_iter
+        return loss[0], loss[1], n_iter, weighted
     except Exception:
         return None
 
@@ -191,7 +192,8 @@ def _bits_f32(i):
 
 def probe_redetection(fn, device="cpu"):
     """-> (threshold_px, min_fraction) when fn(H, template_coords (2,N), cur_coords (2,N), weights) is
-    `mean(torch_proj_errors(H, cur[None], template[None]) <= threshold_px) > min_fraction`, else None."""
+    `mean(torch_proj_errors(H, cur[None], template[None]) <= threshold_px) > min_fraction`; ("const", bool) when it returns the
+    same Python bool without looking at anything; else None."""
     g = torch.Generator().manual_seed(9)
     n = 1000
     H = torch.eye(3)[None].to(device)
@@ -213,6 +215,19 @@ def probe_redetection(fn, device="cpu"):
 
     try:
         big = 3.0e38
+        # a verdict that never looks at anything (the reference's "alwayswarp" / "neverwarp" ablations: `return True` / `return False`)
+        const = set()
+        trials = [(H, tmpl, cur, w), (H * 3.0, tmpl * 0.0, cur + 1e4, torch.zeros_like(w)), (H.flip(1), cur, tmpl, torch.ones_like(w)),
+                  (H, tmpl[:, :7], cur[:, :7], w[:, :7] * 100.0), (-H, -tmpl, cur * 1e-3, 1.0 - w)]
+        for args in trials:                # (inputs of every kind: a verdict that reads ANY of them is not a constant)
+            with _Recorder(torch.zeros(1, args[1].shape[1])) as rec:
+                v = fn(*args)
+            if rec.calls or not isinstance(v, (bool, np.bool_)):
+                const = None
+                break
+            const.add(bool(v))
+        if const is not None:
+            return ("const", const.pop()) if len(const) == 1 else None
         if not verdict(torch.zeros(n)) or verdict(torch.full((n,), big)):
             return None
         # threshold: the largest float32 t with "every error = t" still a success (positive floats order like their bit patterns)
@@ -287,7 +302,7 @@ def solver_spec(estimator, subsampler, redetection, device="cpu"):
     dict(reweight, huber_k, n_irls, thr, min_frac, n_draw) or None (callable back end), and how it was decided."""
     how = []
     spec = getattr(estimator, "woft_spec", None)
-    est = (int(spec[1]), float(spec[2]), int(spec[3])) if spec is not None else probe_estimator(estimator, device)
+    est = (int(spec[1]), float(spec[2]), int(spec[3]), True) if spec is not None else probe_estimator(estimator, device)
     how.append("estimator: " + ("tagged" if spec is not None else ("probed" if est is not None else "callable")))
     spec = getattr(redetection, "woft_spec", None)
     if spec is not None:
@@ -307,4 +322,6 @@ def solver_spec(estimator, subsampler, redetection, device="cpu"):
         how.append("subsampler: " + ("tagged" if spec is not None else ("probed" if n_draw is not None else "callable")))
     if est is None or red is None or n_draw is None or n_draw > 1024:
         return None, "; ".join(how)
-    return dict(reweight=est[0], huber_k=est[1], n_irls=est[2], thr=red[0], min_frac=red[1], n_draw=n_draw), "; ".join(how)
+    const = red[1] if red[0] == "const" else None
+    return dict(reweight=est[0], huber_k=est[1], n_irls=est[2], weighted=est[3], thr=5.0 if const is not None else red[0],
+                min_frac=0.0 if const is not None else red[1], const_verdict=const, n_draw=n_draw), "; ".join(how)

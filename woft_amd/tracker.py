@@ -355,17 +355,21 @@ class YAOFTrackerSingleControl:
         F, b = self._fused, self._fused_buffers(grid[0] * grid[1])
         res = b["res"]
         ires = res.view(torch.int32)
+        weighted = F.get("weighted", True)
         if w is None and getattr(self.flower, "weights_deferred", False):
             # The correspondences the fit will read are decided by the flow alone (masks, bounds, Sobol draw): select them
             # first, then let the provider evaluate the weight head on the windows under THEIR upsampling support only and
-            # hand back the weights of exactly these pixels (exact: the head has no cross-pixel terms) -- identical fit
+            # hand back the weights of exactly these pixels (exact: the head has no cross-pixel terms) -- identical fit.
+            # An UNWEIGHTED estimator (the reference's "plainLSq" configs call the library with weights=None) reads no weight at
+            # all: the deferred head is then simply never evaluated.
             ops.tc_select(dst_xy, None, src_mask_u8, dst_valid_u8, frame_hw[0], frame_hw[1], bounds, F["sobol_u"], b["ws"],
                           b["pa"], b["pb"], b["w"], ires[12:14], grid=grid)
-            self.flower.finish_weights(b["pb"], ires[12:13], b["pb"].shape[0], out=b["w"])      # (pb: the source pixels)
+            if weighted:
+                self.flower.finish_weights(b["pb"], ires[12:13], b["pb"].shape[0], out=b["w"])      # (pb: the source pixels)
         else:
             ops.tc_select(dst_xy, w, src_mask_u8, dst_valid_u8, frame_hw[0], frame_hw[1], bounds, F["sobol_u"], b["ws"],
                           b["pa"], b["pb"], b["w"], ires[12:14], grid=grid)
-        ops.hfit(b["pa"], b["pb"], b["w"], res[0:9], ires[10:11], count=ires[12:13], reweight=F["reweight"],
+        ops.hfit(b["pa"], b["pb"], b["w"] if weighted else None, res[0:9], ires[10:11], count=ires[12:13], reweight=F["reweight"],
                  huber_k=F["huber_k"], n_irls=F["n_irls"], ws=b["fit_ws"])
         ops.inlier_frac(b["pa"], b["pb"], res[0:9], res[9:10], thr=F["thr"], count=ires[12:13])
         # the flow's single device->host read: into a pinned buffer (no staging copy, no allocation), then wait for it
@@ -381,7 +385,10 @@ class YAOFTrackerSingleControl:
         ih = host.view(torch.int32)
         if int(ih[10]) == 1:
             raise AssertionError(torch.Size([1, int(ih[12]), 2]))    # least_squares_H.py:162 (fewer than 4 points)
-        return _Fit(H=host[0:9].numpy().astype(np.float64).reshape(3, 3), success=bool(np.float32(host[9]) > np.float32(F["min_frac"])))   # (astype: a copy; the verdict in float32, as torch compares a float32 mean with a Python float)
+        verdict = F.get("const_verdict")       # (a re-detection test that is `return True` / `return False`: the reference's ablations)
+        if verdict is None:
+            verdict = bool(np.float32(host[9]) > np.float32(F["min_frac"]))
+        return _Fit(H=host[0:9].numpy().astype(np.float64).reshape(3, 3), success=bool(verdict))   # (astype: a copy; the verdict in float32, as torch compares a float32 mean with a Python float)
 
     def _solve_callables(self, src_xy, dst_xy, w, grid, frame_hw, src_mask_u8, dst_valid_u8, bounds, judge):
         C = self.C
