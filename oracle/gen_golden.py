@@ -379,7 +379,20 @@ def gen_tracker():
             conf.H_estimator = lambda a, b, w: torch.Tensor(est(a.as_subclass(FakeCuda), b, w))
         run("irls", "ablation_08.py", 5, [1, 2, 3], mutate=cuda_flag)
     out["iters"], out["seed"] = iters, 7
-    np.savez_compressed(GOLD / "tracker_ref_runs.npz", **out)
+    if os.environ.get("GOLDEN_TRACKER_ABLATIONS") != "only":
+        np.savez_compressed(GOLD / "tracker_ref_runs.npz", **out)
+    # (d) round 5: two of the reference's ablation configs whose callables the HIP tracker's probe maps onto its device solver
+    #     -- the UNWEIGHTED least-squares fit (..._noreliableinl_plainLSq.py hands the library weights=None) and a re-detection test
+    #     that is `return False` (..._neverwarp_wLSq.py: every frame takes the frame-to-frame branch, TRK:171-207)
+    out2 = {}
+    out, keep = out2, out
+    with tempfile.TemporaryDirectory() as td:
+        model = os.path.join(td, "sd.pth")
+        torch.save(sd, model)
+        run("plain", "YAOFT_single_control_repRAFT_sub500_noreliableinl_plainLSq.py", 6, [1, 2, 3])
+        run("never", "YAOFT_single_control_repRAFT_sub500_neverwarp_wLSq.py", 7, [1, 2, 3])
+    out2["iters"], out2["seed"] = iters, 7
+    np.savez_compressed(GOLD / "tracker_ref_runs_ablations.npz", **out2)
 
 
 def demo_frame(i):

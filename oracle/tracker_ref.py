@@ -105,6 +105,8 @@ class TrackerRef:
         self._n_tracked = 0
         if estimator == "qr":
             self.H_estimator = hfit_ref.find_homography_nonhomogeneous_QR
+        elif estimator == "plain_qr":          # configs/..._plainLSq.py:16-20: the library called with weights=None
+            self.H_estimator = lambda a, b, w: hfit_ref.find_homography_nonhomogeneous_QR(a, b, None)
         elif estimator == "irls_huber2":
             self.H_estimator = lambda a, b, w: hfit_ref.find_homography_IRLSq_QR(
                 a, b, w, reweighting_fn=lambda r: hfit_ref.IRLSq_Huber(r, k=2))

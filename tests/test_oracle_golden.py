@@ -191,6 +191,28 @@ def test_tracker_state_machine_vs_reference_runs(golden_dir, name, estimator):
             assert _box_err(m.H_local_cur2init, g[f"{name}_Hlocal_{i}"], H, W) < 0.02
 
 
+@torch.no_grad()
+@pytest.mark.parametrize("name,estimator,fail_all", [("plain", "plain_qr", False), ("never", "qr", True)])
+def test_tracker_state_machine_vs_reference_ablation_runs(golden_dir, name, estimator, fail_all):
+    """Runs of the reference's tracker with two of its ablation configs (gen_tracker (d)): the unweighted fit of
+    ..._noreliableinl_plainLSq.py and the `return False` re-detection test of ..._neverwarp_wLSq.py (every frame takes the
+    frame-to-frame branch)."""
+    g = np.load(golden_dir / "tracker_ref_runs_ablations.npz")
+    sd = synth.make_state_dict(seed=int(g["seed"]))
+    ref = tracker_ref.TrackerRef(sd, iters=int(g["iters"]), estimator=estimator)
+    n = len(g[f"{name}_frames"])
+    ref.force_fail = tuple(range(n)) if fail_all else ()
+    ref.init(g[f"{name}_template"], g[f"{name}_mask"])
+    H, W = g[f"{name}_mask"].shape
+    for i, f in enumerate(g[f"{name}_frames"]):
+        Hc, m = ref.track(f)
+        lost, n_lost, ok, has_local = g[f"{name}_meta"][i]
+        assert (m.lost, m.N_lost, bool(m.global_H_success)) == (bool(lost), int(n_lost), bool(ok)), (name, i)
+        assert bool(lost) == fail_all
+        assert _box_err(Hc, g[f"{name}_H"][i], H, W) < 0.02, (name, i)
+        assert hasattr(m, "H_local_cur2init") == bool(has_local)
+
+
 DEGENERATE = ["constant", "constant_vs_texture", "saturated", "identical"]
 
 

@@ -679,3 +679,34 @@ def test_unweighted_estimator_and_constant_verdict_on_the_device_solver(monkeypa
         res[fused] = [trk.track(f) for f in frames]
     for (Ha, ma), (Hb, mb) in zip(res[True], res[False]):
         assert _corners_err(Ha, Hb, H, W) < 1e-2 and not ma.lost and not mb.lost and ma.global_H_success and mb.global_H_success
+
+
+@pytest.mark.parametrize("name", ["plain", "never"])
+@pytest.mark.parametrize("backend", ["device", "callables"])
+def test_tracker_vs_reference_tracker_ablation_runs(golden_dir, monkeypatch, name, backend):
+    """Runs of the REFERENCE's tracker with its plain-LSq and never-re-detected ablation configs (gen_tracker (d)) against the
+    HIP tracker driven by the same configs in inline form (tests/configs/inline_ablations.py): on the device back end the probe
+    maps them to an unweighted fit / a constant verdict, on the callable back end the functions themselves run."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("inline_ablations", str(ROOT / "tests" / "configs" / "inline_ablations.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    g = np.load(golden_dir / "tracker_ref_runs_ablations.npz")
+    monkeypatch.setenv("WOFT_FUSED", "1" if backend == "device" else "0")
+    conf = mod.get_config(name)
+    conf.flow_config.model, conf.flow_config.iters = synth.make_state_dict(seed=int(g["seed"])), int(g["iters"])
+    tracker = conf.tracker_class(conf)
+    assert (tracker._fused is not None) == (backend == "device")
+    if backend == "device":
+        assert tracker._fused["weighted"] == (name != "plain") and tracker._fused["const_verdict"] == (None if name == "plain" else False)
+    mask = g[f"{name}_mask"]
+    H, W = mask.shape
+    tracker.init(g[f"{name}_template"], mask)
+    for i, f in enumerate(g[f"{name}_frames"]):
+        Hg, mg = tracker.track(f)
+        lost, n_lost, ok, has_local = g[f"{name}_meta"][i]
+        assert (mg.lost, mg.N_lost, bool(mg.global_H_success)) == (bool(lost), int(n_lost), bool(ok)), (name, i)
+        assert _corners_err(Hg, g[f"{name}_H"][i], H, W) < 1.0, (name, i)
+        assert hasattr(mg, "H_local_cur2init") == bool(has_local)
+        if has_local:
+            assert _corners_err(mg.H_local_cur2init, g[f"{name}_Hlocal_{i}"], H, W) < 1.0
