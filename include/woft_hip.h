@@ -95,7 +95,7 @@ typedef struct woft_conv_params {
     int32_t ldo1;
     float* stat_sum;       /* optional [2*ceil(M/BM)][cout_pad] per-wave-row partial sums of y */
     float* stat_sq;        /*          ... and of y*y  (InstanceNorm statistics)               */
-    int32_t tile_m, tile_n;/* block tile: 128 or 64 each                                       */
+    int32_t tile_m, tile_n;/* block tile: 128 or 64 each (halo 16: tile_n 256; flat: 128)      */
     int32_t halo;          /* 0: gather A per tap.  Split-bf16 precisions, stride 1, 3x3/1x5/5x1 only:
                               input halo of the output tile resident in LDS for all taps; tile_m ignored:
                               1 = 8x16 px, 4 = 4x16 px, 2 = one 9x9 image per workgroup (weight-head patches;
@@ -104,7 +104,13 @@ typedef struct woft_conv_params {
                               7 = the encoders' first layer (extractor.py:127-129: 7x7, stride 2, pad 3) on its own kernel:
                               flat packing of an NHWC4 image (cs0 = 4, taps_y = 7, taps_x = 1, cin_pad = 32), split-bf16
                               precisions, cout_pad % 64 == 0, 8x16 output pixels x 64 channels per tile, statistics rows
-                              indexed by those tiles; results bit-identical to halo = 0 */
+                              indexed by those tiles; results bit-identical to halo = 0
+                              16 = wide 1x1 / stride-1 layers (update.py:89 convc1, extractor.py:166 conv2) on the streamed
+                              GEMM kernel (conv_1x1.hip): 64 pixels x tile_n = 256 columns per workgroup, the activations
+                              read and converted once per layer, weights from wgt_frag (taps = 1); also stride-1 flat
+                              layers (flat != 0, cin_pad = 32, taps_x = 1, pad_y = taps_y / 2; update.py:91 convf1) with
+                              tile_n = 128, K chunks = tap rows; split-bf16 precisions, cout_pad % tile_n == 0, no
+                              statistics / in_norm; bit-identical to halo = 0.  woft_conv2d_pair takes two such layers */
     int32_t in_norm;       /* halo != 0 only: 0 = use in0 as is; 1 / 2 = in0 holds a RAW conv output whose
                               InstanceNorm is applied while loading (extractor.py:44-47: x = (x - in_mean[c]) *
                               in_rstd[c], 2: followed by ReLU), zero padding applied after it; in1 must be NULL */
@@ -151,11 +157,12 @@ typedef struct woft_conv_params {
 
 int woft_conv2d(const woft_conv_params* p, void* stream);
 /* Two INDEPENDENT layers in one launch: both must select the same kernel instance -- same precision (split-bf16 only),
- * halo mode (0 = per-tap kernel, any tap shapes; 8 / 12 = register-streamed kernel, equal tap shape), tile_m / tile_n;
- * no InstanceNorm statistics.  The first layer's workgroups are dispatched first.  Results are those of two woft_conv2d
- * calls; what is saved is one kernel boundary and the partly empty last round of workgroups of each launch (the motion
- * encoder's correlation and flow branches, update.py:91-95, are independent until `conv` joins them).  WOFT_EINVAL when the
- * layers do not share a kernel: the caller launches them one after the other. */
+ * halo mode (0 = per-tap kernel, any tap shapes; 8 / 12 = register-streamed kernel, equal tap shape; 16 = streamed GEMM
+ * kernel: a 1x1 and a flat layer, or two of a kind, each with its own tile_n), tile_m / tile_n; no InstanceNorm
+ * statistics.  The first layer's workgroups are dispatched first.  Results are those of two woft_conv2d calls; what is
+ * saved is one kernel boundary and the partly empty last round of workgroups of each launch (the motion encoder's
+ * correlation and flow branches, update.py:91-95, are independent until `conv` joins them).  WOFT_EINVAL when the layers
+ * do not share a kernel: the caller launches them one after the other. */
 int woft_conv2d_pair(const woft_conv_params* a, const woft_conv_params* b, void* stream);
 /* Host frame -> device (the plugin API hands track() a numpy frame per call: TRK:57-62, WOFT_demo.py:61-78).  `src` is
  * pageable host memory, `pinned` a page-locked staging buffer and `dev` the device buffer, `bytes` each.  The frame is moved in

@@ -448,6 +448,83 @@ def test_conv_flat_first_layer(ops, precision, tol):
 
 
 @pytest.mark.parametrize("precision", ["bf16x3", "bf16", "fp16"])
+@pytest.mark.parametrize("cin,cout,h,w,two", [(324, 256, 135, 240, False), (324, 256, 17, 25, False), (128, 256, 9, 7, False),
+                                              (96, 512, 33, 20, False), (160, 256, 24, 40, True), (32, 256, 8, 8, False)])
+def test_conv_1x1_kernel_equals_gather_kernel(ops, cin, cout, h, w, two, precision):
+    """Wide 1x1 layers on the streamed GEMM kernel (conv_1x1.hip, halo 16: 64 pixels x 256 columns per workgroup, activations
+    converted once, weights global -> registers) against the per-tap gather kernel: every output bit-identical (update.py:89
+    convc1 with its 324 -> 352 padded lookup rows, extractor.py:166); ragged pixel tiles, 1-11 chunks (fewer than the loader's
+    prefetch depth included), two-source input, bias + ReLU at a channel offset."""
+    x = _rand(1, cin, h, w, seed=70)
+    wt = _rand(cout, cin, 1, 1, seed=71, scale=1.0 / math.sqrt(cin))
+    b = _rand(cout, seed=72, scale=0.1)
+    if two:                                   # channels [0, 96) from one tensor, [96, 160) from a second one (32-channel aligned split)
+        pc = ops.pack_conv(wt, b)
+        xa = ops.act_from_nchw(x[:, :96], cs=96)
+        xb = ops.act_from_nchw(x[:, 96:], cs=64)
+        kw = dict(x2=xb, c_split=96)
+    else:
+        pc = ops.pack_conv(wt, b)
+        xa = ops.act_from_nchw(x, cs=ops._round_up(cin, 32))
+        kw = {}
+    outs = []
+    for halo in (None, 0):
+        out = ops.new_act(1, h, w, cout + 8, cs=cout + 8, zero=True)
+        cp = ops.conv_params(xa, pc, out, co_off=8, epi=ops._lib.EPI_RELU, precision=precision, halo=halo, **kw)
+        assert cp.halo == (16 if halo is None else 0), cp.halo
+        ops.run_conv(cp)
+        outs.append(out.t.clone())
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1]), f"max diff {float((outs[0] - outs[1]).abs().max()):.3e}"
+    assert float(outs[0][:, :8].abs().max()) == 0.0
+    ref = F.relu(F.conv2d(x, wt, b))
+    _close(outs[0][:, 8:].reshape(1, h, w, cout).permute(0, 3, 1, 2), ref, {"bf16x3": 1e-4, "bf16": 3e-2, "fp16": 4e-3}[precision],
+           what="1x1 vs torch")
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16", "fp16"])
+@pytest.mark.parametrize("h,w,k,flat_cs", [(135, 240, 7, 4), (17, 25, 7, 4), (8, 8, 7, 4), (5, 3, 7, 4), (24, 40, 3, 8)])
+def test_flat_conv_on_the_1x1_kernel_and_shared_launch(ops, h, w, k, flat_cs, precision):
+    """The motion encoder's convf1 (update.py:91: 7x7 on the 2-channel flow, "flat" packing: a K chunk = one tap row of the NHWC
+    image) on the streamed GEMM kernel (conv_1x1.hip, halo 16): bit-identical to the per-tap gather kernel -- frames narrower than
+    the kernel, rows / columns outside the image, a second flat form (3 taps x 8-channel pixels) -- and, with a wide 1x1 layer, in
+    ONE launch (woft_conv2d_pair, either order of the two layers) bit-identical to the two separate launches."""
+    cin = 2 if flat_cs == 4 else 7
+    x = _rand(1, cin, h, w, seed=80)
+    wt = _rand(128, cin, k, k, seed=81, scale=1.0 / math.sqrt(cin * k * k))
+    b = _rand(128, seed=82, scale=0.1)
+    pc = ops.pack_conv(wt, b, padding=k // 2, flat_cs=flat_cs)
+    xa = ops.act_from_nchw(x, cs=flat_cs)
+    outs, cps = [], []
+    for halo in (None, 0):
+        out = ops.new_act(1, h, w, 128, zero=True)
+        cp = ops.conv_params(xa, pc, out, epi=ops._lib.EPI_RELU, precision=precision, halo=halo)
+        assert cp.halo == (16 if halo is None else 0), cp.halo
+        ops.run_conv(cp)
+        outs.append(out)
+        cps.append(cp)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0].t, outs[1].t), f"max diff {float((outs[0].t - outs[1].t).abs().max()):.3e}"
+    _close(outs[0].nchw(), F.relu(F.conv2d(x, wt, b, padding=k // 2)), {"bf16x3": 1e-4, "bf16": 3e-2, "fp16": 4e-3}[precision], what="flat vs torch")
+    # one launch with a wide 1x1 layer on the same pixels
+    y = _rand(1, 96, h, w, seed=83)
+    pw = ops.pack_conv(_rand(256, 96, 1, 1, seed=84, scale=0.1), _rand(256, seed=85, scale=0.1))
+    ya = ops.act_from_nchw(y, cs=96)
+    wide = ops.new_act(1, h, w, 256, zero=True)
+    cw = ops.conv_params(ya, pw, wide, epi=ops._lib.EPI_RELU, precision=precision)
+    assert cw.halo == 16 and ops.pair_ok(cw, cps[0]) and not ops.pair_ok(cw, cps[1])
+    ops.run_conv(cw)
+    torch.cuda.synchronize()
+    want = (wide.t.clone(), outs[0].t.clone())
+    for a, bb in ((cw, cps[0]), (cps[0], cw)):
+        wide.t.fill_(float("nan"))
+        outs[0].t.fill_(float("nan"))
+        ops.run_conv_pair(a, bb)
+        torch.cuda.synchronize()
+        assert torch.equal(wide.t, want[0]) and torch.equal(outs[0].t, want[1]), (a is cw)
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16", "fp16"])
 @pytest.mark.parametrize("h,w", [(75, 91), (64, 128), (272, 480), (13, 9)])
 def test_conv_stem_kernel_equals_gather_kernel(ops, h, w, precision):
     """The encoders' 7x7 / stride-2 first layer on its own kernel (conv_stem.hip, halo 7: 8x16-pixel tiles, patch in LDS

@@ -14,7 +14,7 @@ tn = int(sys.argv[3]) if len(sys.argv) > 3 else None
 prec = sys.argv[4] if len(sys.argv) > 4 else "bf16x3"
 hf, wf = int(os.environ.get("HF", 135)), int(os.environ.get("WF", 240))
 cin, x2c, cout, kh, kw = {"zr": (128, 128, 256, 1, 5), "q": (128, 128, 128, 5, 1), "fh1": (128, 0, 256, 3, 3),
-                          "c2": (256, 0, 192, 3, 3), "e64": (64, 0, 64, 3, 3), "e96": (96, 0, 96, 3, 3)}[case]
+                          "c2": (256, 0, 192, 3, 3), "c1": (352, 0, 256, 1, 1), "f1": (128, 0, 256, 1, 1), "e64": (64, 0, 64, 3, 3), "e96": (96, 0, 96, 3, 3)}[case]
 wt = torch.randn(cout, cin + x2c, kh, kw) * 0.05
 pc = ops.pack_conv(wt, torch.randn(cout) * 0.1, padding=(kh // 2, kw // 2))
 x = ops.new_act(1, hf, wf, cin)
@@ -32,6 +32,8 @@ p = ops.conv_params(x, pc, out, x2=x2, c_split=cin if x2c else 0, epi=_lib.EPI_L
 import os
 if os.environ.get("NOSTORE"):
     p.out_w = -12345
+if os.environ.get("ABL"):            # conv_1x1.hip: 1 no activation loads, 2 no weight loads, 4 no stores
+    p.out_w = -12350 - int(os.environ["ABL"])
 stamps = None
 if os.environ.get("STAMPS"):
     stamps = torch.zeros(4096 * 32, dtype=torch.int64, device="cuda")

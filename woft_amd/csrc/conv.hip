@@ -1003,6 +1003,7 @@ int launch_conv(const woft_conv_params& p, const woft_conv_params* second, hipSt
 // conv_regb.hip, the part of this precision
 int WOFT_CAT2(woft_conv_regb_launch_p, WOFT_ONLY_PREC)(const woft_conv_params& p, const woft_conv_params* second, void* stream);
 int woft_conv_stem_launch(const woft_conv_params& p, void* stream);                                     // conv_stem.hip
+int woft_conv_1x1_launch(const woft_conv_params& p, const woft_conv_params* second, void* stream);      // conv_1x1.hip
 int woft_conv_dispatch_p1(const woft_conv_params& p, const woft_conv_params* second, void* stream);
 int woft_conv_dispatch_p2(const woft_conv_params& p, const woft_conv_params* second, void* stream);
 int woft_conv_dispatch_p3(const woft_conv_params& p, const woft_conv_params* second, void* stream);
@@ -1025,7 +1026,8 @@ static int conv_check(const woft_conv_params& p) {
     if (p.n_img <= 0 || p.h <= 0 || p.w <= 0 || p.ho <= 0 || p.wo <= 0 || p.taps_y <= 0 || p.taps_x <= 0 ||
         p.stride <= 0 || p.cout <= 0)
         return WOFT_EINVAL;
-    if ((p.tile_m != 64 && p.tile_m != 128) || (p.tile_n != 64 && p.tile_n != 128)) return WOFT_EINVAL;
+    if ((p.tile_m != 64 && p.tile_m != 128) || (p.tile_n != 64 && p.tile_n != 128 && !(p.halo == 16 && p.tile_n == 256)))
+        return WOFT_EINVAL;
     if (p.cout_pad % p.tile_n != 0 || p.cout > p.cout_pad) return WOFT_EINVAL;
     if (p.epi < 0 || p.epi > WOFT_EPI_FLOWHEAD) return WOFT_EINVAL;
     if (p.epi == WOFT_EPI_FLOWHEAD && (p.halo != 8 || p.precision == 0 || p.stat_sum != nullptr || p.bias_map != nullptr ||
@@ -1068,10 +1070,13 @@ int WOFT_CAT2(woft_conv_dispatch_p, WOFT_ONLY_PREC)(const woft_conv_params& p, c
     hipStream_t s = (hipStream_t)stream;
     if (second != nullptr && (second->precision != p.precision || second->halo != p.halo ||
                               (p.halo == 0 && second->tile_m != p.tile_m) ||
-                              second->tile_n != p.tile_n || p.precision == 0 || (p.halo != 0 && p.halo != 8 && p.halo != 12)))
+                              (second->tile_n != p.tile_n && p.halo != 16) || p.precision == 0 ||
+                              (p.halo != 0 && p.halo != 8 && p.halo != 12 && p.halo != 16)))
         return WOFT_EINVAL;
     if (p.halo == 7)                      // the encoders' 7x7 / stride-2 first layer on its own kernel (conv_stem.hip)
         return second != nullptr ? WOFT_EINVAL : woft_conv_stem_launch(p, stream);
+    if (p.halo == 16)                     // wide 1x1 layers on the streamed GEMM kernel (conv_1x1.hip)
+        return p.precision == 0 ? WOFT_EINVAL : woft_conv_1x1_launch(p, second, stream);
     for (const woft_conv_params* q : {&p, second}) {
         if (q == nullptr || q->halo == 0) continue;
         // LDS-halo kernels: split-bf16 precisions, stride 1, 3x3 / 1x5 / 5x1 taps, non-flat, same-size output

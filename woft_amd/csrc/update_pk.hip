@@ -40,9 +40,9 @@ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 template <int T>
 constexpr int smem_of() {
     int m = 0;
-    m = cmax(m, RegbGeom<8, 16, 3, 3, 2, T>::SMEM_ELEMS); m = cmax(m, RegbGeom<8, 16, 3, 3, 1, T>::SMEM_ELEMS); m = cmax(m, RegbGeom<4, 16, 3, 3, 1, T>::SMEM_ELEMS);
-    m = cmax(m, RegbGeom<8, 16, 1, 5, 2, T>::SMEM_ELEMS); m = cmax(m, RegbGeom<8, 16, 1, 5, 1, T>::SMEM_ELEMS); m = cmax(m, RegbGeom<4, 16, 1, 5, 1, T>::SMEM_ELEMS);
-    m = cmax(m, RegbGeom<8, 16, 5, 1, 2, T>::SMEM_ELEMS); m = cmax(m, RegbGeom<8, 16, 5, 1, 1, T>::SMEM_ELEMS); m = cmax(m, RegbGeom<4, 16, 5, 1, 1, T>::SMEM_ELEMS);
+    m = cmax(m, RegbGeom<8, 16, 3, 3, 2, T>::SMEM_ELEMS); m = cmax(m, RegbGeom<8, 16, 3, 3, 1, T>::SMEM_ELEMS);
+    m = cmax(m, RegbGeom<8, 16, 1, 5, 1, T>::SMEM_ELEMS); m = cmax(m, RegbGeom<4, 16, 1, 5, 1, T>::SMEM_ELEMS);
+    m = cmax(m, RegbGeom<8, 16, 5, 1, 1, T>::SMEM_ELEMS); m = cmax(m, RegbGeom<4, 16, 5, 1, 1, T>::SMEM_ELEMS);
     return m;
 }
 constexpr int PK_SMEM = smem_of<MAIN_TERMS>();
@@ -159,11 +159,8 @@ __global__ __launch_bounds__(256, 2) void update_pk_kernel(const woft_pk_layer* 
     case K: regb_tile<TY, 16, KY, KX, WM, T, NB, D, 2>(p, m_tile, n_tile, smem, nullptr); break
             PK_CASE(0, 8, 3, 3, 2, MAIN_TERMS, 3, 2);
             PK_CASE(1, 8, 3, 3, 1, MAIN_TERMS, 3, 2);
-            PK_CASE(2, 4, 3, 3, 1, MAIN_TERMS, 3, 2);
-            PK_CASE(3, 8, 1, 5, 2, MAIN_TERMS, 5, 3);
             PK_CASE(4, 8, 1, 5, 1, MAIN_TERMS, 5, 3);
             PK_CASE(5, 4, 1, 5, 1, MAIN_TERMS, 5, 3);
-            PK_CASE(6, 8, 5, 1, 2, MAIN_TERMS, 5, 3);
             PK_CASE(7, 8, 5, 1, 1, MAIN_TERMS, 5, 3);
             PK_CASE(8, 4, 5, 1, 1, MAIN_TERMS, 5, 3);
 #undef PK_CASE
@@ -205,7 +202,11 @@ int kind_of(const woft_conv_params& c) {
     else if (c.halo == 8 && c.tile_n == 128) shape = 1;
     else if (c.halo == 12 && c.tile_n == 128) shape = 2;
     else return -1;
-    return taps * 3 + shape;
+    // the tile forms the layer chooser (woft_amd/ops.py) gives the update block: 3x3 on 8x16 x 64 | 128, 1x5 / 5x1 on 8x16 x 128 and
+    // 4x16 x 128 -- the other three combinations (3x3 on 4x16 tiles, 1x5 / 5x1 on 64-column tiles) are not instantiated (each
+    // instance is a minute of this unit's compile time, the longest of the build)
+    const int kind = taps * 3 + shape;
+    return (kind == 2 || kind == 3 || kind == 6) ? -1 : kind;
 }
 
 }  // namespace

@@ -633,11 +633,6 @@ class _Plan:
             hd = sp.hdim
             hS = (self.hB, self.hB1)
             h_in, h_out = (self.net0 if first else hS[1 - par]), hS[par]
-            # (developer knob WOFT_PK_TN=64: 64-column tiles for every layer -- twice the work items of the 128-column layers,
-            #  so that a tile's producers are a full round of the resident workgroups ahead of it in the queue)
-            tn = int(os.environ.get("WOFT_PK_TN", "0"))
-            if tn:
-                cp = lambda *a, **kw: self._cp(*a, halo=8, tiles=(128, tn), **kw)
             L = [cp(self.fl1, e.convf2, self.cf, co_off=192, epi=EPI.EPI_RELU),
                  cp(self.c1, e.convc2, self.cf, co_off=0, epi=EPI.EPI_RELU),
                  cp(self.cf, e.convm, self.xbuf, co_off=sp.cdim, epi=EPI.EPI_RELU)]
@@ -648,8 +643,7 @@ class _Plan:
                             out1=rb, bias_map=gz))
                 L.append(cp(rb, e.q_dyn[k], ho, x2=self.xbuf, x2_off=sp.cdim, c_split=hd, epi=EPI.EPI_GRU_Q, e0=hi, e1=zb,
                             bias_map=gq))
-            L.append(ops.flowhead_params(h_out, e.fh1, self.fh_part, e.fh2_frag, precision=self.prec,
-                                         **(dict(halo=8, tiles=(128, tn)) if tn else {})))
+            L.append(ops.flowhead_params(h_out, e.fh1, self.fh_part, e.fh2_frag, precision=self.prec))
             if last:
                 L.append(cp(h_out, e.mk1, self.mk, epi=EPI.EPI_RELU))
             try:

@@ -216,6 +216,7 @@ USE_HALO = os.environ.get("WOFT_HALO", "1") != "0"
 USE_REGB = os.environ.get("WOFT_REGB", "1") != "0"
 REGB_TY4 = os.environ.get("WOFT_REGB_TY4", "1") != "0"
 USE_STEM = os.environ.get("WOFT_STEM", "1") != "0"        # 7x7 / stride-2 first layer on conv_stem.hip (0: gather kernel)
+USE_1X1 = os.environ.get("WOFT_1X1", "1") != "0"          # wide 1x1 layers on conv_1x1.hip (0: gather kernel)
 HALO_TILES = {1: (8, 16, 1), 2: (9, 9, 1), 4: (4, 16, 1), 7: (8, 16, 1), 8: (8, 16, 1), 12: (4, 16, 1)}     # (TY, TX, images per workgroup)
 HALO_MIN_BLOCKS = int(os.environ.get("WOFT_HALO_MIN_BLOCKS", "400"))
 WH_HALO = int(os.environ.get("WOFT_WH_HALO", "2"))
@@ -334,6 +335,23 @@ def conv_params(x, pc, out, co_off=0, epi=_lib.EPI_LINEAR, x2=None, c_split=0, e
     if REGB_TY4 and auto_halo and halo == 8 and p.tile_n == 64 and pc.cout_pad % 128 == 0 and _round_up(p.cout, 64) == pc.cout_pad \
             and (pc.taps_y, pc.taps_x) in ((1, 5), (5, 1)):
         halo, p.tile_n = 12, 128
+    # wide 1x1 / stride-1 layers (convc1: 324 -> 256; the encoders' closing 128 -> 256): the streamed GEMM kernel (conv_1x1.hip, halo
+    # 16) -- 64 pixels x all 256 columns per workgroup, activations read and converted once per layer; bit-identical to the gather kernel
+    if USE_1X1 and auto_halo and halo == 0 and tiles is None and stats is None and not in_norm and wh0 is None and p.precision != 0 \
+            and not pc.flat and (pc.taps_y, pc.taps_x, pc.stride, pc.pad_y, pc.pad_x) == (1, 1, 1, 0, 0) and (ho, wo) == (x.h, x.w) \
+            and pc.cout_pad % 256 == 0 and _round_up(p.cout, 256) == pc.cout_pad:
+        # (layers that only fill 128-column tiles gain nothing: mask head conv2 256 -> 576 61.5 vs 59.9 us, 128 -> 128 13.8 vs 14.0)
+        halo = 16
+        p.tile_m, p.tile_n, p.cout_pad = 64, 256, pc.cout_pad
+        tm = 64
+    # ... and the flat-packed 7x7 conv on the flow (convf1, update.py:91) on the same kernel (128 columns per workgroup, K chunks = tap
+    # rows), so that it keeps sharing convc1's launch (pair_ok)
+    if USE_1X1 and auto_halo and halo == 0 and tiles is None and stats is None and not in_norm and wh0 is None and p.precision != 0 \
+            and pc.flat and x2 is None and (pc.taps_x, pc.stride, pc.cin_pad) == (1, 1, 32) and 2 * pc.pad_y + 1 == pc.taps_y \
+            and (ho, wo) == (x.h, x.w) and pc.cout_pad % 128 == 0 and _round_up(p.cout, 128) == pc.cout_pad:
+        halo = 16
+        p.tile_m, p.tile_n, p.cout_pad = 64, 128, pc.cout_pad
+        tm = 64
     p.halo = halo
     p.wgt_frag = None
     p.wgt_mx = None
@@ -371,6 +389,8 @@ def conv_params(x, pc, out, co_off=0, epi=_lib.EPI_LINEAR, x2=None, c_split=0, e
         if p.tile_n == 128 and pc.cout_pad % 128 != 0:
             p.tile_n = 64
         p.cout_pad = pc.cout_pad if stats is not None else _round_up(p.cout, p.tile_n)
+    if halo == 16:
+        p.wgt_frag = ptr(pc.frag(2 if p.precision == 1 else 1, f16=p.precision == 3))
     p.bias_map, p.ld_bias_map = (ptr(bias_map.t), bias_map.cs) if bias_map is not None else (None, 0)
     p.in_norm, p.in_mean, p.in_rstd = 0, None, None
     if in_norm and halo in (1, 4) and (pc.taps_y, pc.taps_x) == (3, 3):   # (instantiated for the 3x3 pixel tiles)
@@ -445,7 +465,11 @@ def flow_head_gather(part, n_planes, h, w, bias2, delta, coords, flow4=None, flo
 
 def pair_ok(a, b):
     """True when woft_conv2d_pair takes the two layers in one launch (they select the same kernel instance)."""
-    if a.precision == 0 or a.precision != b.precision or a.halo != b.halo or a.tile_n != b.tile_n:
+    if a.precision == 0 or a.precision != b.precision or a.halo != b.halo:
+        return False
+    if a.halo == 16:                                          # (conv_1x1.hip: a kernel whose workgroups pick their layer's tile form)
+        return not (a.stat_sum or b.stat_sum)
+    if a.tile_n != b.tile_n:
         return False
     if a.halo == 0 and a.tile_m != b.tile_m:                  # (the pixel-tile kernels ignore tile_m)
         return False
