@@ -304,7 +304,13 @@ def test_two_layers_in_one_launch(ops, h, w, precision):
         cf = ops.new_act(1, h, w, 256, zero=True)
         pa = ops.conv_params(corr, c1, a1, epi=1, precision=precision)
         pb = ops.conv_params(flow, f1, b1, epi=1, precision=precision)
-        assert ops.pair_ok(pa, pb) and pa.halo == 0
+        assert ops.pair_ok(pa, pb) and pa.halo == pb.halo == 16          # (the streamed GEMM kernel, conv_1x1.hip)
+        if paired:                                                       # ... and the same pair on the gather kernel: one launch too
+            a0, b0 = ops.new_act(1, h, w, 256, zero=True), ops.new_act(1, h, w, 128, zero=True)
+            pa0 = ops.conv_params(corr, c1, a0, epi=1, precision=precision, halo=0)
+            pb0 = ops.conv_params(flow, f1, b0, epi=1, precision=precision, halo=0)
+            assert ops.pair_ok(pa0, pb0) and not ops.pair_ok(pa, pb0)
+            ops.run_conv_pair(pa0, pb0)
         if paired:
             ops.run_conv_pair(pa, pb)
         else:
@@ -320,6 +326,8 @@ def test_two_layers_in_one_launch(ops, h, w, precision):
             ops.run_conv(qb)
         torch.cuda.synchronize()
         res[paired] = (a1.t.clone(), b1.t.clone(), cf.t.clone())
+        if paired:
+            assert torch.equal(a0.t, a1.t) and torch.equal(b0.t, b1.t)
         assert not ops.pair_ok(pa, qa)
         if paired:
             with pytest.raises(Exception):
