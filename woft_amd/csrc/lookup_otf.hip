@@ -22,7 +22,9 @@
 
 // Measured and NOT kept (rounds 2-3, tools/bench_lookup_otf.py; the code is in the git history): DMA pieces issued one per k
 // sub-step instead of four in a row after the barrier (88.3 vs 82.0 us); the window drop of chunk c - 1 spread under the MFMAs of
-// chunk c (81.3 vs 81.9 us, +-0 in a frame); a fully unrolled sampling loop (+-0, spills at 256 registers).
+// chunk c (81.3 vs 81.9 us, +-0 in a frame); a fully unrolled sampling loop (+-0, spills at 256 registers).  Round 5: the three
+// `pos / bw` per chunk and lane as a float multiply with the box width's reciprocal + one correction step (84.3-85.0 vs 82.0-82.8 us:
+// the divisor is wave-uniform, so the compiler already hoists its reciprocal out of the chunk loop and a use costs a v_mul_hi_u32).
 #define OTF_SAMPLE_UNROLL 3      // unroll factor of the sampling loop
 
 namespace {
