@@ -219,7 +219,7 @@ def main():
     torch.cuda.synchronize()
     # the kernel with the largest share of a frame (profiles/r03_bench_kernel_stats_bf16x3.csv): the 3x3 / 64-column
     # instance of the register-streamed-weights conv kernel = the motion encoder's three 3x3 layers (update.py:83,85,86)
-    ROOF_TAGS = ("convc2", "convf2", "convc2+convf2", "convm", "pk")
+    ROOF_TAGS = ("convc2", "convf2", "convc2+convf2", "convm")
     # (HIP events are stream-ordered barriers: the volume-free lookup, not this mode's roofline kernel, is timed in isolation
     #  below -- 'lookup_otf_by_flow_field' -- instead of inside the timed region)
     plan.lookup_events = [] if corr_mode == "volume" else None
@@ -316,32 +316,6 @@ def main():
                 "note": "frac prices the launches' own 2*M*K*N products against the dense peak of the MFMA type used; the "
                         "issue fraction also counts the 3 bf16 MFMAs per fp32-emulating product and tile padding"}
 
-    def pk_roofline(evs):
-        """The persistent update-block kernel (csrc/update_pk.hip; round 5): convf2, convc2, convm, z|r and q of both GRU half
-        steps and the flow head's conv of one refinement iteration (+ the mask head's first conv in the last one) in ONE launch --
-        by far the symbol with the largest share of a frame.  HIP events around its launches on every EVENT_EVERY-th frame of the
-        timed region: achieved = sum over the launches of their layers' 2*M*K*N / sum of their times; matrix-core bound."""
-        tot_ms, tot_fl, tot_issued, items = 0.0, 0.0, 0.0, 0
-        for s_, e_, tab in evs:
-            tot_ms += s_.elapsed_time(e_)
-            tot_fl += sum(2.0 * q._m * q.taps_y * q.taps_x * q.cin_pad * q.cout for q in tab.layers)
-            # issued: the rows / columns the tiles really multiply (tile padding) x matrix-pipe passes per product of each layer
-            tot_issued += sum(2.0 * (q._m_tiles * (64 if q.halo == 12 else 128)) * q.taps_y * q.taps_x * q.cin_pad * q.cout_pad
-                              * {1: 3, 2: 1, 3: 1, 4: 2}[q.precision] for q in tab.layers)
-            items += tab.n_items
-        t = tot_ms * 1e-3
-        n = max(len(evs), 1)
-        tab0 = evs[0][2]
-        return {"bound": "mfma", "kernel": f"update_pk_kernel (persistent: {len(tab0.layers)} register-streamed conv layers of a refinement "
-                                           f"iteration, {tab0.n_items} tile work items per launch on {tab0.layers[0]._m} pixels)",
-                "achieved": tot_fl / t / 1e12, "peak": mfma_peak, "unit": "TFLOP/s", "frac": tot_fl / t / 1e12 / mfma_peak,
-                "traffic": None, "matrix_core_issue_frac": tot_issued / t / 1e12 / mfma_peak,
-                "algorithmic_flops_per_launch": tot_fl / n, "mfma_terms_per_product": terms, "avg_launch_ms": tot_ms / n,
-                "launches_timed": len(evs), "work_items_per_launch": items / n,
-                "layers": [f"{q.taps_y}x{q.taps_x} {q.cin_pad}->{q.cout} tile {4 if q.halo == 12 else 8}x16x{q.tile_n}" for q in tab0.layers],
-                "note": "frac prices the launches' own 2*M*K*N products against the dense bf16 MFMA peak; the issue fraction also "
-                        "counts the matrix-pipe passes per fp32-emulating product (3 in bf16x3) and tile padding"}
-
     def wh_roofline(evs, layer, P):
         """Weight-head 3x3 128->128 layer on 9x9 lookup windows (weighted_raft.py:337-340; the first 5->128 layer is
         computed inside the same launch), matrix-core bound; HIP events around its launches in the timed region."""
@@ -387,8 +361,7 @@ def main():
                    "weight_head": wh_desc,
                    "template_cache": not args.no_template_cache, "weights": "synthetic seed 7 (reference key set)",
                    "frames_resident_in_hbm": True, "precision": args.precision, "precision_source": precision_source,
-                   "update_block": ("one persistent launch per refinement iteration (woft_update_pk) + lookup + convc1|convf1"
-                                    if any(v is not None for v in getattr(plan, "_pk", {}).values()) else "one launch per layer"),
+                   "update_block": "one launch per layer (9 launches per refinement iteration)",
                    "solver": getattr(tracker, "solver_decision", None)},
         "lost_frames": n_lost, "hbm_allocated_peak_gb": peak_gb, "tracks_gathered": [int(tracks.shape[0]), int(tracks.shape[1])],
         # one entry per rank (a straggler shows here; `value` uses the slowest rank): ms per step inside the same barriers,
@@ -405,16 +378,11 @@ def main():
     if len(same) > 1:                    # (another resolution / precision picked different kernels: keep the largest layer)
         layers = {k_: v_ for k_, v_ in layers.items() if k_.startswith("convc2")}
     have_conv = bool(layers) and any(conv_events.get(t) for t in layers)
-    have_pk = bool(conv_events.get("pk"))
     if corr_mode == "volume":
         # the lookup reads the volume: the named HBM-roofline kernel, measured live in the timed region
         out["roofline"] = lookup_roofline(events, plan.P, tracker.flower.engine.volume_storage)
-        if have_pk:
-            out["roofline_mfma"] = pk_roofline(conv_events["pk"])
-        elif have_conv:
+        if have_conv:
             out["roofline_mfma"] = conv_roofline(conv_events, layers)
-    elif have_pk:
-        out["roofline"] = pk_roofline(conv_events["pk"])
     elif have_conv:
         # volume-free correlation: no HBM-bound lookup on the path; the dominant kernel is a matrix-core conv
         # (the volume lookup's HBM roofline is measured in the 'alt_corr' pass below -> 'roofline_lookup')
@@ -591,17 +559,6 @@ def main():
             del trk
             drop()
         out["reference_format_config"] = ref_form
-        # ---- A/B of the update block's launch structure in this run: the other mode (persistent launch <-> one launch per layer)
-        from woft_amd import engine as _eng
-        saved_pk = _eng.UPDATE_PK
-        _eng.UPDATE_PK = "0" if saved_pk != "0" else "1"
-        r, trk, pl, _ = side_run(max(K2, 20), check_tracks=True)
-        r["update_block"] = ("one persistent launch per iteration" if any(v is not None for v in getattr(pl, "_pk", {}).values())
-                             else "one launch per layer")
-        out["alt_update_block"] = r
-        _eng.UPDATE_PK = saved_pk
-        del trk, pl
-        drop()
         # ---- like-for-like ladder: the flow operator doing the reference's FULL work (weight head on every pixel, as
         # WeightedRAFT.forward evaluates it) in the fp32-emulating arithmetic of the headline and in the reference's own
         # arithmetic class (exact fp32 MFMA products); same sequence, same step count each
@@ -719,7 +676,6 @@ def main():
     cfgd["fps_reference_form_config_unmodified"] = r1(g(out, "reference_format_config", "no_precision_key", "frames_per_s"))
     cfgd["fps_reference_form_config_bf16x3"] = r1(g(out, "reference_format_config", "precision_bf16x3", "frames_per_s"))
     cfgd["fps_reference_form_config_fp32"] = r1(g(out, "reference_format_config", "precision_fp32", "frames_per_s"))
-    cfgd["fps_update_block_other_mode"] = r1(g(out, "alt_update_block", "frames_per_s"))
     cfgd["fps_f16mx8"] = r1(g(out, "alt_precisions", "f16mx8", "frames_per_s"))     # (opt-in: 2 matrix-pipe passes per product on the 3x3 layers)
     cfgd["epe_mean_px"] = g(out, "flow_epe_vs_cpu_oracle", "mean_px")
     cfgd["epe_gate_passed"] = out["epe_gate"]["passed"]
@@ -730,4 +686,13 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    _clean = False
+    try:
+        main()
+        _clean = True
+    except SystemExit as ex:             # (rank 0's EPE-gate exit: the other ranks are already waiting at the last barrier)
+        _clean = True
+        raise
+    finally:
+        from woft_amd import dist as _wdist
+        _wdist.finalize(clean=_clean)

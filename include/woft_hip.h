@@ -26,7 +26,7 @@ extern "C" {
 
 /* ABI / build identification: returns 10000*major + 100*minor + patch. */
 int woft_abi_version(void);
-/* sizeof(woft_conv_params) (which = 0) / woft_lookup_params (1) / woft_lookup_otf_params (2) / woft_pk_layer (3): layout check for FFI mirrors. */
+/* sizeof(woft_conv_params) (which = 0) / woft_lookup_params (1) / woft_lookup_otf_params (2): layout check for FFI mirrors. */
 int woft_sizeof(int which);
 /* developer knob for the micro-benchmarks in tools/ (ablation bits of the correlation GEMM, key 2); 0 in production. */
 int woft_set_tuning(int key, int value);
@@ -172,51 +172,6 @@ int woft_conv2d_pair(const woft_conv_params* a, const woft_conv_params* b, void*
  * Returns after the last piece is ENQUEUED: `pinned` may be rewritten once the stream has passed this point (the caller records an
  * event).  (Measured alternative, what the Python host now does by default: the runtime's own pageable copy, 0.13 ms.) */
 int woft_upload_u8(const void* src, void* pinned, void* dev, int64_t bytes, int32_t n_chunks, void* stream);
-/* ---------------------------------------------------------------------------------------
- * Persistent update-block kernel (round 5): the register-streamed conv layers of ONE refinement iteration
- * (BasicUpdateBlock, update.py:89-97 motion encoder convc2 / convf2 / conv, :45-60 SepConvGRU z|r and q of both half
- * steps, :10-17 flow head conv1 (+ mask.0 in the last iteration, update.py:118-125)) as ONE launch instead of seven.
- * 2 x (number of CUs) resident workgroups pull (layer, tile) work items from a device-side queue in dependency order; a
- * tile of layer k + 1 starts as soon as the tiles of layer k under its input halo are complete (per-tile completion
- * counters: write-through output stores -> counter increment; the consumer polls its producers' counters, then one
- * agent-scope acquire) -- no launch ramp, tail or write-back between layers, and the two workgroups of a CU drift out of
- * phase (one's epilogue beside the other's main loop).  Every tile is computed by the code of woft_conv2d's halo 8 / 12
- * kernel (same products, same order): results are bit-identical to the seven launches.  Precision 1 (bf16x3) layers only.
- * MEASURED SLOWER than the launches it replaces (0.53-0.61 vs 0.41 ms per iteration at 1/8 of 1080p; DESIGN.md section 4, round
- * 5, tools/pk_timeline.py): kept as an opt-in path (WOFT_UPDATE_PK=1) and as the instrument of that measurement.
- *
- * The caller describes the layers in launch order in a table of woft_pk_layer (built on the host, copied to the device
- * once per resolution); `state` is a zero-initialised device buffer of woft_update_pk_state_bytes() that the kernel
- * leaves zeroed again (head of the queue, exit count, an error word, the counters).
- * No buffer may be written by two layers of one table (the dependency counters order readers after writers, not
- * writers after readers): the host keeps the two half steps' z / r*h tensors and consecutive iterations' states apart. */
-#define WOFT_PK_MAX_DEPS 3
-#define WOFT_PK_MAX_LAYERS 16
-typedef struct woft_pk_layer {
-    woft_conv_params conv;          /* the layer exactly as woft_conv2d takes it: halo 8 or 12, n_img 1, no statistics / in_norm */
-    int32_t n_dep;                  /* producer layers (earlier entries of the table) this layer's tiles wait for */
-    int32_t dep[WOFT_PK_MAX_DEPS];  /* ... their table indices */
-    int32_t dep_hy[WOFT_PK_MAX_DEPS], dep_hx[WOFT_PK_MAX_DEPS];   /* how many pixels beyond its own output tile this layer reads of
-                                       that producer's output (conv input: pad_y / pad_x; epilogue operand only: 0) */
-    /* filled by woft_update_pk_prepare: */
-    int32_t kind;                   /* kernel instance (tap shape x tile shape) */
-    int32_t ty;                     /* tile rows: 8 (halo 8) or 4 (halo 12); tiles are ty x 16 pixels */
-    int32_t n_ty, n_tx, n_nt;       /* pixel-tile rows / columns, column tiles */
-    int32_t item0;                  /* first work item of the layer (items: layer-major, column tile fastest) */
-    int32_t cnt_off;                /* first completion counter of the layer in `state` (one per pixel tile) */
-} woft_pk_layer;
-/* Validates the table (n <= WOFT_PK_MAX_LAYERS entries, HOST memory) and fills the derived fields.  WOFT_EINVAL when a layer
- * is not one the persistent kernel instantiates (the caller launches the layers one by one instead). */
-int woft_update_pk_prepare(woft_pk_layer* table, int32_t n);
-/* Bytes of the state buffer for a prepared table (zero it once; the kernel restores the zeros). */
-int64_t woft_update_pk_state_bytes(const woft_pk_layer* table, int32_t n);
-/* One launch.  table_dev: the prepared table copied to the device; table_host: the same table (host), read for the grid
- * geometry only.  state[2] != 0 after the launch: a workgroup gave up waiting (give-up code = 1 + its work item; never
- * expected -- the kernel cannot deadlock while its resident workgroups run; results are then invalid and `state` must be
- * zeroed by the caller).  options (developer A/B knobs): bit 0 = no acquire fence after the dependency wait; bit 2 = every second
- * workgroup starts ~20 us late.  state[4..5] = device address of a [items][4] uint64 timeline buffer or 0 (tools/pk_timeline.py). */
-int woft_update_pk(const woft_pk_layer* table_dev, const woft_pk_layer* table_host, int32_t n, uint32_t* state, int32_t options,
-                   void* stream);
 /* fp32 array (n % 4 == 0) -> bf16 planes hi = bf16(x), lo = bf16(x - hi) (lo may be NULL): the
  * split form of a dynamic B operand (fmap2 in the correlation GEMM). */
 int woft_split_bf16(const float* x, int64_t n, void* hi, void* lo, void* stream);

@@ -6,6 +6,9 @@ from pathlib import Path
 import numpy as np
 
 
+_IMAGE_SUFFIXES = {".jpg", ".jpeg", ".png"}
+
+
 def _imread_bgr(path):
     try:
         import cv2
@@ -20,8 +23,7 @@ class GeneralVideoCapture:
         self.image_inputs = Path(path).is_dir()
         if self.image_inputs:
             self.path = path
-            self.images = sorted(f for f in next(os.walk(path))[2]
-                                 if os.path.splitext(f)[1].lower() in [".jpg", ".png", ".jpeg"])
+            self.images = sorted(q.name for q in Path(path).iterdir() if q.is_file() and q.suffix.lower() in _IMAGE_SUFFIXES)
             if reverse:
                 self.images = self.images[::-1]
             self.i = 0

@@ -469,7 +469,6 @@ def test_launch_merging_switches_are_bit_identical(monkeypatch, small):
     for pair, fold in ((True, True), (False, True), (True, False), (False, False)):
         monkeypatch.setattr(engine, "PAIR_BRANCHES", pair)
         monkeypatch.setattr(engine, "FOLD_GATHER", fold)
-        monkeypatch.setattr(engine, "UPDATE_PK", "0")        # (the per-layer launch programs: the persistent kernel has its own test)
         c = _flow_config(sd, 5, raft_type=rt, padding_mode="nopad", small=small, precision="bf16x3")
         prov = c.of_class(c)
         flow, w = prov.compute_flow(a, b, mode="flow")

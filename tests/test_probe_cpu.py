@@ -6,6 +6,11 @@ from pathlib import Path
 import numpy as np
 import torch
 
+# one test below loads config files that live in the READ-ONLY reference tree: no __pycache__ may be written next to them (SURVEY
+# line 67) -- switched off for the whole interpreter before the first import machinery runs on such a file, and the loader below
+# compiles from source without touching any cache
+sys.dont_write_bytecode = True
+
 ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
 
@@ -20,6 +25,16 @@ def _module(path):
     m = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(m)
     return m
+
+
+def _load_config_without_cache(path):
+    """pytracking.utils.config.load_config's semantics (module.get_config()) for a file in a read-only tree: the source is compiled
+    in memory, nothing is read from or written to a __pycache__ directory."""
+    import types
+    m = types.ModuleType("tracker_config")
+    m.__file__ = str(path)
+    exec(compile(Path(path).read_text(), str(path), "exec"), m.__dict__)
+    return m.get_config()
 
 
 def test_reference_form_config_is_recognised():
@@ -118,8 +133,9 @@ def test_the_references_own_config_files_through_the_shim():
     ref = Path("/root/reference/pytracking/configs")
     if not ref.exists():
         pytest.skip("reference tree not present on this machine")
-    from pytracking.utils.config import load_config
     from woft_amd.tracker import YAOFTrackerSingleControl
+    load_config = _load_config_without_cache
+    before = sorted(str(q) for q in ref.rglob("*.pyc"))
     want = {"WOFT.py": (0, True, None), "WOFT_downscale_2x.py": (0, True, None), "ablation_08.py": (2, True, None),
             "YAOFT_single_control_repRAFT_sub500_noreliableinl_wIRLSq.py": (2, True, None),
             "YAOFT_single_control_repRAFT_sub500_noreliableinl_plainLSq.py": (0, False, None),
@@ -133,3 +149,4 @@ def test_the_references_own_config_files_through_the_shim():
         assert (spec["reweight"], spec["weighted"], spec["const_verdict"], spec["n_draw"]) == (rew, weighted, const, 500), (name, spec)
         if const is None:
             assert (spec["thr"], spec["min_frac"]) == (5.0, 0.2)
+    assert sorted(str(q) for q in ref.rglob("*.pyc")) == before, "the test wrote bytecode into the read-only reference tree"

@@ -35,17 +35,6 @@ class ConvParams(C.Structure):
     ]
 
 
-PK_MAX_DEPS, PK_MAX_LAYERS = 3, 16
-
-
-class PkLayer(C.Structure):
-    """woft_pk_layer (include/woft_hip.h): one layer of the persistent update-block kernel's table."""
-    _fields_ = [
-        ("conv", ConvParams), ("n_dep", i32), ("dep", i32 * PK_MAX_DEPS), ("dep_hy", i32 * PK_MAX_DEPS), ("dep_hx", i32 * PK_MAX_DEPS),
-        ("kind", i32), ("ty", i32), ("n_ty", i32), ("n_tx", i32), ("n_nt", i32), ("item0", i32), ("cnt_off", i32),
-    ]
-
-
 class LookupParams(C.Structure):
     _fields_ = [
         ("vol", vp * 4), ("ht", i32 * 4), ("wt", i32 * 4), ("plane", i64 * 4),
@@ -71,9 +60,6 @@ _SIGS = {
     "woft_conv2d": (i32, [C.POINTER(ConvParams), vp]),
     "woft_conv2d_pair": (i32, [C.POINTER(ConvParams), C.POINTER(ConvParams), vp]),
     "woft_upload_u8": (i32, [vp, vp, vp, i64, i32, vp]),
-    "woft_update_pk_prepare": (i32, [C.POINTER(PkLayer), i32]),
-    "woft_update_pk_state_bytes": (i64, [C.POINTER(PkLayer), i32]),
-    "woft_update_pk": (i32, [vp, C.POINTER(PkLayer), i32, vp, i32, vp]),
     "woft_split_bf16": (i32, [vp, i64, vp, vp, vp]),
     "woft_split_bf16_lines": (i32, [vp, i64, vp, vp]),
     "woft_flow_to_tc": (i32, [vp, vp, i32, i32, vp, vp, i32, vp]),
@@ -132,7 +118,7 @@ def load():
         fn = getattr(lib, name)           # AttributeError if a declared symbol is not exported
         fn.restype, fn.argtypes = res, args
     if lib.woft_sizeof(0) != C.sizeof(ConvParams) or lib.woft_sizeof(1) != C.sizeof(LookupParams) \
-            or lib.woft_sizeof(2) != C.sizeof(LookupOtfParams) or lib.woft_sizeof(3) != C.sizeof(PkLayer):
+            or lib.woft_sizeof(2) != C.sizeof(LookupOtfParams):
         raise WoftHipError("ctypes mirror of woft_conv_params / woft_lookup_params is out of sync with the library")
     _lib = lib
     return lib

@@ -70,10 +70,10 @@ def build(force=False, verbose=True):
         u.update(src.read_bytes())
         u.update(" ".join(FLAGS + extra).encode())
         return u.hexdigest()
-    # longest compiles first (measured on this image: update_pk.hip ~6 min on one core, a part of conv.hip ~4, of conv_regb.hip ~2,
+    # longest compiles first (measured on this image: a part of conv.hip ~4 min on one core, of conv_regb.hip ~2,
     # conv_1x1.hip ~2, everything else under a minute); at most `jobs` compilers at a time
     jobs = int(os.environ.get("WOFT_BUILD_JOBS", os.cpu_count() or 4))
-    weight = {"update_pk.hip": 60, "conv.hip": 8, "conv_regb.hip": 6, "conv_1x1.hip": 20}
+    weight = {"conv.hip": 8, "conv_regb.hip": 6, "conv_1x1.hip": 20}
     units.sort(key=lambda u: -(u[0].stat().st_size * weight.get(u[0].name, 1)))
     pending, running = [], []
     for src, obj, extra in units:

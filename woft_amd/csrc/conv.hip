@@ -1023,6 +1023,9 @@ static int conv_check(const woft_conv_params& p) {
     if (p.cs0 % 4 != 0 || (p.in1 != nullptr && p.cs1 % 4 != 0)) return WOFT_EINVAL;
     if (p.flat && (p.taps_x != 1 || p.in1 != nullptr || (p.cs0 != 4 && p.cs0 != 8 && p.cs0 != 16 && p.cs0 != 32)))
         return WOFT_EINVAL;
+    // a pixel's K range must lie inside its own row of the tensor (the last pixel would otherwise be read past the allocation)
+    if (!p.flat && (p.cs0 < (p.in1 != nullptr ? p.c_split : p.cin_pad) || (p.in1 != nullptr && p.cs1 < p.cin_pad - p.c_split)))
+        return WOFT_EINVAL;
     if (p.n_img <= 0 || p.h <= 0 || p.w <= 0 || p.ho <= 0 || p.wo <= 0 || p.taps_y <= 0 || p.taps_x <= 0 ||
         p.stride <= 0 || p.cout <= 0)
         return WOFT_EINVAL;

@@ -120,33 +120,10 @@ typedef __attribute__((address_space(1))) f32x4 g_f32x4;
 typedef __attribute__((address_space(1))) float g_f32;
 struct GPtr {
     uint64_t a;
-#ifdef WOFT_STORE_WT
-    bool plain = false;    // developer ablation (woft_conv_params.out_w == -12347): ordinary stores -- NOT a valid hand-off, timing only
-#endif
     __device__ __forceinline__ bool null() const { return a == 0; }
     __device__ __forceinline__ f32x4 ld4(int64_t off) const { return *(const g_f32x4*)(a + 4 * (uint64_t)off); }
-#ifdef WOFT_STORE_WT
-    // Write-through (sc1) stores: the persistent update-block kernel (update_pk.hip) hands its output tiles to workgroups on
-    // other CUs / XCDs INSIDE the launch -- payload stored through to memory, then a flag (guide: Guideline 16, form R1; a
-    // release fence instead would write back the whole XCD L2, 6-8 us per 64 KB tile).  Buffer-descriptor form, 32-bit byte
-    // offsets: the launcher checks that every output is smaller than 2 GiB.
-    __device__ __forceinline__ void st4(int64_t off, f32x4 v) const {
-        typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-        if (plain) { *(g_f32x4*)(a + 4 * (uint64_t)off) = v; return; }
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v),
-                                               __builtin_amdgcn_make_buffer_rsrc((void*)a, 0, 0x7fffffff, 0x00020000),
-                                               (int)(4 * off), 0, 16);
-    }
-    __device__ __forceinline__ void st1(int64_t off, float v) const {
-        if (plain) { *(g_f32*)(a + 4 * (uint64_t)off) = v; return; }
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v),
-                                              __builtin_amdgcn_make_buffer_rsrc((void*)a, 0, 0x7fffffff, 0x00020000),
-                                              (int)(4 * off), 0, 16);
-    }
-#else
     __device__ __forceinline__ void st4(int64_t off, f32x4 v) const { *(g_f32x4*)(a + 4 * (uint64_t)off) = v; }
     __device__ __forceinline__ void st1(int64_t off, float v) const { *(g_f32*)(a + 4 * (uint64_t)off) = v; }
-#endif
 };
 __device__ __forceinline__ GPtr keep_gptr(const void* p) { return GPtr{keep_sgpr((uint64_t)(uintptr_t)p)}; }
 
@@ -338,9 +315,6 @@ __device__ __forceinline__ void conv_epilogue_t(const PT& p, f32x16 (&acc)[TM][T
     a.ld_bias_map = keep_sgpr(p.ld_bias_map); a.co_off = keep_sgpr(p.co_off); a.cout = keep_sgpr(p.cout);
     a.split = keep_sgpr(p.split); a.epi = keep_sgpr(p.epi); a.alpha = keep_sgpr(p.alpha);
     a.no_store = p.out_w == -12345;                            // (micro-benchmark ablation, tools/bench_conv.py)
-#ifdef WOFT_STORE_WT
-    a.out.plain = a.out1.plain = p.out_w == -12347;
-#endif
     a.fast = p.precision != 0 && p.out_w != -12346;            // (-12346: developer ablation, library gate functions)
     const GPtr stat_sum = keep_gptr(p.stat_sum), stat_sq = keep_gptr(p.stat_sq);
     const int cout_pad = keep_sgpr(p.cout_pad);

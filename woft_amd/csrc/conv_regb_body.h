@@ -1,7 +1,6 @@
 // LDS-halo convolution with the WEIGHT operand streamed global -> registers (no LDS stage, no LDS-DMA, no per-tap
-// barrier): the body of ONE output tile as a device function, shared by conv_regb_kernel (conv_regb.hip: one tile per
-// workgroup, one layer -- or two independent ones -- per launch) and by the persistent update-block kernel
-// (update_pk.hip: resident workgroups pulling (layer, tile) work items of a whole refinement iteration from a queue).
+// barrier): the body of ONE output tile as a device function, called by conv_regb_kernel (conv_regb.hip: one tile per
+// workgroup, one layer -- or two independent ones -- per launch).
 // Same GEMM formulation, arithmetic modes and epilogues as conv_halo_bf16_kernel (conv.hip): stride 1, taps 3x3 / 1x5 /
 // 5x1, split-bf16 operands on v_mfma_f32_32x32x16_bf16, fp32 accumulation.
 //
@@ -70,9 +69,9 @@ struct RegbGeom {
 // smem: RegbGeom<...>::SMEM_ELEMS bf16 elements, 16-byte aligned; all 256 threads of the workgroup call together.
 // The caller guarantees that the tile's inputs are visible to this CU and may reuse smem after the call returns (the body ends
 // with the epilogue's last store ISSUED, not completed).
-// ParamsT: woft_conv_params -- or the same struct behind a constant-address-space reference (update_pk.hip: the layer table lives in
-// device memory; only address space 4 makes its fields SCALAR loads -- through a plain pointer the compiler reads them with
-// vector loads, base addresses end up in VGPRs and the epilogue's "+s" operands fail with 'illegal VGPR to SGPR copy').
+// ParamsT: woft_conv_params -- or the same struct behind a constant-address-space reference (a table in device memory: only
+// address space 4 makes its fields SCALAR loads -- through a plain pointer the compiler reads them with vector loads, base
+// addresses end up in VGPRs and the epilogue's "+s" operands fail with 'illegal VGPR to SGPR copy').
 template <int TY, int TX, int KY, int KX, int WM, int TERMS, int NBUF, int DIST, int AD, bool IL = true, class ParamsT = woft_conv_params>
 __device__ __forceinline__ void regb_tile(const ParamsT& p, const int m_tile, const int n_tile, __bf16* smem,
                                           unsigned long long* stamps) {
@@ -531,9 +530,6 @@ __device__ __forceinline__ void regb_tile(const ParamsT& p, const int m_tile, co
         const uint64_t dbase = (uint64_t)(uintptr_t)(p.out + (int64_t)n_tile * M * p.ldo);   // wave-uniform; said explicitly (an
         woft::GPtr dst{((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(dbase >> 32)) << 32) |   // "+s" asm
                        (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)dbase)};   // operand here: 'illegal VGPR to SGPR copy')
-#ifdef WOFT_STORE_WT
-        dst.plain = p.out_w == -12347;
-#endif
         for (int idx = tid; idx < G::BM * (SLD / 4); idx += 256) {
             const int row = idx / (SLD / 4), c4 = (idx - row * (SLD / 4)) * 4;
             const int wmr = row / WROWS, lr = row - wmr * WROWS;

@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void feature_pyramid_kernel(const PyrArgs a) {
 
 }  // namespace
 
-extern "C" int woft_abi_version(void) { return 10000 * 0 + 100 * 2 + 0; }
+extern "C" int woft_abi_version(void) { return 10000 * 0 + 100 * 3 + 0; }
 
 extern "C" int woft_preprocess_bgr_u8(const uint8_t* img, int32_t h, int32_t w, float* out, int32_t hp, int32_t wp,
                                       int32_t pad_top, int32_t pad_left, void* stream) {
@@ -318,7 +318,6 @@ extern "C" int woft_sizeof(int which) {
     if (which == 0) return (int)sizeof(woft_conv_params);
     if (which == 1) return (int)sizeof(woft_lookup_params);
     if (which == 2) return (int)sizeof(woft_lookup_otf_params);
-    if (which == 3) return (int)sizeof(woft_pk_layer);
     return -1;
 }
 

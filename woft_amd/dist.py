@@ -137,3 +137,17 @@ def max_over_ranks(value, device=None):
 def barrier():
     if dist.is_initialized():
         dist.barrier()
+
+
+def finalize(clean=True):
+    """End of a multi-rank job: every rank meets at one last barrier (rank 0 prints the result line after the others have
+    finished their timed work; nobody may tear the communicator down under a collective that is still running) and then
+    destroys the process group -- without it RCCL warns at interpreter exit at best and hangs in its watchdog at worst.
+    clean=False (an exception is propagating on this rank): no barrier, the group is only destroyed."""
+    if not dist.is_initialized():
+        return
+    try:
+        if clean:
+            dist.barrier()
+    finally:
+        dist.destroy_process_group()

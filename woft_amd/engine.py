@@ -33,12 +33,6 @@ FUSE_FLOWHEAD = os.environ.get("WOFT_FUSE_FLOWHEAD", "1") != "0"
 # motion encoder: the correlation branch (convc1 -> convc2) and the flow branch (convf1 -> convf2) are independent until
 # `conv` joins them (update.py:89-97): first layers in one launch, second layers in one launch (woft_conv2d_pair)
 PAIR_BRANCHES = os.environ.get("WOFT_PAIR", "1") != "0"
-# The seven register-streamed conv layers of a refinement iteration (convc2 | convf2, convm, z|r and q of both GRU half steps, the flow
-# head's conv) as ONE persistent launch: resident workgroups pull (layer, tile) work items from a queue and hand tiles to each other
-# through per-tile ready counters (csrc/update_pk.hip; bf16x3).  Bit-identical to the per-layer launches (tested) and OPT-IN
-# (WOFT_UPDATE_PK=1): measured 0.53-0.61 ms per iteration against 0.41 ms for the seven launches (DESIGN section 4, round 5:
-# the launches' ramps and tails were never idle matrix time -- the workgroups that remain run faster --, the hand-offs are).
-UPDATE_PK = os.environ.get("WOFT_UPDATE_PK", "0")
 PYRAMID_ONE_LAUNCH = os.environ.get("WOFT_PYRAMID", "1") != "0"    # target pyramid (pool + split of all levels) in one launch
 # the flow-head gather of iteration k runs inside the lookup launch of iteration k + 1 (volume-free lookup; the last
 # iteration's as its own launch): one launch fewer per iteration, same operations in the same order (0: always its own launch)
@@ -314,7 +308,6 @@ class _Plan:
         self.rh = new_act(1, hf, wf, sp.hdim, zero=True)
         self.hA = new_act(1, hf, wf, sp.hdim, zero=True)
         self.hB = new_act(1, hf, wf, sp.hdim, zero=True)
-        self._pk = {}              # persistent update-block launch: {(first, parity, last): program} (UPDATE_PK)
         self.fh = new_act(1, hf, wf, 128 if sp.small else 256, zero=True)
         self.fh_part = None        # flow head folded into one conv launch: per-pixel partial products of its second conv
         self.delta = new_act(1, hf, wf, 2, cs=4, zero=True)
@@ -371,13 +364,12 @@ class _Plan:
                 if not eng.wh_flat0:                     # first kernel wider than 3: 32-channel rows instead of the flat 8
                     self.x32 = new_act(P, n, n, 5, cs=32, zero=True)
                     x = self.x32
-                cmax = max(_ru(pc.cout, 4) for pc in eng.wh_layers)
-                # (zeroed once: a layer writes its cout channels only, and the next layer's K chunks read whole 32-channel groups
-                #  against zero weights -- what a wider earlier layer left behind is finite, never NaN)
-                bufs = [new_act(P, n, n, cmax, cs=_ru(cmax, 32), zero=True), new_act(P, n, n, cmax, cs=_ru(cmax, 32), zero=True)]
+                # one activation per layer, zeroed once: a layer writes its cout channels only, so the pad channels that the next
+                # layer's 32-channel K chunks (and woft_wh_reduce) read against zero weights stay exact zeros for ever -- a buffer
+                # shared between layers of different widths would show a narrower layer what a wider one left behind (0 * inf = NaN)
                 self.prog_wh = []
-                for i, pc in enumerate(eng.wh_layers):
-                    out = Act(bufs[i % 2].t, P, n, n, pc.cout)
+                for pc in eng.wh_layers:
+                    out = new_act(P, n, n, pc.cout, cs=_ru(_ru(pc.cout, 4), 32), zero=True)
                     self.prog_wh.append(cpw(x, pc, out, epi=EPI.EPI_RELU))
                     x = out
                 self.wh_last = x
@@ -612,75 +604,11 @@ class _Plan:
             prog += [("conv", cp(self.fh, e.fh2, self.delta)), ("coords", None)]
         return prog
 
-    # ---- the same iteration with its seven register-streamed conv layers in ONE persistent launch (UPDATE_PK) ----
-    def _pk_program(self, first, par, last):
-        """Launch list of one refinement iteration: lookup (+ the previous iteration's flow-head gather), convc1 | convf1 on the
-        per-tap kernel, then ONE woft_update_pk launch for convf2, convc2, convm, z|r / q of both half steps and the flow head's
-        conv (+ the mask head's first conv when `last`).  Same layers, same structs as _iter_program -- except that nothing is
-        written twice inside the launch (its tile counters order readers after writers only): the two half steps have their own
-        z / r*h tensors and the GRU state alternates between two buffers (par = iteration parity; the first iteration reads net0).
-        -> None when the persistent kernel does not take this plan (then the per-layer launches run)."""
-        key = (bool(first), int(par), bool(last))
-        if key in self._pk:
-            return self._pk[key]
-        e, cp, sp = self.eng, self._cp, self.eng.spec
-        prog = None
-        ok = (not sp.small and self.prec == "bf16x3" and self._fold is not None and self.gate_bias is not None and len(e.zr) == 2
-              and self.fh_part is not None and ops.USE_REGB and ops.USE_HALO)
-        if ok:
-            if not hasattr(self, "hB1"):
-                self.hB1, self.zbuf2, self.rh2 = (new_act(1, self.hf, self.wf, sp.hdim, zero=True) for _ in range(3))
-            hd = sp.hdim
-            hS = (self.hB, self.hB1)
-            h_in, h_out = (self.net0 if first else hS[1 - par]), hS[par]
-            L = [cp(self.fl1, e.convf2, self.cf, co_off=192, epi=EPI.EPI_RELU),
-                 cp(self.c1, e.convc2, self.cf, co_off=0, epi=EPI.EPI_RELU),
-                 cp(self.cf, e.convm, self.xbuf, co_off=sp.cdim, epi=EPI.EPI_RELU)]
-            states, zr_bufs = [h_in, self.hA, h_out], [(self.zbuf, self.rh), (self.zbuf2, self.rh2)]
-            for k in range(2):
-                hi, ho, (gz, gq), (zb, rb) = states[k], states[k + 1], self.gate_bias[k], zr_bufs[k]
-                L.append(cp(hi, e.zr_dyn[k], zb, x2=self.xbuf, x2_off=sp.cdim, c_split=hd, epi=EPI.EPI_GRU_ZR, split=hd, e0=hi,
-                            out1=rb, bias_map=gz))
-                L.append(cp(rb, e.q_dyn[k], ho, x2=self.xbuf, x2_off=sp.cdim, c_split=hd, epi=EPI.EPI_GRU_Q, e0=hi, e1=zb,
-                            bias_map=gq))
-            L.append(ops.flowhead_params(h_out, e.fh1, self.fh_part, e.fh2_frag, precision=self.prec))
-            if last:
-                L.append(cp(h_out, e.mk1, self.mk, epi=EPI.EPI_RELU))
-            try:
-                table = ops.PkTable(L, options=int(os.environ.get("WOFT_PK_OPTIONS", "0"))) if all(q is not None for q in L) else None
-            except _lib.WoftHipError:
-                table = None
-            if table is not None:
-                head = [ent for ent in self.prog_iter if ent[0] in ("conv", "conv2") and len(ent) > 2
-                        and ent[2] in ("convc1+convf1", "convc1", "convf1")]
-                # the flow-head gather of the previous iteration inside this iteration's lookup launch, on THIS table's column-tile
-                # planes (they differ from the per-layer program's when the table picked another tile width)
-                planes = L[7]._n_planes
-                lk = self._fold["lookup"]
-                if planes != lk.fh_planes:
-                    lk2 = type(lk).from_buffer_copy(lk)
-                    lk2.fh_planes, lk2._keep = planes, lk._keep
-                    lk = lk2
-                self._pk_gather = [("fh_gather", (planes, self.prog_iter[-1][1][1]))]
-                prog = [("lookup", self.lookup) if first else ("lookup", lk)] + head + [("pk", table, "pk")]
-        self._pk[key] = prog
-        return prog
-
     # ---- execution ------------------------------------------------------------------------
     def run(self, prog):
         for ent in prog:
             kind, a = ent[0], ent[1]
-            if kind == "pk":
-                ev = self.conv_events
-                if ev is not None and "pk" in ev:
-                    s, t = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    s.record()
-                    a.run()
-                    t.record()
-                    ev["pk"].append((s, t, a))
-                else:
-                    a.run()
-            elif kind == "conv2":
+            if kind == "conv2":
                 ev = self.conv_events
                 if ev is not None and len(ent) > 2 and ent[2] in ev:
                     s, t = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -780,24 +708,16 @@ class _Plan:
         ops.coords_init(self.coords, self.hf, self.wf, self.flow4.t, self.xbuf.t[:, off:], self.xbuf.cs)
         last = getattr(self, "prog_iter_last", None) if iters > 1 else None
         fold = self._fold if trace is None else None        # (a trace reads the coordinates after every iteration)
-        # persistent update-block launch: every iteration's program exists, else the per-layer launches
-        pk = UPDATE_PK != "0" and trace is None and all(
-            self._pk_program(it == 0, it % 2, it == iters - 1) is not None for it in sorted({0, 1, 2, iters - 1}) if it < iters)
         for it in range(iters):
-            if pk:
-                self.run(self._pk_program(it == 0, it % 2, it == iters - 1))
-                continue
             prog = self.prog_iter_first if it == 0 else (last if (last is not None and it == iters - 1) else self.prog_iter)
             if fold is not None:
                 prog = fold[id(prog)]
             self.run(prog)
             if trace is not None:
                 trace(self, it)
-        if pk:
-            self.run(self._pk_gather)
-        elif fold is not None:
+        if fold is not None:
             self.run(fold["gather"])
-        for p in (self.prog_mask[1:] if (last is not None or pk) else self.prog_mask):
+        for p in (self.prog_mask[1:] if last is not None else self.prog_mask):
             ops.run_conv(p)
         wlow = None
         if defer_wh:

@@ -81,6 +81,14 @@ class RAFTWrapper:
             if val:
                 self.precision, self.precision_source = str(val), src
                 break
+        # What arithmetic the caller got, said out loud: SURVEY 8a reads "IEEE fp32 unless stated", so anything else is STATED here --
+        # at WARNING level when nobody asked for it (the built-in default of a config without the key), at INFO level otherwise.
+        note = (f"RAFT arithmetic: precision = '{self.precision}' (from: {self.precision_source}). "
+                + ("This is the reference's arithmetic (exact IEEE fp32 products)." if self.precision == "fp32" else
+                   "NOT the reference's IEEE-fp32 products: set precision = 'fp32' in the flow config (or WOFT_PRECISION=fp32) "
+                   "for the reference's arithmetic (about 4x slower)."))
+        logger.log(logging.WARNING if self.precision_source.startswith("built-in default") else logging.INFO, note)
+        self.precision_note = note
         # correlation: "volume" (all-pairs volume + pyramid in HBM, corr.py:13-69) or "otf" (volume-free lookup, what
         # the reference's `alternate_corr` switch selects, corr.py:72-100).  Bit-identical results in every precision
         # (exact fp32 included: the lookup's fp32-MFMA instantiation), "otf" is faster and needs no P x P buffer: the default.

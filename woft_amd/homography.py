@@ -51,7 +51,12 @@ def _operands(points1, points2, weights, b):
 
 def _fit(points1, points2, weights, reweight, huber_k, n_irls):
     if not points1.is_cuda:
-        raise AssertionError("correspondences should be on GPU")
+        # The reference's QR estimator takes tensors of any device (least_squares_H.py:142-210 has no device check; only the IRLS
+        # variant asserts, :292-293 -- and so does find_homography_IRLSq_QR below).  Host tensors are copied to the HIP device,
+        # fitted by the same kernel and the result handed back on the caller's device: there is no CPU solver here.
+        dev = torch.device("cuda")
+        out = _fit(points1.to(dev), points2.to(dev), None if weights is None else weights.to(dev), reweight, huber_k, n_irls)
+        return out.to(points1.device)
     B = points1.shape[0]
     out = torch.empty(B, 3, 3, dtype=torch.float32, device=points1.device)
     status = torch.zeros(B, dtype=torch.int32, device=points1.device)

@@ -338,7 +338,7 @@ def conv_params(x, pc, out, co_off=0, epi=_lib.EPI_LINEAR, x2=None, c_split=0, e
     # wide 1x1 / stride-1 layers (convc1: 324 -> 256; the encoders' closing 128 -> 256): the streamed GEMM kernel (conv_1x1.hip, halo
     # 16) -- 64 pixels x all 256 columns per workgroup, activations read and converted once per layer; bit-identical to the gather kernel
     if USE_1X1 and auto_halo and halo == 0 and tiles is None and stats is None and not in_norm and wh0 is None and p.precision != 0 \
-            and not pc.flat and (pc.taps_y, pc.taps_x, pc.stride, pc.pad_y, pc.pad_x) == (1, 1, 1, 0, 0) and (ho, wo) == (x.h, x.w) \
+            and not pc.flat and x2 is None and (pc.taps_y, pc.taps_x, pc.stride, pc.pad_y, pc.pad_x) == (1, 1, 1, 0, 0) and (ho, wo) == (x.h, x.w) \
             and pc.cout_pad % 256 == 0 and _round_up(p.cout, 256) == pc.cout_pad:
         # (layers that only fill 128-column tiles gain nothing: mask head conv2 256 -> 576 61.5 vs 59.9 us, 128 -> 128 13.8 vs 14.0)
         halo = 16
@@ -478,77 +478,6 @@ def pair_ok(a, b):
     if a.halo == 0:
         return True
     return a.halo in (8, 12) and (a.taps_y, a.taps_x) == (b.taps_y, b.taps_x) and a.taps_y * a.taps_x > 1
-
-
-def _storage_ptr(act):
-    return None if act is None else act.t.untyped_storage().data_ptr()
-
-
-class PkTable:
-    """The layer table of one persistent update-block launch (woft_update_pk): `layers` = conv_params structs in dependency
-    order (halo 8 / 12 layers of one image).  Dependencies are derived from the tensors the structs were built from: a layer
-    waits for the earlier layers of the table that write one of its conv inputs (halo = its padding) or epilogue operands
-    (halo 0).  The host checks what the kernel's counters cannot order: no tensor region is written twice, and nothing is
-    read before a LATER layer of the table writes it."""
-
-    def __init__(self, layers, options=0):
-        lib = _lib.load()
-        n = len(layers)
-        assert 1 <= n <= _lib.PK_MAX_LAYERS
-        self.layers, self.options = list(layers), int(options)
-        arr = (_lib.PkLayer * n)()
-        writes = []                                # per layer: [(storage ptr, first channel, end channel)]
-        for i, p in enumerate(layers):
-            x, x2, pc, out, e0, e1, out1 = p._keep[:7]
-            bias_map = p._keep[9]
-            C.memmove(C.byref(arr[i].conv), C.byref(p), C.sizeof(_lib.ConvParams))
-            w = [(_storage_ptr(out), p.co_off, p.co_off + p.cout)] if p.epi != _lib.EPI_FLOWHEAD else [(_storage_ptr(out), 0, 1 << 30)]
-            if out1 is not None:
-                w.append((_storage_ptr(out1), 0, 1 << 30))
-            reads = [(x, p.pad_y, p.pad_x), (x2, p.pad_y, p.pad_x), (e0 if p.epi != _lib.EPI_FLOWHEAD else None, 0, 0), (e1, 0, 0),
-                     (bias_map, 0, 0)]
-            deps = {}
-            for t, hy, hx in reads:
-                sp = _storage_ptr(t)
-                if sp is None:
-                    continue
-                for j in range(i):
-                    if any(ws == sp for ws, _, _ in writes[j]):
-                        old = deps.get(j, (0, 0))
-                        deps[j] = (max(old[0], hy), max(old[1], hx))
-            for j, wj in enumerate(writes):        # written twice?
-                for ws, a0, a1 in wj:
-                    for ws2, b0, b1 in w:
-                        assert not (ws == ws2 and a0 < b1 and b0 < a1), f"layers {j} and {i} of a persistent launch write the same tensor region"
-            assert len(deps) <= _lib.PK_MAX_DEPS, deps
-            arr[i].n_dep = len(deps)
-            for k, (j, (hy, hx)) in enumerate(sorted(deps.items())):
-                arr[i].dep[k], arr[i].dep_hy[k], arr[i].dep_hx[k] = j, hy, hx
-            writes.append(w)
-        for i, p in enumerate(layers):             # read before a later layer writes it?
-            x, x2, _, _, e0, e1 = p._keep[:6]
-            for t in (x, x2, e0 if p.epi != _lib.EPI_FLOWHEAD else None, e1):
-                sp = _storage_ptr(t)
-                for j in range(i + 1, n):
-                    assert sp is None or all(ws != sp for ws, _, _ in writes[j]), \
-                        f"layer {i} reads a tensor that layer {j} of the same persistent launch overwrites"
-        check(lib.woft_update_pk_prepare(arr, n), "woft_update_pk_prepare")
-        self.host, self.n = arr, n
-        self.dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(DEV)
-        self.state = torch.zeros(int(lib.woft_update_pk_state_bytes(arr, n)) // 4, dtype=torch.int32, device=DEV)
-        self.n_items = arr[n - 1].item0 + arr[n - 1].n_ty * arr[n - 1].n_tx * arr[n - 1].n_nt
-
-    def run(self):
-        check(_lib.load().woft_update_pk(ptr(self.dev), self.host, self.n, ptr(self.state), self.options, stream_ptr()), "woft_update_pk")
-
-    def status(self):
-        """Synchronises.  0, or the give-up code of a launch that failed (1 + work item); a failed table is reset."""
-        s = self.state[:3].cpu()
-        err = int(s[2])
-        if err != 0 or int(s[0]) != 0 or int(s[1]) != 0:
-            self.state.zero_()
-            return err or -1
-        return 0
 
 
 def run_conv_pair(a, b):

@@ -151,32 +151,55 @@ def _match_loss(fn):
     return None
 
 
+def _probe_estimator_once(fn, n, device, with_weights=True):
+    g = torch.Generator().manual_seed(5 + n)
+    a = torch.rand(1, n, 2, generator=g).to(device) * 100
+    b = torch.rand(1, n, 2, generator=g).to(device) * 100
+    w = torch.rand(1, n, generator=g).to(device) if with_weights else None
+    with _Recorder() as rec:
+        out = fn(a, b, w)
+    if len(rec.calls) != 1:
+        return None
+    c = rec.calls[0]
+    if c["kind"] not in ("lsq", "irls") or out is not c["out"]:
+        return None
+    same = lambda x, y: x is y or (isinstance(x, torch.Tensor) and isinstance(y, torch.Tensor) and x.shape == y.shape
+                                   and x.dtype == y.dtype and torch.equal(x, y))
+    if not (same(c["a"], a) and same(c["b"], b) and (c["w"] is None or same(c["w"], w))):
+        return None
+    weighted = c["w"] is not None          # (the reference's "plainLSq" configs hand the library weights=None: an unweighted fit)
+    if c["kind"] == "lsq":
+        return 0, 0.0, 0, weighted
+    loss = _match_loss(c["fn"])
+    n_iter = c["n_iter"]
+    if loss is None or not isinstance(n_iter, int) or not (0 <= n_iter <= 64):
+        return None
+    return loss[0], loss[1], n_iter, weighted
+
+
+ESTIMATOR_PROBE_SIZES = (64, 4, 5, 500, 1500)
+
+
 def probe_estimator(fn, device="cpu"):
     """-> (reweight, huber_k, n_irls, weighted) when fn(pts_A (1,N,2), pts_B, weights (1,N)) is one pass-through call of the
-    library's least-squares / IRLS estimator (reweight 0 / 1 L1 / 2 Huber; weighted = it hands the weights on), else None."""
-    g = torch.Generator().manual_seed(5)
-    a = torch.rand(1, 64, 2, generator=g).to(device) * 100
-    b = torch.rand(1, 64, 2, generator=g).to(device) * 100
-    w = torch.rand(1, 64, generator=g).to(device)
+    library's least-squares / IRLS estimator (reweight 0 / 1 L1 / 2 Huber; weighted = it hands the weights on), else None.
+    Asked at several N -- the minimal 4, 5, the subsampler's 500, beyond the one-workgroup solver's range -- and every answer must be
+    the same (a callable that switches estimator on the number of correspondences keeps the callable back end); where it also accepts
+    weights=None it must make the same call there, unweighted."""
     try:
-        with _Recorder() as rec:
-            out = fn(a, b, w)
-        if len(rec.calls) != 1:
+        first = None
+        for n in ESTIMATOR_PROBE_SIZES:
+            got = _probe_estimator_once(fn, n, device)
+            if got is None or (first is not None and got != first):
+                return None
+            first = got
+        try:
+            plain = _probe_estimator_once(fn, 64, device, with_weights=False)
+        except Exception:
+            plain = "raises"                   # (it needs its weights: the tracker always provides them)
+        if plain != "raises" and (plain is None or plain[:3] != first[:3] or plain[3]):
             return None
-        c = rec.calls[0]
-        if c["kind"] not in ("lsq", "irls") or out is not c["out"]:
-            return None
-        same = lambda x, y: x is y or (isinstance(x, torch.Tensor) and x.shape == y.shape and x.dtype == y.dtype and torch.equal(x, y))
-        if not (same(c["a"], a) and same(c["b"], b) and (c["w"] is None or same(c["w"], w))):
-            return None
-        weighted = c["w"] is not None          # (the reference's "plainLSq" configs hand the library weights=None: an unweighted fit)
-        if c["kind"] == "lsq":
-            return 0, 0.0, 0, weighted
-        loss = _match_loss(c["fn"])
-        n_iter = c["n_iter"]
-        if loss is None or not isinstance(n_iter, int) or not (0 <= n_iter <= 64):
-            return None
-        return loss[0], loss[1], n_iter, weighted
+        return first
     except Exception:
         return None
 

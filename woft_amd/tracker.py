@@ -122,15 +122,18 @@ class _Fit(SimpleNamespace):
 
 
 class YAOFTrackerSingleControl:
+    DEVICE = "cuda"                  # (a host-logic test may build the tracker around a stub flow provider on "cpu")
+
     def __init__(self, config):
         self.C = config
         if self.C.subsampler_fn:
             self.C.subsampler_fn = make_forward_compatible(self.C.subsampler_fn)
         self.flower = config.flow_config.of_class(config.flow_config)
-        self.device = "cuda"
+        self.device = self.DEVICE
         self._fused = self._fused_specs()
         self._sparse_weights = False
         self._replay = None
+        self._announced = False
         self._upload = _FrameUploader()
         self.host_wait_s = 0.0       # seconds this tracker's thread spent blocked on the per-flow result read (device back end)
 
@@ -153,12 +156,19 @@ class YAOFTrackerSingleControl:
         from .probe import solver_spec
         spec, how = solver_spec(C.H_estimator, C.subsampler_fn or None, C.redet_success_fn, device=self.device)
         self.solver_decision = ("device back end" if spec is not None else "callable back end") + f" ({how})"
-        logger.info(f"tracker solver: {self.solver_decision}")
+        # A decision taken by PROBING replaces the config's own callables with the device solver on the strength of what they did
+        # on synthetic inputs (woft_amd.probe): said at WARNING level, with the way out.  Tagged presets / no replacement: INFO.
+        probed = spec is not None and "probed" in how
+        logger.log(logging.WARNING if probed else logging.INFO,
+                   f"tracker solver: {self.solver_decision}"
+                   + (" -- the config's estimator / subsampler / re-detection callables were recognised by behavioural probing and "
+                      "are replaced by the HIP solver (same results, tested); set `device_solver = False` in the tracker config "
+                      "(or WOFT_FUSED=0) to run the config's own callables instead" if probed else ""))
         if spec is None:
             return None
         from .presets import sobol_points
         n_draw = spec["n_draw"]
-        spec["sobol_u"] = torch.from_numpy(sobol_points(n_draw).astype(np.float32)).cuda() if n_draw else None
+        spec["sobol_u"] = torch.from_numpy(sobol_points(n_draw).astype(np.float32)).to(self.device) if n_draw else None
         return spec
 
     def _fused_buffers(self, n_grid):
@@ -266,6 +276,11 @@ class YAOFTrackerSingleControl:
         self.prev_img, self.prev_img_identifier = frame, img_identifier
         self._set_pose(H_cur2init.copy(), good=not self.lost)
         meta.lost, meta.N_lost, meta.global_H_success = self.lost, self.N_lost, fit.success
+        if not self._announced:           # first tracked frame: which arithmetic and which solver produced these results
+            self._announced = True
+            meta.precision = getattr(self.flower, "precision", None)
+            meta.precision_source = getattr(self.flower, "precision_source", None)
+            meta.solver_decision = self.solver_decision
         k = self.C.downscale_inputs
         if k:                                                        # TRK:280-283
             H_cur2init = compose_H(np.diag([1.0 / k, 1.0 / k, 1.0]), H_cur2init, np.diag([float(k), float(k), 1.0]))
