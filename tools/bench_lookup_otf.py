@@ -34,10 +34,10 @@ def main():
     coords = (base + flow + noise).contiguous()
     out = torch.zeros(P, 352, device="cuda")
     lp = ops.make_lookup_otf_params(f1s, f2s, dims, hf, wf, c, coords, out, 4, 3)
-    lp.ablate = int(os.environ.get("OTF_ABL", "0"))     # developer ablation bits (include/woft_hip.h)
+    lp.ablate = int(os.environ.get("OTF_ABL", "0")) | (int(os.environ.get("OTF_VARIANT", "0")) << 8)     # developer ablation bits / kernel variant (include/woft_hip.h)
     ms = bench(lambda: ops.run_lookup_otf(lp), reps=20)
     print(f"volume-free lookup {hf}x{wf}, flow {flow}, ablate {lp.ablate}: {ms * 1e3:8.1f} us")
-    if lp.ablate & 16:      # per-workgroup timeline: [start | per level: coords written, synced, stream primed, chunks done, samples written]
+    if (lp.ablate & 16) and not (lp.ablate >> 8):      # per-workgroup timeline: [start | per level: coords written, synced, stream primed, chunks done, samples written]
         import numpy as np
         torch.cuda.synchronize()
         rows = out.view(hf, wf, 352)[::8, ::8, 324:348].contiguous().view(torch.int32).cpu().numpy().astype(np.int64).reshape(-1, 24)
@@ -47,7 +47,7 @@ def main():
         for l in range(4):
             print(f"  level {l}: " + ", ".join(f"{n} {int(np.median(d[:, 5 * l + k]))}" for k, n in enumerate(names)))
         print(f"  workgroup total (median cycles): {int(np.median((rows[:, 20] - rows[:, 0]) & 0xffffffff))}")
-    if lp.ablate & 32:      # one chunk (level 0, second chunk), per K-step group: [start, stream landed, barrier, issued, MFMAs done] ... drop
+    if (lp.ablate & 32) and not (lp.ablate >> 8):      # one chunk (level 0, second chunk), per K-step group: [start, stream landed, barrier, issued, MFMAs done] ... drop
         import numpy as np
         torch.cuda.synchronize()
         rows = out.view(hf, wf, 352)[::8, ::8, 324:348].contiguous().view(torch.int32).cpu().numpy().astype(np.int64).reshape(-1, 24)

@@ -98,10 +98,15 @@ __device__ __forceinline__ void tile_1x1(const woft_conv_params& p, const int m_
             for (int e = 0; e < 2; ++e) rh[slot][e] = *(const f32x4*)(p.in0 + (okx[e] ? rowoff + run0 + 4 * e : 0u));
         } else {
             const int c0 = ck * BK;
-            // single-source layers only (woft_conv_1x1_launch rejects in1): the two-source base `in1 + (c0 - c_split)` formed here
-            // is the expression conv.hip documents as miscompiled on this toolchain (stale high half of the 64-bit shift)
-            rh[slot][0] = *(const f32x4*)(p.in0 + (pix * (uint32_t)p.cs0 + (uint32_t)c0 + 8 * v));
-            rh[slot][1] = *(const f32x4*)(p.in0 + (pix * (uint32_t)p.cs0 + (uint32_t)c0 + 8 * v + 4));
+            // two sources: the base pointer is one of the two kernel arguments as it stands and the channel offset goes into the
+            // 32-bit lane offset (conv.hip's form).  `in1 + (c0 - c_split)` as a 64-bit base formed here is the expression conv.hip
+            // documents as miscompiled on this toolchain (stale high half of the 64-bit shift): not used
+            const bool second = (p.in1 != nullptr) && (c0 >= p.c_split);
+            const float* base = second ? p.in1 : p.in0;
+            const uint32_t cs = (uint32_t)(second ? p.cs1 : p.cs0);
+            const uint32_t coff = (uint32_t)(second ? c0 - p.c_split : c0);
+            rh[slot][0] = *(const f32x4*)(base + (pix * cs + coff + 8 * v));
+            rh[slot][1] = *(const f32x4*)(base + (pix * cs + coff + 8 * v + 4));
         }
     };
     auto store_a = [&](int chunk, __bf16* As, auto slot_tag) {              // fp32 -> bf16 terms -> LDS
@@ -260,7 +265,6 @@ int woft_conv_1x1_launch(const woft_conv_params& a, const woft_conv_params* seco
             return WOFT_EINVAL;
         }
         if (p.wgt_frag == nullptr || p.stat_sum != nullptr || p.in_norm != 0 || p.wh0_lookup != nullptr) return WOFT_EINVAL;
-        if (p.in1 != nullptr) return WOFT_EINVAL;                   // (two-source layers stay on the gather kernel)
         if (p.epi == WOFT_EPI_FLOWHEAD || p.epi == WOFT_EPI_WH_MEAN || p.epi == WOFT_EPI_CTX) return WOFT_EINVAL;
         if (p.cout_pad % p.tile_n != 0) return WOFT_EINVAL;
         const int64_t cs_max = (p.in1 != nullptr && p.cs1 > p.cs0) ? p.cs1 : p.cs0;

@@ -338,7 +338,7 @@ def conv_params(x, pc, out, co_off=0, epi=_lib.EPI_LINEAR, x2=None, c_split=0, e
     # wide 1x1 / stride-1 layers (convc1: 324 -> 256; the encoders' closing 128 -> 256): the streamed GEMM kernel (conv_1x1.hip, halo
     # 16) -- 64 pixels x all 256 columns per workgroup, activations read and converted once per layer; bit-identical to the gather kernel
     if USE_1X1 and auto_halo and halo == 0 and tiles is None and stats is None and not in_norm and wh0 is None and p.precision != 0 \
-            and not pc.flat and x2 is None and (pc.taps_y, pc.taps_x, pc.stride, pc.pad_y, pc.pad_x) == (1, 1, 1, 0, 0) and (ho, wo) == (x.h, x.w) \
+            and not pc.flat and (pc.taps_y, pc.taps_x, pc.stride, pc.pad_y, pc.pad_x) == (1, 1, 1, 0, 0) and (ho, wo) == (x.h, x.w) \
             and pc.cout_pad % 256 == 0 and _round_up(p.cout, 256) == pc.cout_pad:
         # (layers that only fill 128-column tiles gain nothing: mask head conv2 256 -> 576 61.5 vs 59.9 us, 128 -> 128 13.8 vs 14.0)
         halo = 16
