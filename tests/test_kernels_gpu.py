@@ -878,7 +878,10 @@ def test_bf16_storage_volume(ops, h, w, precision):
 
 @pytest.mark.parametrize("h,w,precision,spread", [(17, 25, "bf16x3", 2.0), (24, 40, "bf16x3", 30.0), (16, 20, "bf16", 3.0),
                                                   (9, 11, "bf16x3", 200.0), (17, 25, "fp32", 2.0), (24, 40, "fp32", 30.0),
-                                                  (9, 11, "fp32", 200.0)])
+                                                  (9, 11, "fp32", 200.0),
+                                                  # round 6: maps with interior blocks (boxes not clipped: windows not cleared, every cell
+                                                  # written) next to clipped ones, a smooth field and a one-sided shift
+                                                  (48, 72, "bf16x3", 0.3), (48, 72, "fp32", 0.3), (48, 72, "bf16", 0.3), (40, 64, "bf16x3", -11.0)])
 def test_lookup_on_the_fly(ops, h, w, precision, spread):
     """Volume-free lookup (woft_corr_lookup_otf) == lookup in the volume built by the correlation GEMM in the same
     arithmetic, bit for bit (identical correlation values, identical interpolation), for smooth, scattered and
@@ -886,7 +889,10 @@ def test_lookup_on_the_fly(ops, h, w, precision, spread):
     c = 256
     f1, f2 = _rand(1, c, h, w, seed=51), _rand(1, c, h, w, seed=52)
     vols, dims = _build_pyramid_gpu(ops, f1, f2, precision, presplit=precision != "fp32")     # (fp32: the fp32-MFMA GEMM)
-    coords = raft_ref.coords_grid(1, h, w) + _rand(1, 2, h, w, seed=53, scale=spread)
+    if spread < 0:              # a global shift (windows leave the map on one side) + a little noise
+        coords = raft_ref.coords_grid(1, h, w) + spread + _rand(1, 2, h, w, seed=53, scale=0.4)
+    else:
+        coords = raft_ref.coords_grid(1, h, w) + _rand(1, 2, h, w, seed=53, scale=spread)
     coords[0, :, 0, 0] = torch.tensor([-7.3, 2.2])
     coords[0, :, h - 1, w - 1] = torch.tensor([w + 9.5, h + 3.0])
     cg = coords[0].permute(1, 2, 0).reshape(h * w, 2).contiguous().cuda()
