@@ -173,7 +173,7 @@ def main():
     template, frames = make_sequence(H, W, rank, CLIP)       # (every pass indexes frames[i % CLIP])
     mask = synth.make_init_mask(H, W)
 
-    def make_tracker(precision, corr=None, mask_wh=None, graph=False):
+    def make_tracker(precision, corr=None, mask_wh=None, graph=False, first=None):
         conf = load_config(ROOT / "pytracking" / "configs" / (args.tracker_config + ".py"))
         conf.mask_weight_head = (not args.full_weight_head) if mask_wh is None else mask_wh
         conf.flow_config.model = sd
@@ -185,7 +185,7 @@ def main():
         # (exact fp32: volume-free since round 3 -- bit-identical to the volume path, no P x P buffer; WOFT_FP32_CORR=volume: A/B)
         conf.flow_config.corr = (corr or args.corr) if precision != "fp32" else (corr or os.environ.get("WOFT_FP32_CORR", "otf"))
         trk = conf.tracker_class(conf)
-        trk.init(template, mask)
+        trk.init(template if first is None else first, mask)
         if args.no_template_cache:
             trk.flower.pin_source(None)
         return trk
@@ -613,6 +613,52 @@ def main():
                                      "pipelined ms_per_step of the headline)"}
         del trk
         drop()
+        # ---- two sequences on ONE GPU in one process (side figure, never `value`): two trackers, two HIP streams, two host threads
+        # (the per-flow result read releases the GIL).  Every layer at 1/8 resolution is ONE round of the chip's 512 workgroup slots,
+        # so a single sequence runs its launches in lock-step (common prologue, common store burst); a second stream's launches fill
+        # those phases.  What a 16-sequence job on 8 GPUs would get per GPU.
+        import threading
+        seqs = [(template, frames), make_sequence(H, W, 101, CLIP)]
+        streams = [torch.cuda.Stream() for _ in seqs]
+        trks2 = []
+        for (tpl, frs), st in zip(seqs, streams):
+            with torch.cuda.stream(st):
+                t2 = make_tracker(args.precision, first=tpl)
+                for i in range(Wm):
+                    t2.track(frs[i % CLIP])
+                st.synchronize()
+            trks2.append(t2)
+        n2 = K2
+        gate = threading.Barrier(len(seqs) + 1)
+        errs = []
+
+        def run_sequence(j):
+            try:
+                with torch.cuda.stream(streams[j]):
+                    gate.wait()
+                    for i in range(Wm, Wm + n2):
+                        if i > 0 and i % CLIP == 0:
+                            restart_clip(trks2[j])
+                        trks2[j].track(seqs[j][1][i % CLIP])
+                    streams[j].synchronize()
+            except Exception as ex:          # (reported in the line; the headline does not depend on this pass)
+                errs.append(f"{type(ex).__name__}: {ex}")
+        threads = [threading.Thread(target=run_sequence, args=(j,)) for j in range(len(seqs))]
+        for th in threads:
+            th.start()
+        torch.cuda.synchronize()
+        gate.wait()
+        t1 = time.perf_counter()
+        for th in threads:
+            th.join()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        out["two_sequences_one_gpu"] = {"sequences": len(seqs), "steps_each": n2, "aggregate_frames_per_s": len(seqs) * n2 / dt,
+                                        "ms_per_step_each": 1000.0 * dt / n2, "errors": errs or None,
+                                        "note": "two trackers on two HIP streams driven by two host threads of this process; "
+                                                "aggregate over both sequences (compare with `value`, one sequence)"}
+        del trks2, streams
+        drop()
         if K < 200:
             # ---- the driver times --steps frames (0.2 s at 20 steps); the same configuration over >= 2 s, in chunks of 20
             trk = make_tracker(args.precision)
@@ -676,6 +722,7 @@ def main():
     cfgd["fps_reference_form_config_unmodified"] = r1(g(out, "reference_format_config", "no_precision_key", "frames_per_s"))
     cfgd["fps_reference_form_config_bf16x3"] = r1(g(out, "reference_format_config", "precision_bf16x3", "frames_per_s"))
     cfgd["fps_reference_form_config_fp32"] = r1(g(out, "reference_format_config", "precision_fp32", "frames_per_s"))
+    cfgd["fps_two_sequences_one_gpu"] = r1(g(out, "two_sequences_one_gpu", "aggregate_frames_per_s"))
     cfgd["fps_f16mx8"] = r1(g(out, "alt_precisions", "f16mx8", "frames_per_s"))     # (opt-in: 2 matrix-pipe passes per product on the 3x3 layers)
     cfgd["epe_mean_px"] = g(out, "flow_epe_vs_cpu_oracle", "mean_px")
     cfgd["epe_gate_passed"] = out["epe_gate"]["passed"]

@@ -757,9 +757,11 @@ _HFIT_WS = {}
 
 
 def hfit_ws(device=None):
-    """Scratch of the streaming fit (woft_hfit_ws_bytes), one per device, reused (stream-ordered)."""
+    """Scratch of the streaming fit (woft_hfit_ws_bytes), one per device and stream, reused (stream-ordered)."""
     dev = torch.device(device or DEV)
-    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    # (one per device AND stream: its use is ordered by the stream it was first used on -- two trackers on two streams of one
+    #  process must not share it)
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device(), stream_ptr())
     if key not in _HFIT_WS:
         _HFIT_WS[key] = torch.empty(int(_lib.load().woft_hfit_ws_bytes()), dtype=torch.uint8, device=dev)
     return _HFIT_WS[key]
