@@ -17,7 +17,7 @@ python bench.py --height 480 --width 640 --no-cpu-baseline --no-ladder --no-alt-
 python tools/bench_hfit.py > $out/${tag}_hfit_fullframe.txt 2>/dev/null
 { python tools/bench_lookup.py; python tools/bench_lookup.py --storage bf16;
   for abl in 1 2 3; do LOOKUP_ABL=$abl python tools/bench_lookup.py; done; } 2>/dev/null | grep lookup > $out/${tag}_lookup_isolated.txt
-{ OTF_ABL=16 python tools/bench_lookup_otf.py; for abl in 1 2 3 15; do OTF_ABL=$abl python tools/bench_lookup_otf.py; done; } 2>/dev/null | grep -v amdgpu > $out/${tag}_lookup_otf_timeline.txt
+{ OTF_ABL=16 python tools/bench_lookup_otf.py; OTF_ABL=64 python tools/bench_lookup_otf.py; for abl in 1 2 3 8 15; do OTF_ABL=$abl python tools/bench_lookup_otf.py; done; SMOOTH=0 python tools/bench_lookup_otf.py; SMOOTH=0 FLOW=8 python tools/bench_lookup_otf.py; } 2>/dev/null | grep -v amdgpu > $out/${tag}_lookup_otf_timeline.txt
 python tools/layer_times.py 2>/dev/null | grep -v amdgpu > $out/${tag}_layer_times_bf16x3.txt
 python tools/layer_times.py --precision fp32 2>/dev/null | grep -v amdgpu > $out/${tag}_layer_times_fp32.txt
 python tools/regb_check.py 2>/dev/null | grep -v amdgpu > $out/${tag}_conv_kernels_ab.txt
