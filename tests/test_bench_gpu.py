@@ -41,7 +41,7 @@ def test_bench_eight_ranks_dry_run():
 def test_bench_line_carries_ladder_and_lost_frames():
     """Small-size run of the default bench line's extra passes: the like-for-like ladder, the lost-frame pass (forced every
     4th frame; the local flow runs in the second buffer set, so the frame after it costs what a normal frame costs) and the
-    >= 200-step steady-state figure."""
+    >= 200-step steady-state figure; the two-sequences-on-one-GPU side pass."""
     env = dict(os.environ)
     cmd = [sys.executable, str(ROOT / "bench.py"), "--no-cpu-baseline", "--no-alt-precisions", "--no-alt-corr",
            "--steps", "8", "--warmup", "2", "--height", "384", "--width", "512"]
@@ -55,6 +55,8 @@ def test_bench_line_carries_ladder_and_lost_frames():
     assert lf["lost_frames"] == lf["frames"] // lf["forced_every"] > 0
     assert lf["lost_frame_ms"] > lf["normal_frame_ms"] > 0 and lf["frame_after_lost_ms"] > 0
     assert d["steady_state"]["steps"] == 200 and d["steady_state"]["frames_per_s"] > 0
+    two = d["two_sequences_one_gpu"]            # round 6: two trackers, two streams, two host threads of one process
+    assert two["sequences"] == 2 and two["errors"] is None and two["aggregate_frames_per_s"] > 0
     assert len(d["per_rank"]) == 1
 
 
