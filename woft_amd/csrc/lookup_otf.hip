@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256, 2) void corr_lookup_otf_kernel(const woft_look
     __shared__ __attribute__((aligned(16))) float Wn[NPX * WLD];
     constexpr int MAXL = 4;
     __shared__ __attribute__((aligned(16))) int s_org[MAXL][NPX];    // window origin per level, clamped to 16 bits and packed (x | y << 16)
-    __shared__ __attribute__((aligned(16))) int s_pm[MAXL][NPX];     // float index of the window's cell (0, 0) minus (ox * WS + oy)
+    __shared__ __attribute__((aligned(16))) int s_pm[MAXL][NPX];     // byte offset in Wn of the window's cell (0, 0) minus 4 (ox * WS + oy)
     __shared__ float s_fx[MAXL][NPX], s_fy[MAXL][NPX];
     __shared__ int s_box[MAXL][4];                       // unclipped bounding box of the valid window origins: min x, max x, min y, max y
     __shared__ float s_trash[64];
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256, 2) void corr_lookup_otf_kernel(const woft_look
                 const int ox = wx0 < -16384 ? -16384 : (wx0 > 16384 ? 16384 : wx0);
                 const int oy = wy0 < -16384 ? -16384 : (wy0 > 16384 ? 16384 : wy0);
                 s_org[l][tid] = cvalid ? ((ox & 0xffff) | (oy << 16)) : 0x40004000;      // (pixels outside the grid: never inside)
-                s_pm[l][tid] = tid * WLD - (ox * WS + oy);
+                s_pm[l][tid] = 4 * (tid * WLD - (ox * WS + oy));     // (BYTE offset: the drop adds its position's once per chunk)
                 const int b0 = wave_reduce_minmax<false>(cvalid ? wx0 : 0x3fffffff), b1 = wave_reduce_minmax<true>(cvalid ? wx0 : -0x3fffffff);
                 const int b2 = wave_reduce_minmax<false>(cvalid ? wy0 : 0x3fffffff), b3 = wave_reduce_minmax<true>(cvalid ? wy0 : -0x3fffffff);
                 if (tid == 0) { s_box[l][0] = b0; s_box[l][1] = b1; s_box[l][2] = b2; s_box[l][3] = b3; }
@@ -371,8 +371,10 @@ __global__ __launch_bounds__(256, 2) void corr_lookup_otf_kernel(const woft_look
                 const int pos = c0 + wn * 32 + r32;
                 const int by = pos / bw, bx = pos - by * bw;
                 const int tx = bx0 + bx, ty = by0 + by;  // target pixel of this column
-                const bool col_ok = pos < N;
-                const int d_pos = (tx & 0xffff) | (ty << 16), d_q = tx * WS + ty;
+                // (a column past the box end takes a position no window contains: 32767 - origin >= 16383 in both halves)
+                const int d_pos = pos < N ? ((tx & 0xffff) | (ty << 16)) : 0x7fff7fff;
+                const uint32_t d_q4 = lds_addr_of(Wn) + 4u * (uint32_t)(tx * WS + ty);
+                const uint32_t trash = lds_addr_of(s_trash) + 4u * (uint32_t)lane;
                 i32x4 org[4], pm[4];
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
@@ -384,9 +386,9 @@ __global__ __launch_bounds__(256, 2) void corr_lookup_otf_kernel(const woft_look
                 for (int r = 0; r < 16; ++r) {
                     const u16x2 dd = __builtin_bit_cast(u16x2, d_pos) - __builtin_bit_cast(u16x2, (int)org[r >> 2][r & 3]);
                     const u16x2 mn = __builtin_elementwise_min(dd, lim);
-                    const bool inside = col_ok && __builtin_bit_cast(uint32_t, mn) == __builtin_bit_cast(uint32_t, dd);
-                    float* cell = inside ? (Wn + (pm[r >> 2][r & 3] + d_q)) : (s_trash + lane);
-                    *cell = acc[r] * p.alpha;
+                    const bool inside = __builtin_bit_cast(uint32_t, mn) == __builtin_bit_cast(uint32_t, dd);
+                    const uint32_t cell = inside ? (uint32_t)pm[r >> 2][r & 3] + d_q4 : trash;
+                    *(__attribute__((address_space(3))) float*)(uintptr_t)cell = acc[r] * p.alpha;
                 }
             }
 #pragma unroll
