@@ -39,7 +39,8 @@
 // matrix pipe (3.07 k per chunk and SIMD for two workgroups) and the L2 -> LDS path (64 KB per chunk and workgroup at the
 // ~40 B/clk a CU's LDS-DMA sustains: 3.2 k) would allow ~3.2 k.
 // Measured and NOT kept (rounds 2-5; git history): DMA pieces one per k sub-step (88.3 vs 82.0 us); the window drop of chunk
-// c - 1 under the MFMAs of chunk c (+-0); a fully unrolled sampling loop (spills); 16 x 8-pixel blocks (-1.7 % frames/s);
+// c - 1 under the MFMAs of chunk c (+-0 in round 3; again in round 6 on this kernel, in 20 slices behind the sub-steps' MFMAs:
+// 74.6 vs 72.0 us -- anything between two MFMAs on the one accumulator delays the dependent MFMA); a fully unrolled sampling loop (spills); 16 x 8-pixel blocks (-1.7 % frames/s);
 // box indexing by float reciprocal (slower).
 #include <type_traits>
 #include <utility>
