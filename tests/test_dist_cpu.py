@@ -40,7 +40,9 @@ def _worker(rank, world, port, q):
     info = wd.bind_to_gpu_node(0, rank, world)        # no GPU here: reports why it did not bind, never raises
     assert info["bound"] is False and info["cores"] >= 1
     q.put((rank, tracks.numpy(), slow))
-    torch.distributed.destroy_process_group()
+    wd.finalize()                        # last barrier + destroy_process_group (what bench.py's ranks end with)
+    assert not torch.distributed.is_initialized()
+    wd.finalize()                        # (idempotent: nothing to do without a group)
 
 
 def test_gather_tracks_world2():

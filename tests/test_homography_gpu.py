@@ -54,6 +54,11 @@ def test_operator_shapes_and_assertions(golden_dir):
         L.find_homography_nonhomogeneous_QR(torch.zeros(1, 8, 3).cuda(), torch.zeros(1, 8, 3).cuda())
     with pytest.raises(AssertionError):                      # the IRLS estimator insists on device tensors, :292-293
         L.find_homography_IRLSq_QR(a.cpu(), b.cpu(), w.cpu())
+    # ... the plain QR estimator does not (least_squares_H.py:142-210 has no device check): host tensors in, host tensor out -- fitted
+    # by the same kernel (there is no CPU solver), so the result is the device call's, bit for bit
+    Hc = L.find_homography_nonhomogeneous_QR(a.cpu(), b.cpu(), w.cpu())
+    assert not Hc.is_cuda and tuple(Hc.shape) == (1, 3, 3) and torch.equal(Hc, H.cpu())
+    assert torch.equal(L.find_homography_nonhomogeneous_QR(a.cpu(), b.cpu()), L.find_homography_nonhomogeneous_QR(a, b).cpu())
     with pytest.raises(AssertionError):
         L.find_homography_IRLSq_QR(a[:, :3], b[:, :3], w[:, :3])
 
