@@ -34,10 +34,11 @@
 // per SIMD nothing hides a dependent instruction's latency, a DMA issue or another wave's phase; the two co-resident
 // workgroups of THIS kernel are what overlaps one's drop / sampling / DMA issue with the other's MFMAs
 // (profiles/r06_lookup_autonomous_waves.txt, tools/micro/dma_issue_probe.hip; the code is in the git history).
-// Where the time is now (profiles/r06_lookup_otf_timeline.txt): a workgroup lives ~105 k cycles, 78 k of them in its 15
-// chunks (5.2 k each: per two K steps ~140 barrier, ~400 DMA issue, ~700 fragment reads + 12 MFMAs; 1.5 k drop); both the
-// matrix pipe (3.07 k per chunk and SIMD for two workgroups) and the L2 -> LDS path (64 KB per chunk and workgroup at the
-// ~40 B/clk a CU's LDS-DMA sustains: 3.2 k) would allow ~3.2 k.
+// Where the time is now (profiles/r06_lookup_otf_timeline.txt): a workgroup lives ~99 k cycles: set-up 5 k, its 15 chunks 73 k
+// (4.9 k each: per two K steps ~50 barrier + ~850 fragment reads / 12 MFMAs / DMA issue with the other workgroup's wave sharing
+// the SIMD; ~1.2 k window drop), sampling + priming of the next level 16 k.  Both the matrix pipe (3.07 k per chunk and SIMD for
+// two workgroups) and the L2 -> LDS path (64 KB per chunk and workgroup at the ~40-50 B/clk a CU's LDS-DMA sustains: ~3.2 k)
+// would allow ~3.2 k per chunk.
 // Measured and NOT kept (rounds 2-5; git history): DMA pieces one per k sub-step (88.3 vs 82.0 us); the window drop of chunk
 // c - 1 under the MFMAs of chunk c (+-0 in round 3; again in round 6 on this kernel, in 20 slices behind the sub-steps' MFMAs:
 // 74.6 vs 72.0 us -- anything between two MFMAs on the one accumulator delays the dependent MFMA); a fully unrolled sampling loop (spills); 16 x 8-pixel blocks (-1.7 % frames/s);
