@@ -50,6 +50,15 @@ def restart_clip(tracker):
     tracker.lost, tracker.N_lost = False, 0
 
 
+def _overrule_run(inner, seen, every, frame, prewarp_H):
+    """Global stage with the re-detection verdict overruled on the last two frames of every `every` (bench.py's lost-run pass)."""
+    fit = inner(frame, prewarp_H)
+    seen["i"] += 1
+    if seen["i"] % every in (every - 2, every - 1):
+        fit.success = False
+    return fit
+
+
 def make_sequence(H, W, seq_id, n_frames):
     """Template (numpy, host) + frames (CUDA uint8 tensors) warped on the device."""
     from woft_amd import ops, synth
@@ -611,6 +620,29 @@ def main():
                              "local_stage_weight_head": "deferred to the drawn correspondences" if getattr(trk, "_sparse_weights", False) else "full map",
                              "note": "wall ms per track() with a device sync after every frame (so each is a little above the "
                                      "pipelined ms_per_step of the headline)"}
+        # ... and runs of lost frames (a loss usually lasts several frames): in the same pass pattern, frames 2 and 3 of every four are
+        # overruled.  From the second frame of a run on, the local flow's source is the previous local flow's target: its features are
+        # taken from there instead of encoded again (woft_amd.tracker._local_stage; identical tracks, tested)
+        seen["i"], every2 = 0, 4
+        trk._global_stage = lambda frame, prewarp_H: _overrule_run(inner, seen, every2, frame, prewarp_H)
+        restart_clip(trk)
+        first_ms, second_ms, reused = [], [], []
+        for i in range(Wm, Wm + 16):
+            if i > 0 and i % CLIP == 0:
+                restart_clip(trk)
+            trk.flower.source_features_reused = False
+            t1 = time.perf_counter()
+            _, m_ = trk.track(frames[i % CLIP])
+            torch.cuda.synchronize()
+            ms_ = 1000.0 * (time.perf_counter() - t1)
+            if m_.lost and m_.N_lost == 1:
+                first_ms.append(ms_)
+            elif m_.lost:
+                second_ms.append(ms_)
+                reused.append(bool(trk.flower.source_features_reused))
+        out["lost_frame"]["runs_of_two"] = {"first_lost_frame_ms": med(first_ms), "second_lost_frame_ms": med(second_ms),
+                                            "second_over_normal": (med(second_ms) / med(other_ms)) if second_ms and other_ms else None,
+                                            "source_features_reused_on_second": bool(reused) and all(reused)}
         del trk
         drop()
         # ---- two sequences on ONE GPU in one process (side figure, never `value`): two trackers, two HIP streams, two host threads
@@ -722,6 +754,7 @@ def main():
     cfgd["fps_reference_form_config_unmodified"] = r1(g(out, "reference_format_config", "no_precision_key", "frames_per_s"))
     cfgd["fps_reference_form_config_bf16x3"] = r1(g(out, "reference_format_config", "precision_bf16x3", "frames_per_s"))
     cfgd["fps_reference_form_config_fp32"] = r1(g(out, "reference_format_config", "precision_fp32", "frames_per_s"))
+    cfgd["lost_run_second_over_normal"] = g(out, "lost_frame", "runs_of_two", "second_over_normal")
     cfgd["fps_two_sequences_one_gpu"] = r1(g(out, "two_sequences_one_gpu", "aggregate_frames_per_s"))
     cfgd["fps_f16mx8"] = r1(g(out, "alt_precisions", "f16mx8", "frames_per_s"))     # (opt-in: 2 matrix-pipe passes per product on the 3x3 layers)
     cfgd["epe_mean_px"] = g(out, "flow_epe_vs_cpu_oracle", "mean_px")

@@ -54,6 +54,8 @@ def test_bench_line_carries_ladder_and_lost_frames():
     lf = d["lost_frame"]
     assert lf["lost_frames"] == lf["frames"] // lf["forced_every"] > 0
     assert lf["lost_frame_ms"] > lf["normal_frame_ms"] > 0 and lf["frame_after_lost_ms"] > 0
+    run2 = lf["runs_of_two"]              # round 6: the second lost frame of a run takes its source features from the previous local flow
+    assert run2["source_features_reused_on_second"] is True and 0 < run2["second_lost_frame_ms"] < run2["first_lost_frame_ms"]
     assert d["steady_state"]["steps"] == 200 and d["steady_state"]["frames_per_s"] > 0
     two = d["two_sequences_one_gpu"]            # round 6: two trackers, two streams, two host threads of one process
     assert two["sequences"] == 2 and two["errors"] is None and two["aggregate_frames_per_s"] > 0

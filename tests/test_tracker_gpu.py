@@ -337,9 +337,9 @@ def test_lost_frames_keep_the_template_resident_and_defer_the_local_weights():
         encodes = {"n": 0}
         enc0 = plan0.encode_source
 
-        def counted(enc0=enc0, encodes=encodes):
+        def counted(enc0=enc0, encodes=encodes, **kw):
             encodes["n"] += 1
-            return enc0()
+            return enc0(**kw)
         plan0.encode_source = counted
         res, deferred_local = [], []
         for t, f in enumerate(frames):
@@ -356,6 +356,52 @@ def test_lost_frames_keep_the_template_resident_and_defer_the_local_weights():
     for a, b in zip(outs[False], outs[True]):
         assert np.array_equal(a[0], b[0]) and a[1:3] == b[1:3]
         assert (a[3] is None) == (b[3] is None) and (a[3] is None or np.array_equal(a[3], b[3]))
+
+
+@pytest.mark.parametrize("precision,host_frames", [("bf16x3", False), ("fp32", False), ("bf16x3", True)])
+def test_consecutive_lost_frames_reuse_the_previous_target_features(precision, host_frames, monkeypatch):
+    """Frames lost in a row (TRK:167-207): frame t was the TARGET of the t-1 -> t flow and is the SOURCE of the t -> t+1 flow, so
+    the provider takes its feature map from the previous call's target pyramid instead of a second fnet pass over the same image
+    (round 6; `compute_flow(..., src_is_previous_dst=True)`, engine.encode_source(reuse_target=True)).  Same launch program on the
+    same pixels: homographies bit-identical with the reuse switched off (WOFT_LOCAL_REUSE=0), frame for frame; reused exactly on
+    the second and later frames of a lost run, also for host (numpy) frames, whose device copies alternate between two buffers."""
+    from pytracking.utils.config import load_config
+    H, W, iters = 256, 320, 3
+    sd = synth.make_state_dict(seed=5)
+    template = synth.make_template(H, W, seq_id=4)
+    frames = [synth.make_frame(template, t) for t in range(1, 8)]
+    if not host_frames:
+        frames = [torch.from_numpy(f).cuda() for f in frames]
+    mask = synth.make_init_mask(H, W)
+    lost_at = {1, 2, 3, 5}                     # runs: frames 1-3 (reuse at 2 and 3), frame 5 alone (no reuse: frame 4 was not a local target)
+    outs = {}
+    for reuse in ("1", "0"):
+        monkeypatch.setenv("WOFT_LOCAL_REUSE", reuse)
+        conf = load_config(ROOT / "pytracking" / "configs" / "WOFT.py")
+        conf.flow_config.model, conf.flow_config.iters, conf.flow_config.precision = sd, iters, precision
+        trk = conf.tracker_class(conf)
+        trk.init(template, mask)
+        inner, k = trk._global_stage, {"i": -1}
+
+        def overruled(frame, prewarp_H, inner=inner, k=k):
+            fit = inner(frame, prewarp_H)
+            k["i"] += 1
+            if k["i"] in lost_at:
+                fit.success = False
+            return fit
+        trk._global_stage = overruled
+        res, reused = [], []
+        for t, f in enumerate(frames):
+            trk.flower.source_features_reused = False
+            Hm, meta = trk.track(f)
+            res.append((Hm, meta.lost, getattr(meta, "H_local_cur2init", None)))
+            reused.append(bool(meta.lost and trk.flower.source_features_reused))
+        assert [r[1] for r in res] == [t in lost_at for t in range(len(frames))]
+        assert reused == [reuse == "1" and t in (2, 3) for t in range(len(frames))], reused
+        outs[reuse] = res
+    for a, b in zip(outs["1"], outs["0"]):
+        assert np.array_equal(a[0], b[0]) and a[1] == b[1]
+        assert (a[2] is None) == (b[2] is None) and (a[2] is None or np.array_equal(a[2], b[2]))
 
 
 @pytest.mark.parametrize("name,cfg", [("woft", "WOFT.py"), ("lost", "WOFT.py"), ("irls", "WOFT_IRLS.py"),

@@ -685,15 +685,27 @@ class _Plan:
     def load_image(self, slot, img_u8, pad_top, pad_left):
         ops.preprocess(img_u8, self.img[slot], self.hp, self.wp, pad_top, pad_left)
 
-    def encode_source(self):
-        """fmap1, net, inp of the source image in img[0] (cacheable across frames)."""
-        self.run(self.prog_f_src)
+    def encode_source(self, reuse_target=False):
+        """fmap1, net, inp of the source image in img[0] (cacheable across frames).
+        reuse_target: the source image IS the target image of this plan's previous flow() (consecutive lost frames: frame t was the
+        target of the t-1 -> t flow and is the source of the t -> t+1 flow, TRK:181-184) -- its feature map is this plan's level-0
+        target map: copied (fp32 map + correlation operand, two device copies) instead of a second fnet pass over the same image by
+        the same launch program (bit-identical).  Volume-free correlation only (the volume mode keeps the target operand in
+        4x4-tile order); -> whether the features were reused."""
+        reused = bool(reuse_target) and self.otf and getattr(self, "target_valid", False)
+        if reused:
+            self.f1rows[:self.P].copy_(self.f2act[0].t.view(self.P, -1))
+            if self.prec != "fp32":
+                self.f1s[:self.P].copy_(self.f2s[0])
+        else:
+            self.run(self.prog_f_src)
         self.run(self.prog_c_src)
-        if self.prec != "fp32":
+        if self.prec != "fp32" and not reused:
             self._split(self.f1rows, self.f1s)
         if self.gate_bias is not None:
             self.inp_c.t.copy_(self.xbuf.t[:, :self.eng.spec.cdim])
             self.run(self.prog_gate_bias)
+        return reused
 
     def flow(self, iters, crop, h, w, flow_up=None, dst=None, wout=None, do_sigmoid=False, trace=None, defer_wh=False):
         """Target features -> volume -> `iters` refinements -> full-resolution outputs.
@@ -704,6 +716,7 @@ class _Plan:
             raise ValueError("iters must be >= 1")
         self.run(self.prog_f_dst)
         self.run(self.prog_volume)
+        self.target_valid = True                             # (level-0 target map + operand now belong to the image in img[1])
         off = sp.flow_off
         ops.coords_init(self.coords, self.hf, self.wf, self.flow4.t, self.xbuf.t[:, off:], self.xbuf.cs)
         last = getattr(self, "prog_iter_last", None) if iters > 1 else None

@@ -106,6 +106,8 @@ class RAFTWrapper:
         self.defer_min_ratio = 6           # defer_weights: region windows per named pixel from which deferring pays
         self._out = {}
         self._cache_errors = set()
+        self._last_dst = {}                # per buffer set: (id of the last dst_img object, padding geometry)
+        self.source_features_reused = False
 
     def _run_flow(self, plan, iters, crop, oh, ow, o, weighted, do_sigmoid, defer_wh=False, want_flow=True):
         """plan.flow() eagerly, or -- use_graph -- as ONE hipGraph launch (captured at the second call with the same
@@ -244,7 +246,8 @@ class RAFTWrapper:
         return own(o["src"]), own(o["dst"]), (own(weights) if weights is not None else None)
 
     def compute_flow(self, src_img, dst_img, mode="TC", vis=False, src_img_identifier=None,
-                     numpy_out=False, do_sigmoid=False, borrow=False, defer_weights=False, weight_region=False):
+                     numpy_out=False, do_sigmoid=False, borrow=False, defer_weights=False, weight_region=False,
+                     src_is_previous_dst=False):
         """src_img / dst_img: (H, W, 3) uint8 BGR (numpy, or CUDA tensors already on the device).
         mode 'TC' -> (src_coords (2,HW) int64, dst_coords (2,HW) f32, weights (1,HW) f32 | None)
         mode 'flow' -> (flow (2,H,W), weights (1,H,W) | None).
@@ -292,7 +295,11 @@ class RAFTWrapper:
         else:
             s = up(src_img)
             plan.load_image(0, s, top, left)
-            plan.encode_source()
+            # src_is_previous_dst (extension, the shim's tracker on consecutive lost frames): the caller states that src_img is the
+            # image it passed as dst_img in its previous call for this buffer set; honoured only when that is the very same object
+            # and geometry -- then the source features are the previous call's target features (engine.encode_source)
+            reuse = bool(src_is_previous_dst) and self._last_dst.get(id(plan)) == (id(src_img), key)
+            self.source_features_reused = bool(plan.encode_source(reuse_target=reuse))
             plan.source_tag = self if pinned_here else None
             if pinned_here:
                 self._pinned_key = key
@@ -310,6 +317,7 @@ class RAFTWrapper:
         plan.set_weight_region(region)
         d = up(dst_img)
         plan.load_image(1, d, top, left)
+        self._last_dst[id(plan)] = (id(dst_img), key)         # (what this buffer set's target features will belong to after this call)
         o = self._outputs(oh, ow)
         weighted = self.C.raft_type == "weighted"
         # (defer_weights = the number of pixels the caller will name: worth it only if their 3x3 supports cannot cover most

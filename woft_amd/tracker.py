@@ -134,6 +134,8 @@ class YAOFTrackerSingleControl:
         self._sparse_weights = False
         self._replay = None
         self._announced = False
+        self._local_chain = None          # (target frame object, frame number) of the last frame t-1 -> t flow
+        self._n_tracked = 0
         self._upload = _FrameUploader()
         self.host_wait_s = 0.0       # seconds this tracker's thread spent blocked on the per-flow result read (device back end)
 
@@ -193,6 +195,7 @@ class YAOFTrackerSingleControl:
         assert _count_components(inside) == 1                        # TRK:36-37 (single contour)
         self.template_img = img
         self.np_template_mask = mask_np
+        self._local_chain = None
         self.template_mask = torch.from_numpy(inside).to(self.device)
         self._template_mask_u8 = torch.from_numpy(inside.astype(np.uint8) * 255).to(self.device)
         if hasattr(self.flower, "pin_source"):
@@ -251,6 +254,7 @@ class YAOFTrackerSingleControl:
             return H_cur2init, meta
 
         meta = SimpleNamespace()
+        self._n_tracked += 1
         if self.C.no_prewarp_after_N and self.N_lost > self.C.no_prewarp_after_N:
             self.last_good_H2init = _EYE.copy()                      # TRK:78-79
         meta.last_good_H2init = self.last_good_H2init.copy()
@@ -300,7 +304,7 @@ class YAOFTrackerSingleControl:
             self.last_good_H2init = H.copy()
 
     # ---- the two flow stages ------------------------------------------------------------------------
-    def _flow(self, src, dst):
+    def _flow(self, src, dst, src_is_previous_dst=False):
         """-> (grid coords (2, n) int64, target coords (2, n) f32, weights (1, n) f32 | None, (gh, gw)); borrowed
         buffers of the provider: consumed before the next flow."""
         # (borrowed buffers, and -- only for THIS caller -- weights restricted to the region pinned in init(): a direct
@@ -310,6 +314,8 @@ class YAOFTrackerSingleControl:
             # both stages: the template flow on its mask region, the frame t-1 -> t flow of a lost frame on the pixels of
             # the carried mask (TRK:314-327) -- either way only the drawn correspondences' weights are read (_solve_device)
             kw["defer_weights"] = int(self._fused["n_draw"])
+        if src_is_previous_dst and "borrow" in kw:
+            kw["src_is_previous_dst"] = True
         src_xy, dst_xy, w = self.flower.compute_flow(src, dst, mode="TC", vis=False, src_img_identifier=None,
                                                      do_sigmoid=True, **kw)
         s = getattr(self.flower, "last_flow_shape", None)
@@ -341,7 +347,12 @@ class YAOFTrackerSingleControl:
         """Frame t-1 -> frame t, chained onto the previous pose (TRK:171-207).  Kept: correspondences that start in
         the template mask carried to frame t-1 (nearest-neighbour warp by inv(prev_H2init), TRK:314-327).  A failed
         fit keeps the previous pose."""
-        src_xy, dst_xy, w, grid = self._flow(self.prev_img, frame)
+        # consecutive lost frames: frame t-1 was the TARGET of the previous local flow and is the SOURCE of this one -- the provider
+        # then takes its feature map from that flow instead of encoding the same image again (identical values)
+        chained = (self._local_chain is not None and self._local_chain[0] is self.prev_img and self._local_chain[1] == self._n_tracked - 1
+                   and os.environ.get("WOFT_LOCAL_REUSE", "1") != "0")
+        src_xy, dst_xy, w, grid = self._flow(self.prev_img, frame, src_is_previous_dst=chained)
+        self._local_chain = (frame, self._n_tracked)
         if np.array_equal(self.prev_H2init, _EYE):
             prev_mask = self._template_mask_u8
         else:
