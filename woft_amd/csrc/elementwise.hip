@@ -71,12 +71,20 @@ __global__ __launch_bounds__(FIN_T) void inorm_finalize_kernel(const float* __re
             ws[(int64_t)g * 2 * FIN_MAXC + FIN_MAXC + c] = tb;
         }
         int* ticket = (int*)(ws + (int64_t)FIN_MAXG * 2 * FIN_MAXC);
-        __threadfence();                                 // release (agent scope): this workgroup's partial row is visible ...
+        // Hand-off to the last workgroup, the guide's counter form (Guideline 16): every wave's stores acknowledged -> barrier ->
+        // ONE lane: agent-scope release (writes back this XCD's L2) -> wait -> relaxed ticket; the workgroup that draws the last
+        // ticket: ONE agent-scope acquire (invalidates this CU's L1) -> barrier -> plain loads.  (Round 6: was __threadfence() by all
+        // 256 threads on both sides -- 2-4 x one lane's cost; this kernel runs 16 times per encoder pass, 1.75 % of a frame.)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (threadIdx.x == 0) s_last = (atomicAdd(ticket, 1) == G - 1);      // ... before its ticket is
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (restated where the compiler cannot drop it: guide, pitfall 12)
+            s_last = (__hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == G - 1);
+            if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
         __syncthreads();
         if (!s_last) return;
-        __threadfence();                                 // acquire: the other workgroups' rows
         if (threadIdx.x == 0) *ticket = 0;               // ready for the next call on this stream
         // total of the G partial rows, fixed order: slice sl of the workgroup takes the rows sl, sl + nsl, ... of channel cc
         // (loads of a thread are independent: issued in batches), then the slices in order
